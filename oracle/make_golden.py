@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE implementation (build container only).
+
+Imports the reference's own `model/` and `preprocessing/graph_construction` packages from
+/root/reference/MinGraph-UNet (they never travel to the GPU box), feeds them the formula
+weights / inputs of oracle/mgunet_oracle.py, checks that the oracle restatement agrees, and
+stores the reference's outputs as small fixtures.  Fixtures hold data only (inputs that are
+not formula-derivable, expected outputs, sample indices) -- never reference source text.
+
+Usage:  python oracle/make_golden.py [--only tiny,gat,graph,c1,c2,c4,c5]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference/MinGraph-UNet"
+sys.path.insert(0, HERE)
+sys.path.insert(0, REF)
+
+import mgunet_oracle as O  # noqa: E402
+from model.unet.unet_model import UNet as RefUNet  # noqa: E402
+from model.gat.graph_attention import GATNetwork as RefGAT, MultiHeadGATLayer as RefMH  # noqa: E402
+from preprocessing.graph_construction.patch_graph_construction import PatchGraphConstructor as RefPGC  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+TOL = 1e-5
+
+
+def sample_idx(name, numel, n=4096):
+    u = O.formula_uniform(name, (n,), 0.0, 1.0, 7).astype(np.float64)
+    return np.minimum((u * numel).astype(np.int64), numel - 1)
+
+
+def ref_unet(cfg, params, train=False):
+    m = RefUNet(*cfg)
+    m.load_state_dict(params)
+    return m.train() if train else m.eval()
+
+
+def check(name, a, b, tol=TOL):
+    d = float((a - b).abs().max()) if a.numel() else 0.0
+    print(f"   oracle-vs-reference {name}: max|d|={d:.3e} (max|ref|={float(b.abs().max()) if b.numel() else 0:.3f})")
+    assert d <= tol, (name, d)
+
+
+def save(fname, **arrs):
+    path = os.path.join(GOLD, fname)
+    np.savez_compressed(path, **arrs)
+    print(f"   wrote {fname}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def gen_tiny():
+    print("[tiny] UNet(1,2,8,2) @1x1x32x32 eval + train; UNet(3,3,8,2) @2x3x37x45 (odd: pad + floor pool)")
+    out = {}
+    for tag, cfg, shape in (("a", (1, 2, 8, 2), (1, 1, 32, 32)), ("b", (3, 3, 8, 2), (2, 3, 37, 45)),
+                            ("c", (3, 2, 8, 3), (2, 3, 64, 48))):
+        p = O.make_unet_params(*cfg, seed=11)
+        x = torch.from_numpy(O.formula_normal(f"tiny/{tag}/x", shape, seed=11))
+        m = ref_unet(cfg, p)
+        with torch.no_grad():
+            lg, sk, ft = m(x)
+            olg, osk, oft = O.unet_forward(p, x, cfg[3])
+        check(f"{tag}.logits", olg, lg)
+        for i in range(cfg[3]):
+            check(f"{tag}.skip{i}", osk[i], sk[i])
+            check(f"{tag}.feat{i}", oft[i], ft[i])
+        out[f"{tag}_logits"] = lg.numpy()
+        for i in range(cfg[3]):
+            out[f"{tag}_skip{i}"] = sk[i].numpy()
+            out[f"{tag}_feat{i}"] = ft[i].numpy()
+        # train-mode forward: batch statistics + running-stat update (unet_encoder.py:12-13)
+        mt = ref_unet(cfg, p, train=True)
+        with torch.no_grad():
+            lgt, _, _ = mt(x)
+            stats = {}
+            olgt, _, _ = O.unet_forward(p, x, cfg[3], training=True, new_stats=stats)
+        check(f"{tag}.train_logits", olgt, lgt, 2e-5)
+        sd = mt.state_dict()
+        for k, v in stats.items():
+            check(f"{tag}.{k}", v, sd[k])
+        out[f"{tag}_train_logits"] = lgt.numpy()
+        out[f"{tag}_bn_rm_last"] = sd["decoder.decoder_blocks.%d.conv_block.bn2.running_mean" % (cfg[3] - 1)].numpy()
+        out[f"{tag}_bn_rv_last"] = sd["decoder.decoder_blocks.%d.conv_block.bn2.running_var" % (cfg[3] - 1)].numpy()
+        out[f"{tag}_bn_rm_first"] = sd["encoder.encoder_blocks.0.bn1.running_mean"].numpy()
+        out[f"{tag}_bn_rv_first"] = sd["encoder.encoder_blocks.0.bn1.running_var"].numpy()
+    save("unet_tiny.npz", **out)
+
+
+# graph_attention.py:209-210 -- the module's own 10-node / 18-edge smoke fixture (data)
+EDGE10 = np.array([[0, 1, 1, 2, 2, 3, 3, 0, 4, 5, 5, 6, 7, 8, 8, 9, 9, 4],
+                   [1, 0, 2, 1, 3, 2, 0, 3, 5, 4, 6, 5, 8, 7, 9, 8, 4, 9]], dtype=np.int64)
+
+
+def gen_gat():
+    print("[gat] 10-node fixture, isolated targets, wide-logit, concat layer, 2-layer/1-head")
+    out = {"edge10": EDGE10}
+
+    def run(tag, cfg, X, ei, scale=1.0, layers=1):
+        p = O.make_gat_params(cfg[0], cfg[1], cfg[2], cfg[3], layers, seed=3, scale=scale)
+        g = RefGAT(cfg[0], cfg[1], cfg[2], cfg[3], num_gat_layers=layers).eval()
+        g.load_state_dict(p)
+        with torch.no_grad():
+            y = g(X, torch.from_numpy(ei))
+            oy = O.gat_network_forward(p, X, torch.from_numpy(ei), cfg[3], layers)
+        check(tag, oy, y)
+        out[tag + "_out"] = y.numpy()
+
+    X10 = torch.from_numpy(O.formula_normal("gat/x10", (10, 32), seed=3))
+    run("g10", (32, 64, 16, 4), X10, EDGE10)
+    # isolated targets: nodes 10,11 have no in-edges (rows must be exactly elu(0)=0); node 11 has no edges at all
+    ei_iso = np.concatenate([EDGE10, np.array([[10, 10], [0, 3]], dtype=np.int64)], axis=1)
+    X12 = torch.from_numpy(O.formula_normal("gat/x12", (12, 32), seed=3))
+    out["edge_iso"] = ei_iso
+    run("iso", (32, 64, 16, 4), X12, ei_iso)
+    # wide-logit case: |e| range > 23 so the +1e-10 and the GLOBAL max bite (graph_attention.py:86,96)
+    Xw = torch.from_numpy(O.formula_normal("gat/xw", (10, 32), seed=4)) * 4.0
+    run("wide", (32, 64, 16, 2), Xw, EDGE10, scale=3.0)
+    p = O.make_gat_params(32, 64, 16, 2, 1, seed=3, scale=3.0)
+    with torch.no_grad():
+        h = Xw @ p["gat_layers.0.heads.0.W.weight"].t()
+        e = torch.nn.functional.leaky_relu(torch.cat([h[EDGE10[0]], h[EDGE10[1]]], 1) @ p["gat_layers.0.heads.0.a.weight"].t(), 0.2)
+    print(f"   wide case: e range [{float(e.min()):.1f}, {float(e.max()):.1f}]")
+    assert float(e.max() - e.min()) > 23
+    # moderate range (~25-60): every edge still contributes, the global max shifts per-target sums by many e-folds
+    Xm = torch.from_numpy(O.formula_normal("gat/xm", (10, 32), seed=6)) * 2.0
+    run("mid", (32, 64, 16, 4), Xm, EDGE10, scale=1.5)
+    # 2 layers, 1 head (the only multi-layer shape the reference can run: SURVEY G3)
+    run("l2h1", (32, 24, 8, 1), X10, EDGE10, layers=2)
+    # MultiHeadGATLayer(concat=True) directly: graph_attention.py:153-155
+    mh = RefMH(32, 64, 4, 0.1, 0.2, concat=True).eval()
+    pc = {}
+    for h_ in range(4):
+        for nm, shp in ((f"heads.{h_}.W.weight", (16, 32)), (f"heads.{h_}.a.weight", (1, 32))):
+            a = 1.414 * float(np.sqrt(6.0 / (shp[0] + shp[1])))
+            pc[nm] = torch.from_numpy(O.formula_uniform("mhc/" + nm, shp, -a, a, 5))
+    mh.load_state_dict(pc)
+    with torch.no_grad():
+        yc = mh(X10, torch.from_numpy(EDGE10))
+        oc = torch.cat([O.gat_head_forward(X10, torch.from_numpy(EDGE10), pc[f"heads.{k}.W.weight"],
+                                           pc[f"heads.{k}.a.weight"]) for k in range(4)], 1)
+    check("mh_concat", oc, yc)
+    out["mhc_out"] = yc.numpy()
+    save("gat_small.npz", **out)
+
+
+def gen_graph():
+    print("[graph] COO index maps: 128^2/p32, 130x140/p32, 512^2/p16, 1024^2/p16, 16x16/p16 (empty)")
+    out = {}
+    for tag, (H, W, p) in {"g128": (128, 128, 32), "g130": (130, 140, 32), "g512": (512, 512, 16),
+                           "g1024": (1024, 1024, 16), "g1": (16, 16, 16), "grow": (16, 80, 16)}.items():
+        pgc = RefPGC(p)
+        nph, npw = O.patch_grid(H, W, p)
+        feats = torch.zeros(nph * npw, 1)
+        _, ei = pgc.construct_patch_graph(torch.zeros(1, H, W), feats)
+        oe = O.patch_graph_edges(H, W, p)
+        assert ei.dtype == torch.int64 and tuple(ei.shape) == oe.shape, (ei.shape, oe.shape)
+        assert np.array_equal(ei.numpy(), oe), tag
+        print(f"   {tag}: nodes={nph*npw} edges={oe.shape[1]} bit-exact")
+        out[tag] = ei.numpy()
+    # image_to_patches + patch-mean on a non-divisible image
+    img = torch.from_numpy(O.formula_normal("graph/img", (5, 37, 45), seed=2))
+    pt, (nph, npw) = RefPGC(16).image_to_patches(img)
+    opt, (onh, onw) = O.image_to_patches(img, 16)
+    assert (nph, npw) == (onh, onw) and torch.equal(pt, opt)
+    out["patches_37x45_mean"] = pt.mean(dim=(2, 3)).numpy()
+    save("patch_graph.npz", **out)
+
+
+def checksums(ts):
+    return np.array([[float(t.double().sum()), float(t.double().abs().sum())] for t in ts], dtype=np.float64)
+
+
+def gen_c1():
+    print("[c1] UNet(1,2,32,4) @1x1x256x256 eval")
+    cfg = (1, 2, 32, 4)
+    p = O.make_unet_params(*cfg, seed=0)
+    x = torch.from_numpy(O.formula_normal("c1/x", (1, 1, 256, 256), seed=0))
+    with torch.no_grad():
+        lg, sk, ft = ref_unet(cfg, p)(x)
+        olg, _, _ = O.unet_forward(p, x, 4)
+    check("c1.logits", olg, lg)
+    idx = sample_idx("c1/idx", lg.numel())
+    save("c1.npz", idx=idx, logits=lg.reshape(-1)[idx].numpy(), sums=checksums([lg] + sk + ft))
+
+
+def gen_c2():
+    print("[c2] UNet(3,2,32,4) @8x3x512x512 eval + patch-mean + GAT(32,128,64,4,1)")
+    cfg = (3, 2, 32, 4)
+    p = O.make_unet_params(*cfg, seed=0)
+    m = ref_unet(cfg, p)
+    gp = O.make_gat_params(32, 128, 64, 4, 1, seed=0)
+    g = RefGAT(32, 128, 64, 4, 1).eval()
+    g.load_state_dict(gp)
+    ei = torch.from_numpy(O.patch_graph_edges(512, 512, 16))
+    out = {}
+    sums = []
+    for b in range(8):
+        x = torch.from_numpy(O.formula_normal(f"c2/x/{b}", (1, 3, 512, 512), seed=1))
+        t0 = time.time()
+        with torch.no_grad():
+            lg, sk, ft = m(x)
+            X = O.patch_mean_features(ft[0][0], 16)
+            y = g(X, ei)
+            if b == 0:
+                olg, _, oft = O.unet_forward(p, x, 4)
+                check("c2.logits[0]", olg, lg)
+                check("c2.gat[0]", O.gat_network_forward(gp, X, ei, 4), y)
+        idx = sample_idx(f"c2/idx/{b}", lg.numel(), 1024)
+        gidx = sample_idx(f"c2/gidx/{b}", y.numel(), 512)
+        out[f"logits_{b}"] = lg.reshape(-1)[idx].numpy()
+        out[f"idx_{b}"] = idx
+        out[f"gat_{b}"] = y.reshape(-1)[gidx].numpy()
+        out[f"gidx_{b}"] = gidx
+        sums.append(checksums([lg] + sk + ft + [X, y]))
+        print(f"   image {b}: {time.time()-t0:.1f}s  max|logit|={float(lg.abs().max()):.3f} max|gat|={float(y.abs().max()):.3f}")
+    out["sums"] = np.stack(sums)
+    save("c2.npz", **out)
+
+
+def gen_c4():
+    print("[c4] synthetic 2048-node in-degree-8 graph, GAT(64,128,64,4,1); 3 images of 1024^2 U-Net")
+    N, deg = 2048, 8
+    u = O.formula_uniform("c4/src", (N * deg,), 0.0, 1.0, 3).astype(np.float64)
+    src = np.minimum((u * N).astype(np.int64), N - 1)
+    ei = np.stack([src, np.repeat(np.arange(N, dtype=np.int64), deg)])
+    X = torch.from_numpy(O.formula_normal("c4/X", (N, 64), seed=3))
+    gp = O.make_gat_params(64, 128, 64, 4, 1, seed=0)
+    g = RefGAT(64, 128, 64, 4, 1).eval()
+    g.load_state_dict(gp)
+    with torch.no_grad():
+        y = g(X, torch.from_numpy(ei))
+        check("c4.gat", O.gat_network_forward(gp, X, torch.from_numpy(ei), 4), y)
+    out = {"gat_out": y.numpy()}
+    cfg = (3, 2, 32, 4)
+    p = O.make_unet_params(*cfg, seed=0)
+    m = ref_unet(cfg, p)
+    for b in (0, 31):
+        x = torch.from_numpy(O.formula_normal(f"c4/x/{b}", (1, 3, 1024, 1024), seed=2))
+        t0 = time.time()
+        with torch.no_grad():
+            lg, _, _ = m(x)
+        idx = sample_idx(f"c4/idx/{b}", lg.numel(), 1024)
+        out[f"logits_{b}"] = lg.reshape(-1)[idx].numpy()
+        out[f"idx_{b}"] = idx
+        print(f"   image {b}: {time.time()-t0:.1f}s max|logit|={float(lg.abs().max()):.3f}")
+    save("c4.npz", **out)
+
+
+def gen_c5():
+    print("[c5] train step UNet(3,2,32,4) on a 2x3x128x128 shard and a 4x3x512x512 shard: CE + Adam(1e-3, wd 1e-4)")
+    cfg = (3, 2, 32, 4)
+    out = {}
+    for tag, shape in (("s", (2, 3, 128, 128)), ("f", (4, 3, 512, 512))):
+        p = O.make_unet_params(*cfg, seed=0)
+        x = torch.from_numpy(O.formula_normal(f"c5/{tag}/x", shape, seed=4))
+        y = torch.from_numpy(O.formula_labels(f"c5/{tag}/y", (shape[0], shape[2], shape[3]), 2, seed=5))
+        m = ref_unet(cfg, p, train=True)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4)  # train_segmentation.py:96
+        t0 = time.time()
+        opt.zero_grad()
+        lg, _, _ = m(x)
+        loss = torch.nn.CrossEntropyLoss()(lg, y)  # train_segmentation.py:91,127
+        loss.backward()
+        grads = {k: v.grad.detach().clone() for k, v in m.named_parameters()}
+        opt.step()
+        print(f"   [{tag}] reference step {time.time()-t0:.1f}s loss={float(loss):.6f}")
+        oloss, og, onew, ostats, _, _ = O.train_step(p, x, y, 4)
+        assert abs(float(oloss) - float(loss)) <= 1e-5 * abs(float(loss)), (float(oloss), float(loss))
+        sd = m.state_dict()
+        names = list(grads.keys())
+        gn = []
+        for k in names:
+            rn = float(grads[k].norm())
+            dn = float((og[k] - grads[k]).norm())
+            assert dn <= 2e-3 * rn + 1e-7, (k, dn, rn)
+            dp = float((onew[k] - sd[k]).abs().max())
+            assert dp <= 2e-5, (k, dp)  # Adam normalises: |step| ~ lr
+            gn.append(rn)
+        for k, v in ostats.items():
+            assert float((v - sd[k]).abs().max()) <= 1e-5, k
+        out[f"{tag}_loss"] = np.float64(float(loss))
+        out[f"{tag}_grad_norms"] = np.array(gn, dtype=np.float64)
+        flat_g = torch.cat([grads[k].reshape(-1) for k in names])
+        flat_p = torch.cat([sd[k].reshape(-1) for k in names])
+        idx = sample_idx(f"c5/{tag}/idx", flat_g.numel(), 4096)
+        out[f"{tag}_idx"] = idx
+        out[f"{tag}_grad_s"] = flat_g[idx].numpy()
+        out[f"{tag}_param_s"] = flat_p[idx].numpy()
+        out[f"{tag}_bn_rm"] = sd["encoder.encoder_blocks.0.bn1.running_mean"].numpy()
+        out[f"{tag}_bn_rv"] = sd["encoder.encoder_blocks.0.bn1.running_var"].numpy()
+        out[f"{tag}_bn_rm_b"] = sd["encoder.bottleneck.bn2.running_mean"].numpy()
+        out[f"{tag}_bn_rv_b"] = sd["encoder.bottleneck.bn2.running_var"].numpy()
+    out["param_names"] = np.array(names)
+    save("c5.npz", **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="tiny,gat,graph,c1,c2,c4,c5")
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    fns = {"tiny": gen_tiny, "gat": gen_gat, "graph": gen_graph, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
+    for k in a.only.split(","):
+        t0 = time.time()
+        fns[k]()
+        print(f"   ({time.time()-t0:.1f}s)")
+
+
+if __name__ == "__main__":
+    main()

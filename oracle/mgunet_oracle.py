@@ -1,0 +1,360 @@
+"""CPU oracle for the MinGraph-UNet hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (torch-functional + numpy, no reference imports) of the
+algorithms on the north-star path of agent-charon/MinGraph-UNet.  It exists so that the HIP
+path can be checked on a box where the reference's Python does not exist.  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it; the product
+(`mingraph-unet_amd/`) never does.
+
+Parity status: PINNED.  `oracle/make_golden.py` (run in the build container, where
+`/root/reference` is importable) loads the same formula weights into the reference's own
+`model.unet.unet_model.UNet`, `model.gat.graph_attention.GATNetwork` and
+`preprocessing.graph_construction.patch_graph_construction.PatchGraphConstructor`, asserts
+this restatement agrees (<= 1e-5 abs on O(1) logits; index maps bit-exact) and writes the
+reference's outputs to `tests/golden/`.  `tests/test_oracle_golden.py` re-checks this file against
+those fixtures on every run.  The reference's own tests hold no numeric expectations
+(SURVEY.md section 4), so the fixtures generated from the reference are the pin.
+
+All citations are relative to /root/reference/MinGraph-UNet/.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# Formula ("counter based") tensors: identical on every box, no torch RNG involved.
+# --------------------------------------------------------------------------------------
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _mix64(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint64, copy=True)
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(30)
+        x *= _M1
+        x ^= x >> np.uint64(27)
+        x *= _M2
+        x ^= x >> np.uint64(31)
+    return x
+
+
+def _key(name: str, seed: int) -> np.uint64:
+    return np.uint64((zlib.crc32(name.encode()) << 32) ^ (seed & 0xFFFFFFFF))
+
+
+def formula_uniform(name: str, shape, lo: float = 0.0, hi: float = 1.0, seed: int = 0) -> np.ndarray:
+    """float32 array of `shape`, element i = lo + (hi-lo) * U(hash(name, seed, i))."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = _mix64(idx * _GOLD + _key(name, seed))
+    u = (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+def formula_normal(name: str, shape, seed: int = 0) -> np.ndarray:
+    """float32 N(0,1) by Box-Muller on two formula uniforms."""
+    u1 = formula_uniform(name + "/u1", shape, 0.0, 1.0, seed).astype(np.float64)
+    u2 = formula_uniform(name + "/u2", shape, 0.0, 1.0, seed).astype(np.float64)
+    u1 = np.maximum(u1, 1e-12)
+    return (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)).astype(np.float32)
+
+
+def formula_labels(name: str, shape, num_classes: int, seed: int = 0) -> np.ndarray:
+    u = formula_uniform(name, shape, 0.0, 1.0, seed)
+    return np.minimum((u * num_classes).astype(np.int64), num_classes - 1)
+
+
+# --------------------------------------------------------------------------------------
+# U-Net parameters (state_dict names of model/unet/unet_model.py:18-19, dumped in SURVEY 8b)
+# --------------------------------------------------------------------------------------
+def _convblock_shapes(prefix, cin, cout, out):
+    # model/unet/unet_encoder.py:7-13 (registration order: conv1, conv2, bn1, bn2)
+    out[prefix + "conv1.weight"] = (cout, cin, 3, 3)
+    out[prefix + "conv1.bias"] = (cout,)
+    out[prefix + "conv2.weight"] = (cout, cout, 3, 3)
+    out[prefix + "conv2.bias"] = (cout,)
+    for bn in ("bn1", "bn2"):
+        out[prefix + bn + ".weight"] = (cout,)
+        out[prefix + bn + ".bias"] = (cout,)
+        out[prefix + bn + ".running_mean"] = (cout,)
+        out[prefix + bn + ".running_var"] = (cout,)
+        out[prefix + bn + ".num_batches_tracked"] = ()
+
+
+def unet_param_shapes(in_channels=3, num_classes=2, init_features=32, depth=4) -> "OrderedDict[str, tuple]":
+    """state_dict() key -> shape, in the reference's registration order."""
+    out: "OrderedDict[str, tuple]" = OrderedDict()
+    feats, cin = init_features, in_channels
+    for i in range(depth):  # unet_encoder.py:46-50
+        _convblock_shapes(f"encoder.encoder_blocks.{i}.", cin, feats, out)
+        cin, feats = feats, feats * 2
+    _convblock_shapes("encoder.bottleneck.", cin, feats, out)  # unet_encoder.py:53
+    prev = init_features * (2 ** depth)
+    for bi, i in enumerate(reversed(range(depth))):  # unet_decoder.py:103-114
+        c = init_features * (2 ** i)
+        p = f"decoder.decoder_blocks.{bi}."
+        out[p + "upsample.weight"] = (prev, prev // 2, 2, 2)  # ConvTranspose2d: (Cin, Cout, 2, 2)
+        out[p + "upsample.bias"] = (prev // 2,)
+        _convblock_shapes(p + "conv_block.", c + prev // 2, c, out)
+        prev = c
+    out["decoder.final_conv.weight"] = (num_classes, prev, 1, 1)  # unet_decoder.py:117
+    out["decoder.final_conv.bias"] = (num_classes,)
+    return out
+
+
+def make_unet_params(in_channels=3, num_classes=2, init_features=32, depth=4, seed=0) -> "OrderedDict[str, torch.Tensor]":
+    """Formula weights scaled so activations stay O(1) through the net (SURVEY 8d 'Weights')."""
+    params: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in unet_param_shapes(in_channels, num_classes, init_features, depth).items():
+        if name.endswith("num_batches_tracked"):
+            params[name] = torch.zeros((), dtype=torch.int64)
+            continue
+        if name.endswith("conv1.weight") or name.endswith("conv2.weight") or name.endswith("final_conv.weight"):
+            fan_in = shape[1] * shape[2] * shape[3]
+            a = 0.9 * float(np.sqrt(6.0 / fan_in))  # 0.9: keeps |logit| ~ 1.5 mean / 8 max at 512^2
+            arr = formula_uniform(name, shape, -a, a, seed)
+        elif name.endswith("upsample.weight"):
+            a = float(np.sqrt(6.0 / shape[0]))  # each output pixel sees Cin inputs through one tap
+            arr = formula_uniform(name, shape, -a, a, seed)
+        elif ".bn" in name and name.endswith(".weight"):
+            arr = formula_uniform(name, shape, 0.5, 1.5, seed)
+        elif name.endswith("running_var"):
+            arr = formula_uniform(name, shape, 0.5, 1.5, seed)
+        elif name.endswith("running_mean"):
+            arr = formula_uniform(name, shape, -0.2, 0.2, seed)
+        elif ".bn" in name and name.endswith(".bias"):
+            arr = formula_uniform(name, shape, -0.2, 0.2, seed)
+        else:  # conv / upsample / final biases
+            arr = formula_uniform(name, shape, -0.1, 0.1, seed)
+        params[name] = torch.from_numpy(arr)
+    return params
+
+
+# --------------------------------------------------------------------------------------
+# U-Net forward (model/unet/*.py)
+# --------------------------------------------------------------------------------------
+def _conv_block(p, prefix, x, training, momentum, eps, new_stats):
+    """ConvBlock.forward, model/unet/unet_encoder.py:15-25 (conv1-bn1-relu-conv2-bn2-relu)."""
+    for c, bn in (("conv1", "bn1"), ("conv2", "bn2")):
+        x = F.conv2d(x, p[prefix + c + ".weight"], p[prefix + c + ".bias"], padding=1)  # :7-8
+        rm, rv = p[prefix + bn + ".running_mean"], p[prefix + bn + ".running_var"]
+        if training:
+            rm, rv = rm.clone(), rv.clone()
+        x = F.batch_norm(x, rm, rv, p[prefix + bn + ".weight"], p[prefix + bn + ".bias"],
+                         training=training, momentum=momentum, eps=eps)  # :12-13 defaults
+        if training and new_stats is not None:
+            new_stats[prefix + bn + ".running_mean"] = rm
+            new_stats[prefix + bn + ".running_var"] = rv
+        x = F.relu(x)  # :9
+    return x
+
+
+def unet_forward(p, x, depth=4, training=False, momentum=0.1, eps=1e-5, new_stats=None):
+    """UNet.forward, model/unet/unet_model.py:34-36.
+
+    Returns (logits, skips shallow->deep, decoder feats shallow->deep) exactly as the
+    reference's 3-tuple.  `new_stats` (dict) receives updated BN running stats in training.
+    """
+    skips = []
+    cur = x
+    for i in range(depth):  # unet_encoder.py:67-70
+        cur = _conv_block(p, f"encoder.encoder_blocks.{i}.", cur, training, momentum, eps, new_stats)
+        skips.append(cur)
+        cur = F.max_pool2d(cur, kernel_size=2, stride=2)  # :48
+    cur = _conv_block(p, "encoder.bottleneck.", cur, training, momentum, eps, new_stats)  # :72
+    feats = []
+    for bi in range(depth):  # unet_decoder.py:139-141
+        skip = skips[depth - 1 - bi]  # reversed_skips, :134
+        pre = f"decoder.decoder_blocks.{bi}."
+        up = F.conv_transpose2d(cur, p[pre + "upsample.weight"], p[pre + "upsample.bias"], stride=2)  # :36
+        dy, dx = skip.shape[2] - up.shape[2], skip.shape[3] - up.shape[3]  # :41-42
+        up = F.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])  # :46-47
+        cur = torch.cat([skip, up], dim=1)  # :53 skip FIRST
+        cur = _conv_block(p, pre + "conv_block.", cur, training, momentum, eps, new_stats)  # :55
+        feats.append(cur)
+    logits = F.conv2d(cur, p["decoder.final_conv.weight"], p["decoder.final_conv.bias"])  # :143
+    return logits, skips, feats[::-1]  # :149
+
+
+def unet_flops(in_channels, num_classes, init_features, depth, H, W) -> float:
+    """2*MAC count of the convolutions only, per image."""
+    fl, cin, f, h, w = 0.0, in_channels, init_features, H, W
+    dims = []
+    for _ in range(depth):
+        fl += 2.0 * h * w * 9 * (cin * f + f * f)
+        dims.append((h, w, f))
+        cin, f, h, w = f, f * 2, h // 2, w // 2
+    fl += 2.0 * h * w * 9 * (cin * f + f * f)
+    prev = f
+    for i in reversed(range(depth)):
+        sh, sw, c = dims[i]
+        fl += 2.0 * h * w * prev * (prev // 2) * 4  # convT 2x2 s2
+        h, w = sh, sw
+        fl += 2.0 * h * w * 9 * ((c + prev // 2) * c + c * c)
+        prev = c
+    fl += 2.0 * h * w * prev * num_classes
+    return fl
+
+
+# --------------------------------------------------------------------------------------
+# Patch graph (preprocessing/graph_construction/patch_graph_construction.py)
+# --------------------------------------------------------------------------------------
+def patch_grid(H: int, W: int, patch: int):
+    """ceil-div grid, patch_graph_construction.py:67-68."""
+    return (H + patch - 1) // patch, (W + patch - 1) // patch
+
+
+def patch_graph_edges(H: int, W: int, patch: int) -> np.ndarray:
+    """COO edge_index (2,E) int64 in the reference's emission order (:77-92, :97)."""
+    nph, npw = patch_grid(H, W, patch)
+    src, dst = [], []
+    for r in range(nph):
+        for c in range(npw):
+            n = r * npw + c
+            if c + 1 < npw:  # right neighbour, both directions (:81-84)
+                src += [n, n + 1]
+                dst += [n + 1, n]
+            if r + 1 < nph:  # down neighbour, both directions (:86-89)
+                src += [n, n + npw]
+                dst += [n + npw, n]
+    if not src:
+        return np.empty((2, 0), dtype=np.int64)  # :95
+    return np.asarray([src, dst], dtype=np.int64)
+
+
+def coo_to_csr(edge_index: np.ndarray, num_nodes: int):
+    """CSR by TARGET, preserving the COO order of the sources of each target (stable)."""
+    tgt = edge_index[1]
+    order = np.argsort(tgt, kind="stable")
+    col = edge_index[0][order].astype(np.int32)
+    rowptr = np.zeros(num_nodes + 1, dtype=np.int32)
+    np.cumsum(np.bincount(tgt, minlength=num_nodes), out=rowptr[1:])
+    return rowptr, col, order.astype(np.int64)
+
+
+def image_to_patches(img_chw: torch.Tensor, patch: int):
+    """patch_graph_construction.py:26-47: zero-pad bottom/right, unfold twice."""
+    C, H, W = img_chw.shape
+    ph, pw = (patch - H % patch) % patch, (patch - W % patch) % patch
+    if ph or pw:
+        img_chw = F.pad(img_chw, (0, pw, 0, ph))
+        C, H, W = img_chw.shape
+    pt = img_chw.unfold(1, patch, patch).unfold(2, patch, patch)
+    nph, npw = pt.shape[1], pt.shape[2]
+    pt = pt.permute(1, 2, 0, 3, 4).contiguous().view(-1, C, patch, patch)
+    return pt, (nph, npw)
+
+
+def patch_mean_features(feat_chw: torch.Tensor, patch: int) -> torch.Tensor:
+    """Deterministic node features for the 'full forward' (SURVEY 8a row L3): the mean of the
+    shallowest decoder feature over each patch produced by image_to_patches -> (Np, C).
+    This is what patch_graph_construction.py:104-136 describes and leaves NotImplemented;
+    the zero padding of :28-33 is included in the mean (divide by patch*patch)."""
+    pt, _ = image_to_patches(feat_chw, patch)
+    return pt.mean(dim=(2, 3))
+
+
+# --------------------------------------------------------------------------------------
+# GAT (model/gat/graph_attention.py)
+# --------------------------------------------------------------------------------------
+def gat_param_shapes(node_feature_dim, hidden_dim, output_dim, num_heads, num_gat_layers=1):
+    """state_dict keys of GATNetwork (graph_attention.py:162-186)."""
+    out: "OrderedDict[str, tuple]" = OrderedDict()
+    layers = []
+    if num_gat_layers == 1:
+        layers.append((node_feature_dim, output_dim, False))  # :168-172
+    else:
+        layers.append((node_feature_dim, hidden_dim, True))  # :175-177
+        for _ in range(num_gat_layers - 2):
+            layers.append((hidden_dim * num_heads, hidden_dim, True))  # :179-182
+        layers.append((hidden_dim * num_heads, output_dim, False))  # :184-186
+    for l, (fin, fout, concat) in enumerate(layers):
+        fh = fout // num_heads if concat else fout  # :137-141
+        for h in range(num_heads):
+            out[f"gat_layers.{l}.heads.{h}.W.weight"] = (fh, fin)  # :28
+            out[f"gat_layers.{l}.heads.{h}.a.weight"] = (1, 2 * fh)  # :31
+    return out, layers
+
+
+def make_gat_params(node_feature_dim, hidden_dim, output_dim, num_heads, num_gat_layers=1, seed=0, scale=1.0):
+    shapes, _ = gat_param_shapes(node_feature_dim, hidden_dim, output_dim, num_heads, num_gat_layers)
+    params = OrderedDict()
+    for name, shape in shapes.items():
+        fan_in, fan_out = shape[1], shape[0]
+        a = 1.414 * float(np.sqrt(6.0 / (fan_in + fan_out))) * scale  # xavier_uniform gain 1.414, :36-37
+        params[name] = torch.from_numpy(formula_uniform(name, shape, -a, a, seed))
+    return params
+
+
+def gat_head_forward(X, edge_index, W, a, alpha=0.2):
+    """GraphAttentionLayer.forward in eval mode, graph_attention.py:40-118, literally."""
+    N = X.shape[0]
+    h = X @ W.t()  # :53
+    hs, ht = h[edge_index[0]], h[edge_index[1]]  # :57-58
+    e = F.leaky_relu(torch.cat([hs, ht], dim=1) @ a.t(), alpha)  # :61-65
+    if e.numel() == 0:
+        return F.elu(torch.zeros_like(h))
+    exp_e = torch.exp(e - torch.max(e))  # :86 GLOBAL max
+    den = torch.zeros(N, 1, dtype=X.dtype).scatter_add_(0, edge_index[1].unsqueeze(1), exp_e)  # :90-91
+    att = exp_e / (den[edge_index[1]] + 1e-10)  # :94-96
+    hp = torch.zeros_like(h)
+    hp.scatter_add_(0, edge_index[1].unsqueeze(1).repeat(1, h.shape[1]), att * hs)  # :104-112
+    return F.elu(hp)  # :118
+
+
+def gat_network_forward(p, X, edge_index, num_heads, num_gat_layers=1, alpha=0.2):
+    """GATNetwork.forward (eval: dropout is identity), graph_attention.py:150-160, 188-192."""
+    h = X
+    for l in range(num_gat_layers):
+        outs = [gat_head_forward(h, edge_index, p[f"gat_layers.{l}.heads.{k}.W.weight"],
+                                 p[f"gat_layers.{l}.heads.{k}.a.weight"], alpha) for k in range(num_heads)]
+        concat = (num_gat_layers > 1) and (l < num_gat_layers - 1)
+        h = torch.cat(outs, dim=1) if concat else torch.mean(torch.stack(outs, 0), 0)  # :153-158
+    return h
+
+
+# --------------------------------------------------------------------------------------
+# Step loops (scripts/train_segmentation.py:117-137, experiments/segmentation_performance.py:119-144)
+# --------------------------------------------------------------------------------------
+def eval_step(p, x, depth=4):
+    """no_grad -> model(x) -> argmax(1): segmentation_performance.py:125-141."""
+    with torch.no_grad():
+        logits, _, _ = unet_forward(p, x, depth, training=False)
+    return logits, torch.argmax(logits, dim=1)
+
+
+def train_step(p, x, y, depth=4, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, step=1,
+               exp_avg=None, exp_avg_sq=None):
+    """zero_grad -> fwd -> CrossEntropyLoss (mean) -> backward -> Adam(lr, wd as L2-in-grad).
+
+    train_segmentation.py:91,96,121-134 with torch.optim.Adam semantics.  Returns
+    (loss, grads, new_params, new_bn_stats, exp_avg, exp_avg_sq)."""
+    names = [k for k, v in p.items() if v.dtype.is_floating_point and "running_" not in k]
+    q = OrderedDict((k, (v.clone().requires_grad_(True) if k in names else v.clone())) for k, v in p.items())
+    stats = {}
+    logits, _, _ = unet_forward(q, x, depth, training=True, new_stats=stats)
+    loss = F.cross_entropy(logits, y)
+    grads = torch.autograd.grad(loss, [q[k] for k in names])
+    grads = OrderedDict(zip(names, grads))
+    new_p = OrderedDict((k, v.detach().clone()) for k, v in q.items())
+    exp_avg = exp_avg or {k: torch.zeros_like(p[k]) for k in names}
+    exp_avg_sq = exp_avg_sq or {k: torch.zeros_like(p[k]) for k in names}
+    b1, b2 = betas
+    for k in names:
+        g = grads[k] + weight_decay * p[k]
+        exp_avg[k] = b1 * exp_avg[k] + (1 - b1) * g
+        exp_avg_sq[k] = b2 * exp_avg_sq[k] + (1 - b2) * g * g
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        denom = exp_avg_sq[k].sqrt() / np.sqrt(bc2) + eps
+        new_p[k] = p[k] - (lr / bc1) * exp_avg[k] / denom
+    for k, v in stats.items():
+        new_p[k] = v
+    return loss.detach(), grads, new_p, stats, exp_avg, exp_avg_sq
