@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark: segmented Mpix/s of the full MinGraph-UNet forward (BASELINE.json).
+
+A "step" = one pass of the hot path over one synthetic batch per rank:
+    U-Net forward (18 conv3x3 + 4 convT + 1x1) -> per-patch mean of decoder_feats[0] -> block-diagonal
+    patch-graph GAT(32 -> 64, 4 heads) over the batch's B*1024 nodes.
+Workload at N=1 = BASELINE configs[1]: batch 8 x 3x512x512 fp32 on one MI355X.  For N>1 each rank gets
+its own 8 images (weak scaling, = configs[2]'s 8 images/GPU at N=8) and there is NO data-path collective
+(images are independent) -- only the timing barrier.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "mingraph-unet_amd"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(batch, H, W, iters):
+    """The oracle (CPU restatement of the reference path, same aten/oneDNN kernels the reference's
+    modules dispatch to) timed on this box's host cores on a bounded sample of the same workload."""
+    import mgunet_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    p = O.make_unet_params(3, 2, 32, 4, seed=0)
+    gp = O.make_gat_params(32, 128, 64, 4, 1, seed=0)
+    ei = torch.from_numpy(O.patch_graph_edges(H, W, 16))
+    x = torch.from_numpy(O.formula_normal("bench/cpu/x", (batch, 3, H, W), seed=1))
+
+    def step():
+        with torch.no_grad():
+            lg, _, ft = O.unet_forward(p, x, 4)
+            for b in range(batch):
+                O.gat_network_forward(gp, O.patch_mean_features(ft[0][b], 16), ei, 4)
+        return lg
+
+    step()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(batch * H * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{batch} images 3x{H}x{W} fp32 of the same workload, 1 warm-up + {iters} timed iterations "
+                      f"({dt:.2f} s/iter), torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE config 2: 8)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if a.gpus > 1:
+            sys.exit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus}` (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import mgunet
+    import mgunet_oracle as O
+    from mgunet import _lib
+
+    B, H, W = a.batch, a.size, a.size
+    unet = mgunet.UNet(3, 2, 32, 4)
+    unet.load_state_dict(O.make_unet_params(3, 2, 32, 4, seed=0))     # random-init-scale formula weights
+    gat = mgunet.GATNetwork(32, 128, 64, 4, 1)
+    gat.load_state_dict(O.make_gat_params(32, 128, 64, 4, 1, seed=0))
+    model = mgunet.MinGraphUNet(unet.to(dev).eval(), gat.to(dev).eval(), 16).eval()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    x = torch.randn((B, 3, H, W), device=dev, generator=gen)           # synthetic batch, resident in HBM
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            out = model(x)
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(a.steps):
+            out = model(x)
+        ev1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[3]).all())
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_step = dt / a.steps * 1e3
+    mpix = world * B * H * W * a.steps / dt / 1e6
+
+    # ---- roofline of the dominant kernel (the fp32 implicit-GEMM conv): HIP events recorded by the
+    # library on the launch stream around every conv/convT/1x1/linear GEMM launch of the same steps
+    roof = None
+    if rank == 0 and not a.no_profile_pass:
+        ctx = next(iter(unet._ctx.values()))
+        L = _lib.lib()
+        conv_ms = tot_ms = 0.0
+        launches = 0
+        nprof = min(a.steps, 10)
+        with torch.no_grad():
+            for _ in range(nprof):
+                L.mgu_profile_enable(ctx.handle, 1)
+                model.unet(x)
+                cm, n, tm = C.c_double(), C.c_int(), C.c_double()
+                _lib.check(L.mgu_profile_read(ctx.handle, C.byref(cm), C.byref(n), C.byref(tm)), ctx.handle)
+                conv_ms += cm.value
+                tot_ms += tm.value
+                launches += n.value
+            L.mgu_profile_enable(ctx.handle, 0)
+        flops = unet.flops(B, H, W)
+        ach = flops * nprof / (conv_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "kernel": "igemm_f32_kernel (all conv3x3/convT/1x1 launches of a step)",
+                "launches_per_step": launches // nprof, "kernel_ms_per_step": round(conv_ms / nprof, 4),
+                "unet_ms_per_step_with_events": round(tot_ms / nprof, 4), "gflop_per_step": round(flops / 1e9, 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(2, H, W, 3)
+
+    if rank == 0:
+        line = {"metric": "segmented Mpix/sec, full MinGraph-UNet forward (U-Net + patch-graph GAT), 512x512 batch",
+                "value": round(mpix, 3), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic (N(0,1) images resident in HBM, formula random-init-scale weights)",
+                "config": {"workload": f"BASELINE configs[1]: batch {B}/GPU x 3x{H}x{W} fp32 full forward "
+                                       f"(UNet(3,2,32,4) + patch16 graph GAT(32->64,4 heads)), eval",
+                           "images_per_gpu": B, "global_batch": B * world, "parallelism": f"batch-shard x{world}, no collective"},
+                "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / a.steps, 4),
+                "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+/*
+ * mgunet.h -- C-ABI of libmgunet.so: the MI355X (gfx950) MinGraph-UNet segmentation hot path.
+ *
+ * The reference (agent-charon/MinGraph-UNet) has no FFI, plugin or operator registry: its hot
+ * path sits behind three Python classes.  Each entry point below names the reference interface
+ * it replaces (paths relative to MinGraph-UNet/).  A maintainer binds these with ctypes -- see
+ * INTEGRATION.md for the stub that swaps them in under the reference's own nn.Modules.
+ *
+ * Conventions
+ *   - every pointer named *_dev / documented "device" is a HIP device pointer owned by the caller;
+ *   - activations are NHWC ("channels_last") fp32 in device memory; logical shapes stay NCHW;
+ *   - all work is enqueued on `hip_stream` (a hipStream_t passed as void*); no hidden syncs
+ *     except inside mgu_*_reserve / the first call that has to grow the library-owned workspace;
+ *   - every function returns MGU_OK (0) or a negative error code; mgu_last_error(ctx) gives text;
+ *   - a ctx is bound to one device and is not thread-safe.
+ */
+#ifndef MGUNET_H
+#define MGUNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGU_OK 0
+#define MGU_ERR_INVALID -1   /* bad argument / unsupported shape (shim raises ValueError)   */
+#define MGU_ERR_HIP -2       /* a HIP runtime call failed (shim raises RuntimeError)          */
+#define MGU_ERR_STATE -3     /* call order violated, e.g. forward before load_weights         */
+#define MGU_ERR_NOMEM -4
+
+#define MGU_DTYPE_F32 0
+#define MGU_DTYPE_BF16 1     /* reserved: bf16 storage + fp32 accumulate (BASELINE config 3)   */
+
+typedef struct mgu_ctx mgu_ctx;
+
+/* One named parameter/buffer of a state_dict(); `ptr` is a device pointer to contiguous fp32
+ * (int64 for num_batches_tracked, which is ignored).  Names are the reference's state_dict keys
+ * (SURVEY.md 8b): "encoder.encoder_blocks.0.conv1.weight", "gat_layers.0.heads.2.a.weight", ... */
+typedef struct {
+  const char* name;
+  const void* ptr;
+  int64_t numel;
+} mgu_tensor_desc;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int mgu_create(int device_id, mgu_ctx** out);
+void mgu_destroy(mgu_ctx* ctx);
+const char* mgu_last_error(mgu_ctx* ctx); /* ctx may be NULL: returns the last create() error */
+const char* mgu_version(void);
+
+/* ---- U-Net: replaces model/unet/unet_model.py:6-36 (UNet.__init__/forward) ------------------- */
+/* = UNet(in_channels, num_classes, init_features, depth) (unet_model.py:7).  init_features must be
+ * a multiple of 4 (NHWC float4 loads).  */
+int mgu_unet_configure(mgu_ctx* ctx, int in_channels, int num_classes, int init_features, int depth, int dtype);
+/* Number of fp32 elements of all trainable parameters, in state_dict order (7 766 018 for (3,2,32,4)). */
+int64_t mgu_unet_param_count(mgu_ctx* ctx);
+/* = load_state_dict: repacks OIHW conv weights to the kernels' [Cout][tap][Cin] panels, and for
+ * eval folds bias + BatchNorm running stats (unet_encoder.py:12-13, eps 1e-5) into a per-channel
+ * scale/shift applied in the conv epilogue.  Must be re-called after the parameters change. */
+int mgu_unet_load_weights(mgu_ctx* ctx, const mgu_tensor_desc* named, int n, void* hip_stream);
+/* Bytes of library-owned scratch a forward of this shape uses (allocated on first use). */
+int mgu_unet_workspace_bytes(mgu_ctx* ctx, int B, int H, int W, int training, size_t* out);
+/* Pre-allocate that scratch (synchronous); forward does it lazily otherwise. */
+int mgu_unet_reserve(mgu_ctx* ctx, int B, int H, int W, int training);
+/* = logits, skips, dec_feats = UNet.forward(x)  (unet_model.py:34-36), eval mode.
+ *   x_dev      : input, element (n,c,y,x) at x_dev[n*xs_n + c*xs_c + y*xs_h + x*xs_w] (fp32; any layout)
+ *   logits_dev : (B,H,W,num_classes) NHWC
+ *   cat_dev[i] : i = 0..depth-1 shallow->deep, NHWC buffer (B,H_i,W_i,2*C_i), C_i = init_features<<i,
+ *                H_i = H>>i.  Channels [0,C_i) receive skip connection i (unet_encoder.py:69); channels
+ *                [C_i,2*C_i) receive the up-sampled decoder input (unet_decoder.py:36-53), i.e. the
+ *                buffer IS torch.cat([skip, up], 1) and no concat kernel ever runs.
+ *   feat_dev[i]: decoder feature i shallow->deep, NHWC dense (B,H_i,W_i,C_i) (unet_decoder.py:141,149)
+ * All outputs stay valid after the call (caller-owned). */
+int mgu_unet_forward(mgu_ctx* ctx, const void* x_dev, int B, int H, int W,
+                     int64_t xs_n, int64_t xs_c, int64_t xs_h, int64_t xs_w,
+                     void* logits_dev, void* const* cat_dev, void* const* feat_dev,
+                     int training, void* hip_stream);
+/* Building blocks (also used by the kernel-level parity tests): one fused Conv2d(k=1|3, pad=k/2, bias)
+ * [+ per-channel scale/shift] [+ ReLU] on an NHWC fp32 tensor, = nn.Conv2d.forward as used at
+ * unet_encoder.py:7-8,16-24 and unet_decoder.py:117; weights in the reference's OIHW layout (device).
+ * scale_dev/shift_dev may be NULL (then y = conv + bias).  in: (B,H,W,Cin) with Cin % 4 == 0; out: pixel
+ * pitch ld_out >= c_off + Cout floats (lets the result land in a channel slice of a wider buffer). */
+int mgu_conv2d_nhwc(mgu_ctx* ctx, const void* in_dev, int B, int H, int W, int Cin, const void* w_oihw_dev,
+                    const void* bias_dev, const void* scale_dev, const void* shift_dev, int Cout, int ksize,
+                    int relu, void* out_dev, int ld_out, int c_off, void* hip_stream);
+/* ConvTranspose2d(Cin, Cout, kernel_size=2, stride=2) + bias (unet_decoder.py:25,36); weight (Cin,Cout,2,2).
+ * in (B,H,W,Cin) NHWC -> out (B,2H,2W,*) NHWC with pixel pitch ld_out, channels [c_off, c_off+Cout). */
+int mgu_conv_transpose2x2_nhwc(mgu_ctx* ctx, const void* in_dev, int B, int H, int W, int Cin, const void* w_iohw_dev,
+                               const void* bias_dev, int Cout, void* out_dev, int ld_out, int c_off, void* hip_stream);
+/* MaxPool2d(2,2) floor mode (unet_encoder.py:48) on NHWC, input pixel pitch ld_in >= C. */
+int mgu_maxpool2x2_nhwc(mgu_ctx* ctx, const void* in_dev, int ld_in, int B, int H, int W, int C, void* out_dev,
+                        void* hip_stream);
+/* argmax over classes of NHWC logits -> int64 (B,H,W): experiments/segmentation_performance.py:141 */
+int mgu_argmax_classes(mgu_ctx* ctx, const void* logits_dev, int64_t npix, int num_classes,
+                       int64_t* pred_dev, void* hip_stream);
+
+/* ---- patch graph: replaces preprocessing/graph_construction/patch_graph_construction.py:49-102 -- */
+/* HOST routine (index maps are tiny and static per image size).  Emits the COO edge_index in the
+ * reference's exact order (:77-92) into coo[0..E) (sources) and coo[E..2E) (targets), and the
+ * CSR-by-target (rowptr[N+1], col[E]) that keeps each target's sources in COO order.  Any output
+ * pointer may be NULL.  *E_out = 2*(nph*(npw-1)+(nph-1)*npw); nodes = nph*npw with ceil-div grid. */
+int mgu_patch_graph_build(int H, int W, int patch, int64_t* coo, int32_t* rowptr, int32_t* col,
+                          int64_t* E_out, int* nph_out, int* npw_out);
+/* HOST: stable COO(2,E int64) -> CSR-by-target for an arbitrary graph (order[k] = COO position). */
+int mgu_coo_to_csr(const int64_t* coo, int64_t E, int num_nodes, int32_t* rowptr, int32_t* col);
+/* Node features of the 'full forward' (SURVEY 8a row L3): mean over each patch x patch window of an
+ * NHWC feature map, zero padded bottom/right as image_to_patches does (:26-47).
+ * out_dev: (B*nph*npw, C) fp32. */
+int mgu_patch_mean(mgu_ctx* ctx, const void* feat_dev, int B, int H, int W, int C, int patch,
+                   void* out_dev, void* hip_stream);
+
+/* ---- GAT: replaces model/gat/graph_attention.py:40-118, 150-160 (one MultiHeadGATLayer, eval) -- */
+/* X_dev (N,Fin) fp32, Fin % 4 == 0; CSR by target on device (rowptr int32[N+1], col int32[E]);
+ * W_dev (heads*Fout_head, Fin) = the heads' W.weight stacked; a_dev (heads, 2*Fout_head) = a.weight
+ * stacked.  graph_ptr_dev int32[num_graphs+1] gives the node range of each graph of a block-diagonal
+ * batch (the reference's exp(e - max(e)) at :86 is per graph and per head); NULL = one graph.
+ * concat=1: out (N, heads*Fout_head) = cat of ELU(head) (:155); concat=0: out (N,Fout_head) = mean (:158). */
+int mgu_gat_layer_forward(mgu_ctx* ctx, const void* X_dev, int N, int Fin,
+                          const int32_t* rowptr_dev, const int32_t* col_dev, int64_t E,
+                          const int32_t* graph_ptr_dev, int num_graphs,
+                          const void* W_dev, const void* a_dev, int heads, int Fout_head,
+                          int concat, float alpha, void* out_dev, void* hip_stream);
+
+/* ---- introspection for bench.py / profiles ------------------------------------------------------ */
+/* FLOPs (2*MAC, convolutions only) of one U-Net forward over B images: SURVEY 8d table. */
+double mgu_unet_flops(mgu_ctx* ctx, int B, int H, int W);
+/* Time the conv/GEMM kernels of the LAST mgu_unet_forward with HIP events on the launch stream:
+ * enable before the forward, read after.  Adds event records only (no syncs) while enabled. */
+int mgu_profile_enable(mgu_ctx* ctx, int on);
+int mgu_profile_read(mgu_ctx* ctx, double* conv_ms, int* conv_launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGUNET_H */

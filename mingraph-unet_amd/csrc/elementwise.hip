@@ -1,0 +1,197 @@
+// HBM-bound helper kernels around the implicit-GEMM: layout packing, 2x2 max-pool, patch mean,
+// weight repacking, BatchNorm folding, class argmax.  All NHWC, 16-byte lanes where channels allow.
+#include "common.h"
+
+namespace mgu {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int nblocks(int64_t work, int threads, int cap = 256 * 16) {
+  int64_t b = (work + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+// ---- input: arbitrary-stride (n,c,y,x) fp32 -> NHWC with channels zero padded to Cp (Cp % 4 == 0) ----
+__global__ void pack_input_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t npix_total, int C,
+                                  int Cp, int H, int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw) {
+  const int q = Cp >> 2;
+  const int64_t total = npix_total * q;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i / q;
+    const int c0 = (int)(i - pix * q) * 4;
+    const int64_t n = pix / ((int64_t)H * W);
+    const int64_t rem = pix - n * (int64_t)H * W;
+    const int y = (int)(rem / W);
+    const int xx = (int)(rem - (int64_t)y * W);
+    const float* p = x + n * sn + y * sh + xx * sw;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (c0 + j < C) ? p[(c0 + j) * sc] : 0.f;
+    *reinterpret_cast<f32x4*>(out + pix * Cp + c0) = v;
+  }
+}
+
+hipError_t launch_pack_input(const float* x, float* out, int B, int C, int Cp, int H, int W, int64_t sn, int64_t sc,
+                             int64_t sh, int64_t sw, hipStream_t s) {
+  const int64_t npix = (int64_t)B * H * W;
+  hipLaunchKernelGGL(pack_input_kernel, dim3(nblocks(npix * (Cp >> 2), 256)), dim3(256), 0, s, x, out, npix, C, Cp, H,
+                     W, sn, sc, sh, sw);
+  return hipGetLastError();
+}
+
+// ---- MaxPool2d(2,2), floor mode (model/unet/unet_encoder.py:48,70); input may be a channel slice ----
+__global__ void maxpool2_kernel(const float* __restrict__ in, int ldin, float* __restrict__ out, int B, int H, int W,
+                                int C) {
+  const int Ho = H >> 1, Wo = W >> 1, q = C >> 2;
+  const int64_t total = (int64_t)B * Ho * Wo * q;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % q) * 4;
+    int64_t pix = i / q;
+    const int xo = (int)(pix % Wo);
+    pix /= Wo;
+    const int yo = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    const float* p = in + (((int64_t)n * H + 2 * yo) * W + 2 * xo) * ldin + c0;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + ldin);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)W * ldin);
+    const f32x4 e = *reinterpret_cast<const f32x4*>(p + (int64_t)W * ldin + ldin);
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(c[j], e[j]));
+    *reinterpret_cast<f32x4*>(out + (((int64_t)n * Ho + yo) * Wo + xo) * C + c0) = v;
+  }
+}
+
+hipError_t launch_maxpool2(const float* in, int ldin, float* out, int B, int H, int W, int C, hipStream_t s) {
+  const int64_t total = (int64_t)B * (H >> 1) * (W >> 1) * (C >> 2);
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(nblocks(total, 256)), dim3(256), 0, s, in, ldin, out, B, H, W, C);
+  return hipGetLastError();
+}
+
+// ---- patch mean: one workgroup per patch; (Np, C) = mean over patch x patch window (zero padded) ----
+__global__ __launch_bounds__(256) void patch_mean_kernel(const float* __restrict__ feat, float* __restrict__ out, int H,
+                                                         int W, int C, int patch, int nph, int npw) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [npl][C]
+  const int q = C >> 2;
+  const int npl = 256 / q;  // pixel lanes
+  const int t = threadIdx.x;
+  const int cq = t % q, pl = t / q;
+  const int node = blockIdx.x;
+  const int img = node / (nph * npw);
+  const int pr = (node / npw) % nph, pc = node % npw;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (pl < npl) {
+    for (int i = pl; i < patch * patch; i += npl) {
+      const int y = pr * patch + i / patch, x = pc * patch + i % patch;
+      if (y < H && x < W) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(feat + (((int64_t)img * H + y) * W + x) * C + cq * 4);
+        acc += v;
+      }
+    }
+    *reinterpret_cast<f32x4*>(red + pl * C + cq * 4) = acc;
+  }
+  __syncthreads();
+  if (t < C) {
+    float sum = 0.f;
+    for (int i = 0; i < npl; ++i) sum += red[i * C + t];
+    out[(int64_t)node * C + t] = sum / (float)(patch * patch);
+  }
+}
+
+hipError_t launch_patch_mean(const float* feat, float* out, int B, int H, int W, int C, int patch, hipStream_t s) {
+  if ((C & 3) || C > 256 || C < 4) return hipErrorInvalidValue;
+  const int nph = (H + patch - 1) / patch, npw = (W + patch - 1) / patch;
+  const int npl = 256 / (C >> 2);
+  hipLaunchKernelGGL(patch_mean_kernel, dim3(B * nph * npw), dim3(256), (size_t)npl * C * sizeof(float), s, feat, out,
+                     H, W, C, patch, nph, npw);
+  return hipGetLastError();
+}
+
+// ---- weights: OIHW (Cout,Cin,KS,KS) -> panel [Cout][Kp], k = (r*KS+s)*Cp + c (zero padded) ------------
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int Cp,
+                                   int KS, int Kp) {
+  const int64_t total = (int64_t)Cout * Kp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / Kp), k = (int)(i - (int64_t)n * Kp);
+    const int tap = k / Cp, c = k - tap * Cp;
+    float v = 0.f;
+    if (tap < KS * KS && c < Cin) v = w[((int64_t)n * Cin + c) * KS * KS + tap];
+    wp[i] = v;
+  }
+}
+
+hipError_t launch_pack_conv_w(const float* w, float* wp, int Cout, int Cin, int Cp, int KS, int Kp, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_w_kernel, dim3(nblocks((int64_t)Cout * Kp, 256)), dim3(256), 0, s, w, wp, Cout, Cin, Cp,
+                     KS, Kp);
+  return hipGetLastError();
+}
+
+// ---- ConvTranspose2d weight (Cin,Cout,2,2) -> panel [(dy*2+dx)*Cout + co][Kp], k = ci ----------------
+__global__ void pack_convt_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int Kp) {
+  const int64_t total = (int64_t)4 * Cout * Kp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / Kp), k = (int)(i - (int64_t)n * Kp);
+    const int q = n / Cout, co = n - q * Cout;
+    wp[i] = (k < Cin) ? w[((int64_t)k * Cout + co) * 4 + q] : 0.f;
+  }
+}
+
+hipError_t launch_pack_convt_w(const float* w, float* wp, int Cin, int Cout, int Kp, hipStream_t s) {
+  hipLaunchKernelGGL(pack_convt_w_kernel, dim3(nblocks((int64_t)4 * Cout * Kp, 256)), dim3(256), 0, s, w, wp, Cin, Cout,
+                     Kp);
+  return hipGetLastError();
+}
+
+// ---- eval BatchNorm + conv bias -> y = scale*acc + shift (unet_encoder.py:12-13,17-24) ----------------
+__global__ void bn_fold_kernel(const float* bias, const float* gamma, const float* beta, const float* mean,
+                               const float* var, float eps, float* scale, float* shift, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C) {
+    const float sc = gamma[i] / sqrtf(var[i] + eps);
+    scale[i] = sc;
+    shift[i] = (bias[i] - mean[i]) * sc + beta[i];
+  }
+}
+
+hipError_t launch_bn_fold(const float* bias, const float* gamma, const float* beta, const float* mean, const float* var,
+                          float eps, float* scale, float* shift, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, s, bias, gamma, beta, mean, var, eps, scale,
+                     shift, C);
+  return hipGetLastError();
+}
+
+__global__ void bias_tile_kernel(const float* bias, float* shift, int C, int reps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C * reps) shift[i] = bias[i % C];
+}
+
+hipError_t launch_bias_tile(const float* bias, float* shift, int C, int reps, hipStream_t s) {
+  hipLaunchKernelGGL(bias_tile_kernel, dim3((C * reps + 255) / 256), dim3(256), 0, s, bias, shift, C, reps);
+  return hipGetLastError();
+}
+
+// ---- argmax over classes (first maximal index, like torch.argmax on distinct values) ---------------
+__global__ void argmax_kernel(const float* __restrict__ logits, int64_t npix, int C, int64_t* __restrict__ pred) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* p = logits + i * C;
+    float best = p[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c)
+      if (p[c] > best) {
+        best = p[c];
+        bi = c;
+      }
+    pred[i] = bi;
+  }
+}
+
+hipError_t launch_argmax(const float* logits, int64_t npix, int C, int64_t* pred, hipStream_t s) {
+  hipLaunchKernelGGL(argmax_kernel, dim3(nblocks(npix, 256)), dim3(256), 0, s, logits, npix, C, pred);
+  return hipGetLastError();
+}
+
+}  // namespace mgu

@@ -1,0 +1,650 @@
+// C-ABI of libmgunet.so (see include/mgunet.h): context, weight repacking, U-Net forward schedule,
+// GAT layer schedule.  Host orchestration only -- every arithmetic op is a kernel in igemm_f32.hip,
+// elementwise.hip or gat.hip.  No CPU fallback exists: without a HIP device every call fails.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mgunet.h"
+#include "common.h"
+
+using namespace mgu;
+
+namespace {
+
+struct Layer {
+  std::string prefix;   // state_dict prefix, e.g. "encoder.encoder_blocks.0."
+  std::string conv;     // "conv1" | "conv2" | "upsample" | "final_conv"
+  std::string bn;       // "bn1" | "bn2" | ""
+  int Cin = 0, Cp = 0, Cout = 0, KS = 3;
+  bool convt = false;
+  int K = 0, Kp = 0, N = 0, Np = 0;
+  float *wp = nullptr, *scale = nullptr, *shift = nullptr;
+};
+
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+std::string g_create_err;
+
+}  // namespace
+
+struct mgu_ctx {
+  int device = 0;
+  std::string err;
+  // U-Net
+  bool configured = false, loaded = false;
+  int in_ch = 0, ncls = 0, feat = 0, depth = 0, dtype = 0, Cp0 = 0;
+  std::vector<Layer> layers;  // enc[i].conv1, enc[i].conv2 ..., bott.conv1, bott.conv2, dec[b].up, dec[b].conv1, dec[b].conv2 ..., final
+  float* arena = nullptr;
+  size_t arena_floats = 0;
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  void* gws = nullptr;  // GAT scratch
+  size_t gws_bytes = 0;
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  int ev_used = 0;
+  hipEvent_t ev_total[2] = {nullptr, nullptr};
+};
+
+namespace {
+
+int fail(mgu_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_err = buf;
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) return fail(c, MGU_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+int ensure(mgu_ctx* c, void** p, size_t* have, size_t need) {
+  if (*have >= need) return MGU_OK;
+  if (*p) {
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+  }
+  hipError_t e = hipMalloc(p, need);
+  if (e != hipSuccess) return fail(c, MGU_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+  *have = need;
+  return MGU_OK;
+}
+
+struct ProfScope {  // records an event pair around one conv/GEMM launch when profiling is on
+  mgu_ctx* c;
+  hipStream_t s;
+  int idx = -1;
+  ProfScope(mgu_ctx* c_, hipStream_t s_) : c(c_), s(s_) {
+    if (!c->prof) return;
+    if ((size_t)(2 * c->ev_used + 2) > c->ev.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      c->ev.push_back(a);
+      c->ev.push_back(b);
+    }
+    idx = c->ev_used++;
+    (void)hipEventRecord(c->ev[2 * idx], s);
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(c->ev[2 * idx + 1], s);
+  }
+};
+
+void level_dims(int H, int W, int depth, std::vector<int>& hs, std::vector<int>& wsz) {
+  hs.assign(depth + 1, 0);
+  wsz.assign(depth + 1, 0);
+  hs[0] = H;
+  wsz[0] = W;
+  for (int i = 1; i <= depth; ++i) {
+    hs[i] = hs[i - 1] / 2;  // MaxPool2d(2,2) floor mode, unet_encoder.py:48
+    wsz[i] = wsz[i - 1] / 2;
+  }
+}
+
+struct WsPlan {
+  size_t xin, tmp, bott, total;
+  std::vector<size_t> pooled;
+};
+
+WsPlan plan_ws(const mgu_ctx* c, int B, int H, int W) {
+  std::vector<int> hs, wsz;
+  level_dims(H, W, c->depth, hs, wsz);
+  WsPlan p;
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    size_t o = off;
+    off += (floats * sizeof(float) + 255) / 256 * 256;
+    return o;
+  };
+  p.xin = take((size_t)B * H * W * c->Cp0);
+  size_t tmax = 0;
+  for (int i = 0; i <= c->depth; ++i) {
+    size_t f = (size_t)B * hs[i] * wsz[i] * ((size_t)c->feat << i);
+    if (f > tmax) tmax = f;
+  }
+  p.tmp = take(tmax);
+  for (int i = 0; i < c->depth; ++i) p.pooled.push_back(take((size_t)B * hs[i + 1] * wsz[i + 1] * ((size_t)c->feat << i)));
+  p.bott = take((size_t)B * hs[c->depth] * wsz[c->depth] * ((size_t)c->feat << c->depth));
+  p.total = off;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mgu_version(void) { return "mgunet 0.1 (gfx950, fp32 MFMA)"; }
+
+int mgu_create(int device_id, mgu_ctx** out) {
+  if (!out) return fail(nullptr, MGU_ERR_INVALID, "out == NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(nullptr, MGU_ERR_HIP, "no HIP device available (%s): libmgunet has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device_id < 0 || device_id >= n) return fail(nullptr, MGU_ERR_INVALID, "device %d out of range [0,%d)", device_id, n);
+  e = hipSetDevice(device_id);
+  if (e != hipSuccess) return fail(nullptr, MGU_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+  mgu_ctx* c = new mgu_ctx();
+  c->device = device_id;
+  *out = c;
+  return MGU_OK;
+}
+
+void mgu_destroy(mgu_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  if (c->arena) (void)hipFree(c->arena);
+  if (c->ws) (void)hipFree(c->ws);
+  if (c->gws) (void)hipFree(c->gws);
+  for (auto e : c->ev) (void)hipEventDestroy(e);
+  for (auto e : c->ev_total)
+    if (e) (void)hipEventDestroy(e);
+  delete c;
+}
+
+const char* mgu_last_error(mgu_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int dtype) {
+  if (!c) return MGU_ERR_INVALID;
+  if (in_ch < 1 || ncls < 1 || feat < 4 || (feat & 3) || depth < 1 || depth > 8)
+    return fail(c, MGU_ERR_INVALID, "unsupported UNet(%d,%d,%d,%d): init_features must be a positive multiple of 4, depth 1..8",
+                in_ch, ncls, feat, depth);
+  if (dtype != MGU_DTYPE_F32) return fail(c, MGU_ERR_INVALID, "dtype %d not built yet (fp32 only)", dtype);
+  HIPCHK(c, hipSetDevice(c->device));
+  c->in_ch = in_ch, c->ncls = ncls, c->feat = feat, c->depth = depth, c->dtype = dtype;
+  c->Cp0 = rup(in_ch, 4);
+  c->layers.clear();
+  auto add_block = [&](const std::string& prefix, int cin, int cp, int cout) {  // ConvBlock, unet_encoder.py:4-25
+    for (int j = 0; j < 2; ++j) {
+      Layer L;
+      L.prefix = prefix;
+      L.conv = j == 0 ? "conv1" : "conv2";
+      L.bn = j == 0 ? "bn1" : "bn2";
+      L.Cin = j == 0 ? cin : cout;
+      L.Cp = j == 0 ? cp : cout;
+      L.Cout = cout;
+      L.KS = 3;
+      c->layers.push_back(L);
+    }
+  };
+  int cin = in_ch, cp = c->Cp0, f = feat;
+  for (int i = 0; i < depth; ++i) {  // unet_encoder.py:46-50
+    add_block("encoder.encoder_blocks." + std::to_string(i) + ".", cin, cp, f);
+    cin = cp = f;
+    f *= 2;
+  }
+  add_block("encoder.bottleneck.", cin, cp, f);  // :53
+  int prev = f;
+  for (int b = 0; b < depth; ++b) {  // unet_decoder.py:103-114
+    const int ci = feat << (depth - 1 - b);
+    Layer U;
+    U.prefix = "decoder.decoder_blocks." + std::to_string(b) + ".";
+    U.conv = "upsample";
+    U.Cin = U.Cp = prev;
+    U.Cout = prev / 2;
+    U.KS = 1;
+    U.convt = true;
+    c->layers.push_back(U);
+    add_block(U.prefix + "conv_block.", ci + prev / 2, ci + prev / 2, ci);
+    prev = ci;
+  }
+  Layer Fc;  // unet_decoder.py:117
+  Fc.prefix = "decoder.";
+  Fc.conv = "final_conv";
+  Fc.Cin = Fc.Cp = prev;
+  Fc.Cout = ncls;
+  Fc.KS = 1;
+  c->layers.push_back(Fc);
+
+  size_t total = 0;
+  for (auto& L : c->layers) {
+    L.K = L.KS * L.KS * L.Cp;
+    L.Kp = rup(L.K, 32);
+    L.N = L.convt ? 4 * L.Cout : L.Cout;
+    L.Np = rup(L.N, 128);
+    total += (size_t)L.Np * L.Kp + 2 * (size_t)L.Np;
+  }
+  if (c->arena) HIPCHK(c, hipFree(c->arena));
+  c->arena = nullptr;
+  HIPCHK(c, hipMalloc((void**)&c->arena, total * sizeof(float)));
+  HIPCHK(c, hipMemset(c->arena, 0, total * sizeof(float)));
+  c->arena_floats = total;
+  float* p = c->arena;
+  for (auto& L : c->layers) {
+    L.wp = p;
+    p += (size_t)L.Np * L.Kp;
+    L.scale = p;
+    p += L.Np;
+    L.shift = p;
+    p += L.Np;
+  }
+  c->configured = true;
+  c->loaded = false;
+  return MGU_OK;
+}
+
+int64_t mgu_unet_param_count(mgu_ctx* c) {
+  if (!c || !c->configured) return -1;
+  int64_t n = 0;
+  for (auto& L : c->layers) {
+    n += (int64_t)L.Cout * L.Cin * L.KS * L.KS * (L.convt ? 4 : 1) + L.Cout;
+    if (!L.bn.empty()) n += 2 * (int64_t)L.Cout;
+  }
+  return n;
+}
+
+int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!c->configured) return fail(c, MGU_ERR_STATE, "mgu_unet_configure must precede mgu_unet_load_weights");
+  if (!named || n <= 0) return fail(c, MGU_ERR_INVALID, "empty state_dict");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  std::map<std::string, const mgu_tensor_desc*> sd;
+  for (int i = 0; i < n; ++i)
+    if (named[i].name) sd[named[i].name] = &named[i];
+  auto get = [&](const std::string& key, int64_t numel, const float** out) -> int {
+    auto it = sd.find(key);
+    if (it == sd.end()) return fail(c, MGU_ERR_INVALID, "state_dict is missing key '%s'", key.c_str());
+    if (it->second->numel != numel)
+      return fail(c, MGU_ERR_INVALID, "state_dict key '%s' has %lld elements, expected %lld", key.c_str(),
+                  (long long)it->second->numel, (long long)numel);
+    if (!it->second->ptr) return fail(c, MGU_ERR_INVALID, "state_dict key '%s' has a NULL pointer", key.c_str());
+    *out = (const float*)it->second->ptr;
+    return MGU_OK;
+  };
+  for (auto& L : c->layers) {
+    const float *w, *b;
+    const std::string cw = L.prefix + L.conv;
+    int rc;
+    if (L.convt) {
+      if ((rc = get(cw + ".weight", (int64_t)L.Cin * L.Cout * 4, &w))) return rc;
+      if ((rc = get(cw + ".bias", L.Cout, &b))) return rc;
+      HIPCHK(c, launch_pack_convt_w(w, L.wp, L.Cin, L.Cout, L.Kp, s));
+      HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 4, s));  // scale unused (nullptr at launch)
+    } else {
+      if ((rc = get(cw + ".weight", (int64_t)L.Cout * L.Cin * L.KS * L.KS, &w))) return rc;
+      if ((rc = get(cw + ".bias", L.Cout, &b))) return rc;
+      HIPCHK(c, launch_pack_conv_w(w, L.wp, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
+      if (!L.bn.empty()) {
+        const float *g, *be, *rm, *rv;
+        const std::string bn = L.prefix + L.bn;
+        if ((rc = get(bn + ".weight", L.Cout, &g))) return rc;
+        if ((rc = get(bn + ".bias", L.Cout, &be))) return rc;
+        if ((rc = get(bn + ".running_mean", L.Cout, &rm))) return rc;
+        if ((rc = get(bn + ".running_var", L.Cout, &rv))) return rc;
+        HIPCHK(c, launch_bn_fold(b, g, be, rm, rv, 1e-5f, L.scale, L.shift, L.Cout, s));
+      } else {
+        HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 1, s));
+      }
+    }
+  }
+  c->loaded = true;
+  return MGU_OK;
+}
+
+int mgu_unet_workspace_bytes(mgu_ctx* c, int B, int H, int W, int training, size_t* out) {
+  if (!c || !out) return MGU_ERR_INVALID;
+  if (!c->configured) return fail(c, MGU_ERR_STATE, "not configured");
+  (void)training;
+  *out = plan_ws(c, B, H, W).total;
+  return MGU_OK;
+}
+
+int mgu_unet_reserve(mgu_ctx* c, int B, int H, int W, int training) {
+  size_t need = 0;
+  int rc = mgu_unet_workspace_bytes(c, B, H, W, training, &need);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  return ensure(c, &c->ws, &c->ws_bytes, need);
+}
+
+static int run_conv(mgu_ctx* c, const Layer& L, const float* in, int ldin, int B, int H, int W, float* out, int ldout,
+                    int coff, int relu, int Hout, int Wout, hipStream_t s) {
+  IgemmDesc d;
+  d.in = in;
+  d.w = L.wp;
+  d.scale = L.bn.empty() ? nullptr : L.scale;
+  d.shift = L.shift;
+  d.out = out;
+  d.M = B * H * W;
+  d.H = H;
+  d.W = W;
+  d.Cp = L.Cp;
+  d.ldin = ldin;
+  d.KS = L.KS;
+  d.K = L.K;
+  d.Kp = L.Kp;
+  d.N = L.N;
+  d.ldout = ldout;
+  d.coff = coff;
+  d.relu = relu;
+  d.out_mode = L.convt ? 1 : 0;
+  d.ct_cout = L.Cout;
+  d.Hout = Hout;
+  d.Wout = Wout;
+  ProfScope ps(c, s);
+  HIPCHK(c, launch_igemm_f32(d, s));
+  return MGU_OK;
+}
+
+int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t xs_n, int64_t xs_c, int64_t xs_h,
+                     int64_t xs_w, void* logits_dev, void* const* cat_dev, void* const* feat_dev, int training,
+                     void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!c->configured || !c->loaded) return fail(c, MGU_ERR_STATE, "configure + load_weights must precede forward");
+  if (training) return fail(c, MGU_ERR_INVALID, "training-mode forward (batch-statistics BatchNorm) is not built yet");
+  if (!x_dev || !logits_dev || !cat_dev || !feat_dev) return fail(c, MGU_ERR_INVALID, "NULL buffer");
+  const int depth = c->depth;
+  if (B < 1 || H < (1 << depth) || W < (1 << depth))
+    return fail(c, MGU_ERR_INVALID, "input %dx%dx%d too small for depth %d", B, H, W, depth);
+  if ((int64_t)B * H * W >= (1ll << 31)) return fail(c, MGU_ERR_INVALID, "B*H*W must be < 2^31");
+  for (int i = 0; i < depth; ++i)
+    if (!cat_dev[i] || !feat_dev[i]) return fail(c, MGU_ERR_INVALID, "NULL cat/feat buffer %d", i);
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  const WsPlan plan = plan_ws(c, B, H, W);
+  int rc = ensure(c, &c->ws, &c->ws_bytes, plan.total);
+  if (rc) return rc;
+  char* ws = (char*)c->ws;
+  float* xin = (float*)(ws + plan.xin);
+  float* tmp = (float*)(ws + plan.tmp);
+  float* bott = (float*)(ws + plan.bott);
+  std::vector<int> hs, wsz;
+  level_dims(H, W, depth, hs, wsz);
+
+  if (c->prof) {
+    c->ev_used = 0;
+    for (auto& e : c->ev_total)
+      if (!e) HIPCHK(c, hipEventCreate(&e));
+    HIPCHK(c, hipEventRecord(c->ev_total[0], s));
+  }
+
+  // odd sizes: F.pad (unet_decoder.py:46-47) leaves a zero row/column in the up-sampled half
+  for (int i = 0; i < depth; ++i)
+    if (2 * hs[i + 1] != hs[i] || 2 * wsz[i + 1] != wsz[i])
+      HIPCHK(c, hipMemsetAsync(cat_dev[i], 0, (size_t)B * hs[i] * wsz[i] * 2 * ((size_t)c->feat << i) * sizeof(float), s));
+
+  HIPCHK(c, launch_pack_input((const float*)x_dev, xin, B, c->in_ch, c->Cp0, H, W, xs_n, xs_c, xs_h, xs_w, s));
+
+  int li = 0;
+  const float* cur = xin;
+  int cur_ld = c->Cp0;
+  for (int i = 0; i < depth; ++i) {  // encoder, unet_encoder.py:67-70
+    const int C = c->feat << i;
+    if ((rc = run_conv(c, c->layers[li++], cur, cur_ld, B, hs[i], wsz[i], tmp, C, 0, 1, 0, 0, s))) return rc;
+    if ((rc = run_conv(c, c->layers[li++], tmp, C, B, hs[i], wsz[i], (float*)cat_dev[i], 2 * C, 0, 1, 0, 0, s))) return rc;
+    float* pooled = (float*)(ws + plan.pooled[i]);
+    HIPCHK(c, launch_maxpool2((const float*)cat_dev[i], 2 * C, pooled, B, hs[i], wsz[i], C, s));
+    cur = pooled;
+    cur_ld = C;
+  }
+  {  // bottleneck, :72
+    const int C = c->feat << depth;
+    if ((rc = run_conv(c, c->layers[li++], cur, cur_ld, B, hs[depth], wsz[depth], tmp, C, 0, 1, 0, 0, s))) return rc;
+    if ((rc = run_conv(c, c->layers[li++], tmp, C, B, hs[depth], wsz[depth], bott, C, 0, 1, 0, 0, s))) return rc;
+    cur = bott;
+    cur_ld = C;
+  }
+  for (int b = 0; b < depth; ++b) {  // decoder, unet_decoder.py:139-141
+    const int i = depth - 1 - b;
+    const int C = c->feat << i;
+    // ConvTranspose2d(k2,s2) -> pixel-shuffle store into channels [C, 2C) of the concat buffer (:36,:53)
+    if ((rc = run_conv(c, c->layers[li++], cur, cur_ld, B, hs[i + 1], wsz[i + 1], (float*)cat_dev[i], 2 * C, C, 0, hs[i],
+                       wsz[i], s)))
+      return rc;
+    if ((rc = run_conv(c, c->layers[li++], (const float*)cat_dev[i], 2 * C, B, hs[i], wsz[i], tmp, C, 0, 1, 0, 0, s))) return rc;
+    if ((rc = run_conv(c, c->layers[li++], tmp, C, B, hs[i], wsz[i], (float*)feat_dev[i], C, 0, 1, 0, 0, s))) return rc;
+    cur = (const float*)feat_dev[i];
+    cur_ld = C;
+  }
+  // final 1x1 conv (:143)
+  if ((rc = run_conv(c, c->layers[li++], cur, cur_ld, B, H, W, (float*)logits_dev, c->ncls, 0, 0, 0, 0, s))) return rc;
+  if (c->prof) HIPCHK(c, hipEventRecord(c->ev_total[1], s));
+  return MGU_OK;
+}
+
+// scratch for the building-block entry points: packed panel + scale/shift, grown on demand
+static int block_scratch(mgu_ctx* c, int Np, int Kp, float** wp, float** scale, float** shift, hipStream_t s) {
+  const size_t need = ((size_t)Np * Kp + 2 * (size_t)Np) * sizeof(float);
+  int rc = ensure(c, &c->gws, &c->gws_bytes, need);
+  if (rc) return rc;
+  *wp = (float*)c->gws;
+  *scale = *wp + (size_t)Np * Kp;
+  *shift = *scale + Np;
+  HIPCHK(c, hipMemsetAsync(c->gws, 0, need, s));
+  return MGU_OK;
+}
+
+int mgu_conv2d_nhwc(mgu_ctx* c, const void* in_dev, int B, int H, int W, int Cin, const void* w_dev, const void* bias_dev,
+                    const void* scale_dev, const void* shift_dev, int Cout, int ksize, int relu, void* out_dev,
+                    int ld_out, int c_off, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!in_dev || !w_dev || !out_dev || B < 1 || H < 1 || W < 1 || Cout < 1 || (ksize != 1 && ksize != 3))
+    return fail(c, MGU_ERR_INVALID, "bad conv2d args (ksize must be 1 or 3)");
+  if (Cin < 4 || (Cin & 3)) return fail(c, MGU_ERR_INVALID, "conv2d needs Cin %% 4 == 0 (got %d)", Cin);
+  if (ld_out < c_off + Cout) return fail(c, MGU_ERR_INVALID, "ld_out %d < c_off %d + Cout %d", ld_out, c_off, Cout);
+  if ((int64_t)B * H * W >= (1ll << 31)) return fail(c, MGU_ERR_INVALID, "B*H*W must be < 2^31");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  Layer L;
+  L.Cin = L.Cp = Cin, L.Cout = Cout, L.KS = ksize;
+  L.K = ksize * ksize * Cin, L.Kp = rup(L.K, 32), L.N = Cout, L.Np = rup(Cout, 128);
+  float *sc, *sh;
+  int rc = block_scratch(c, L.Np, L.Kp, &L.wp, &sc, &sh, s);
+  if (rc) return rc;
+  HIPCHK(c, launch_pack_conv_w((const float*)w_dev, L.wp, Cout, Cin, Cin, ksize, L.Kp, s));
+  IgemmDesc d;
+  memset(&d, 0, sizeof d);
+  d.in = (const float*)in_dev, d.w = L.wp, d.out = (float*)out_dev;
+  d.M = B * H * W, d.H = H, d.W = W, d.Cp = Cin, d.ldin = Cin, d.KS = ksize, d.K = L.K, d.Kp = L.Kp;
+  d.N = Cout, d.ldout = ld_out, d.coff = c_off, d.relu = relu;
+  if (scale_dev && shift_dev) {  // y = scale*(conv) + shift, bias folded by the caller into shift
+    d.scale = (const float*)scale_dev;
+    d.shift = (const float*)shift_dev;
+  } else if (bias_dev) {
+    HIPCHK(c, launch_bias_tile((const float*)bias_dev, sh, Cout, 1, s));
+    d.shift = sh;
+  }
+  ProfScope ps(c, s);
+  HIPCHK(c, launch_igemm_f32(d, s));
+  return MGU_OK;
+}
+
+int mgu_conv_transpose2x2_nhwc(mgu_ctx* c, const void* in_dev, int B, int H, int W, int Cin, const void* w_dev,
+                               const void* bias_dev, int Cout, void* out_dev, int ld_out, int c_off, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!in_dev || !w_dev || !out_dev || B < 1 || H < 1 || W < 1 || Cout < 1) return fail(c, MGU_ERR_INVALID, "bad convT args");
+  if (Cin < 4 || (Cin & 3)) return fail(c, MGU_ERR_INVALID, "convT needs Cin %% 4 == 0 (got %d)", Cin);
+  if (ld_out < c_off + Cout) return fail(c, MGU_ERR_INVALID, "ld_out %d < c_off %d + Cout %d", ld_out, c_off, Cout);
+  if ((int64_t)B * H * W * 4 >= (1ll << 31)) return fail(c, MGU_ERR_INVALID, "4*B*H*W must be < 2^31");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int Kp = rup(Cin, 32), N = 4 * Cout, Np = rup(N, 128);
+  float *wp, *sc, *sh;
+  int rc = block_scratch(c, Np, Kp, &wp, &sc, &sh, s);
+  if (rc) return rc;
+  HIPCHK(c, launch_pack_convt_w((const float*)w_dev, wp, Cin, Cout, Kp, s));
+  IgemmDesc d;
+  memset(&d, 0, sizeof d);
+  d.in = (const float*)in_dev, d.w = wp, d.out = (float*)out_dev;
+  d.M = B * H * W, d.H = H, d.W = W, d.Cp = Cin, d.ldin = Cin, d.KS = 1, d.K = Cin, d.Kp = Kp;
+  d.N = N, d.ldout = ld_out, d.coff = c_off, d.out_mode = 1, d.ct_cout = Cout, d.Hout = 2 * H, d.Wout = 2 * W;
+  if (bias_dev) {
+    HIPCHK(c, launch_bias_tile((const float*)bias_dev, sh, Cout, 4, s));
+    d.shift = sh;
+  }
+  ProfScope ps(c, s);
+  HIPCHK(c, launch_igemm_f32(d, s));
+  return MGU_OK;
+}
+
+int mgu_maxpool2x2_nhwc(mgu_ctx* c, const void* in_dev, int ld_in, int B, int H, int W, int Cc, void* out_dev,
+                        void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!in_dev || !out_dev || B < 1 || H < 2 || W < 2 || Cc < 4 || (Cc & 3) || ld_in < Cc || (ld_in & 3))
+    return fail(c, MGU_ERR_INVALID, "bad maxpool args (C and ld_in must be multiples of 4, H,W >= 2)");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_maxpool2((const float*)in_dev, ld_in, (float*)out_dev, B, H, W, Cc, (hipStream_t)hip_stream));
+  return MGU_OK;
+}
+
+int mgu_argmax_classes(mgu_ctx* c, const void* logits_dev, int64_t npix, int num_classes, int64_t* pred_dev,
+                       void* hip_stream) {
+  if (!c || !logits_dev || !pred_dev || num_classes < 1 || npix < 0) return fail(c, MGU_ERR_INVALID, "bad argmax args");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_argmax((const float*)logits_dev, npix, num_classes, pred_dev, (hipStream_t)hip_stream));
+  return MGU_OK;
+}
+
+int mgu_patch_mean(mgu_ctx* c, const void* feat_dev, int B, int H, int W, int C, int patch, void* out_dev,
+                   void* hip_stream) {
+  if (!c || !feat_dev || !out_dev || B < 1 || H < 1 || W < 1 || patch < 1)
+    return fail(c, MGU_ERR_INVALID, "bad patch_mean args");
+  if ((C & 3) || C < 4 || C > 256) return fail(c, MGU_ERR_INVALID, "patch_mean needs C %% 4 == 0 and 4 <= C <= 256 (got %d)", C);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_patch_mean((const float*)feat_dev, (float*)out_dev, B, H, W, C, patch, (hipStream_t)hip_stream));
+  return MGU_OK;
+}
+
+int mgu_gat_layer_forward(mgu_ctx* c, const void* X_dev, int N, int Fin, const int32_t* rowptr_dev,
+                          const int32_t* col_dev, int64_t E, const int32_t* graph_ptr_dev, int num_graphs,
+                          const void* W_dev, const void* a_dev, int heads, int Fout_head, int concat, float alpha,
+                          void* out_dev, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (N < 0 || E < 0 || heads < 1 || heads > 32 || Fout_head < 4 || (Fout_head & 3) || Fin < 4 || (Fin & 3))
+    return fail(c, MGU_ERR_INVALID, "GAT layer needs Fin %% 4 == 0, Fout_head %% 4 == 0, 1 <= heads <= 32 (Fin=%d Fout=%d heads=%d)",
+                Fin, Fout_head, heads);
+  const int HF = heads * Fout_head;
+  if (HF > 1024) return fail(c, MGU_ERR_INVALID, "heads*Fout_head = %d exceeds 1024", HF);
+  if (N == 0) return MGU_OK;
+  if (!X_dev || !rowptr_dev || !W_dev || !a_dev || !out_dev || (E > 0 && !col_dev)) return fail(c, MGU_ERR_INVALID, "NULL buffer");
+  if (num_graphs < 1) num_graphs = 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  // scratch: Wh (N,HF) | st (2,N,heads) | packed W panel (HFp, Kp) | gmax (G,heads)
+  const int Kp = rup(Fin, 32), HFp = rup(HF, 128);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const size_t o_wh = take((size_t)N * HF * 4), o_st = take((size_t)2 * N * heads * 4);
+  const size_t o_wp = take((size_t)HFp * Kp * 4), o_gm = take((size_t)num_graphs * heads * 4);
+  int rc = ensure(c, &c->gws, &c->gws_bytes, off);
+  if (rc) return rc;
+  char* g = (char*)c->gws;
+  float* Wh = (float*)(g + o_wh);
+  float* st = (float*)(g + o_st);
+  float* wp = (float*)(g + o_wp);
+  unsigned* gmax = (unsigned*)(g + o_gm);
+  HIPCHK(c, hipMemsetAsync(wp, 0, (size_t)HFp * Kp * 4, s));
+  HIPCHK(c, hipMemsetAsync(gmax, 0, (size_t)num_graphs * heads * 4, s));
+  // nn.Linear weight (F',Fin) stacked over heads is already the [N][K] panel; only pad K to 32
+  HIPCHK(c, launch_pack_conv_w((const float*)W_dev, wp, HF, Fin, Fin, 1, Kp, s));
+  IgemmDesc d;
+  memset(&d, 0, sizeof d);
+  d.in = (const float*)X_dev;
+  d.w = wp;
+  d.out = Wh;
+  d.M = N, d.H = 1, d.W = N;
+  d.Cp = Fin, d.ldin = Fin, d.KS = 1, d.K = Fin, d.Kp = Kp;
+  d.N = HF, d.ldout = HF;
+  {
+    ProfScope ps(c, s);
+    HIPCHK(c, launch_igemm_f32(d, s));  // h = W(X), graph_attention.py:53, all heads at once
+  }
+  HIPCHK(c, launch_gat_st(Wh, (const float*)a_dev, st, N, heads, Fout_head, s));
+  HIPCHK(c, launch_gat_edge_max(st, rowptr_dev, col_dev, graph_ptr_dev, num_graphs, N, heads, alpha, gmax, s));
+  HIPCHK(c, launch_gat_aggregate(Wh, st, rowptr_dev, col_dev, graph_ptr_dev, num_graphs, gmax, N, heads, Fout_head,
+                                 concat, alpha, (float*)out_dev, s));
+  return MGU_OK;
+}
+
+double mgu_unet_flops(mgu_ctx* c, int B, int H, int W) {
+  if (!c || !c->configured) return -1.0;
+  std::vector<int> hs, wsz;
+  level_dims(H, W, c->depth, hs, wsz);
+  double fl = 0;
+  int li = 0;
+  for (int i = 0; i <= c->depth; ++i)
+    for (int j = 0; j < 2; ++j, ++li) {
+      const Layer& L = c->layers[li];
+      fl += 2.0 * hs[i] * wsz[i] * 9.0 * L.Cin * L.Cout;
+    }
+  for (int b = 0; b < c->depth; ++b) {
+    const int i = c->depth - 1 - b;
+    const Layer& U = c->layers[li++];
+    fl += 2.0 * hs[i + 1] * wsz[i + 1] * (double)U.Cin * U.Cout * 4.0;
+    for (int j = 0; j < 2; ++j, ++li) {
+      const Layer& L = c->layers[li];
+      fl += 2.0 * hs[i] * wsz[i] * 9.0 * L.Cin * L.Cout;
+    }
+  }
+  fl += 2.0 * H * W * (double)c->layers[li].Cin * c->ncls;
+  return fl * B;
+}
+
+int mgu_profile_enable(mgu_ctx* c, int on) {
+  if (!c) return MGU_ERR_INVALID;
+  c->prof = on != 0;
+  c->ev_used = 0;
+  return MGU_OK;
+}
+
+int mgu_profile_read(mgu_ctx* c, double* conv_ms, int* conv_launches, double* total_ms) {
+  if (!c) return MGU_ERR_INVALID;
+  if (c->ev_used == 0 || !c->ev_total[1]) return fail(c, MGU_ERR_STATE, "no profiled forward to read");
+  HIPCHK(c, hipEventSynchronize(c->ev_total[1]));
+  double sum = 0;
+  for (int i = 0; i < c->ev_used; ++i) {
+    float ms = 0;
+    HIPCHK(c, hipEventSynchronize(c->ev[2 * i + 1]));
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]));
+    sum += ms;
+  }
+  float tot = 0;
+  HIPCHK(c, hipEventElapsedTime(&tot, c->ev_total[0], c->ev_total[1]));
+  if (conv_ms) *conv_ms = sum;
+  if (conv_launches) *conv_launches = c->ev_used;
+  if (total_ms) *total_ms = tot;
+  return MGU_OK;
+}
+
+}  // extern "C"

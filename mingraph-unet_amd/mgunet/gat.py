@@ -1,0 +1,167 @@
+"""Host-side mirror of model/gat/graph_attention.py routed through libmgunet.so.
+
+Same classes, constructor signatures and state_dict() keys (`gat_layers.{l}.heads.{h}.W.weight`,
+`...a.weight`).  forward(node_features, edge_index) takes the reference's COO int64 (2,E) edge_index;
+the CSR-by-target the HIP kernels consume is derived once per edge_index tensor and cached.
+All heads of a layer run in ONE kernel sequence (the reference loops over heads in Python,
+graph_attention.py:151).  Eval-mode semantics (dropout = identity); train mode is accepted only with
+dropout_rate == 0, because the reference's train-mode output depends on torch's dropout RNG stream.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def coo_to_csr_device(edge_index: torch.Tensor, num_nodes: int):
+    """Stable COO -> CSR-by-target on the tensor's device (torch index plumbing, cached by callers)."""
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError("edge_index must have shape (2, E)")
+    if edge_index.dtype != torch.int64:
+        raise TypeError("edge_index must be int64 (torch.long) like the reference's")
+    E = edge_index.shape[1]
+    if E:
+        lo, hi = int(edge_index.min()), int(edge_index.max())
+        if lo < 0 or hi >= num_nodes:
+            raise IndexError(f"edge_index values must be in [0, {num_nodes}); got [{lo}, {hi}]")
+    tgt = edge_index[1]
+    order = torch.argsort(tgt, stable=True)
+    col = edge_index[0][order].to(torch.int32).contiguous()
+    rowptr = torch.zeros(num_nodes + 1, dtype=torch.int32, device=edge_index.device)
+    if E:
+        rowptr[1:] = torch.cumsum(torch.bincount(tgt, minlength=num_nodes), 0).to(torch.int32)
+    return rowptr, col
+
+
+class GraphAttentionLayer(nn.Module):
+    """One attention head (graph_attention.py:5-118): parameter holder + single-head forward."""
+
+    def __init__(self, in_features, out_features, dropout_rate, alpha, concat=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.dropout_rate, self.alpha, self.concat = dropout_rate, alpha, concat
+        self.W = nn.Linear(in_features, out_features, bias=False)
+        self.a = nn.Linear(2 * out_features, 1, bias=False)
+        self.leakyrelu = nn.LeakyReLU(self.alpha)
+        self.dropout = nn.Dropout(self.dropout_rate)
+        nn.init.xavier_uniform_(self.W.weight, gain=1.414)  # :36-37
+        nn.init.xavier_uniform_(self.a.weight, gain=1.414)
+
+    def forward(self, node_features, edge_index, graph_ptr=None):
+        return _gat_layer_forward([self], node_features, edge_index, True, self.alpha, self.training,
+                                  self.dropout_rate, graph_ptr, _csr_cache(self))
+
+
+def _csr_cache(mod):
+    c = mod.__dict__.get("_mgu_csr_cache")
+    if c is None:
+        c = {}
+        mod.__dict__["_mgu_csr_cache"] = c
+    return c
+
+
+_CTX = {}
+
+
+def _context(device: torch.device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ctx = _CTX.get(idx)
+    if ctx is None:
+        ctx = _CTX[idx] = _lib.Context(idx)
+    return ctx
+
+
+def _gat_layer_forward(heads, X, edge_index, concat, alpha, training, dropout_rate, graph_ptr, cache):
+    if training and dropout_rate > 0:
+        raise RuntimeError("train-mode GAT applies torch-RNG dropout to attention coefficients "
+                           "(graph_attention.py:97,160); the HIP path implements eval mode -- call .eval() "
+                           "or construct with dropout_rate=0")
+    if not X.is_cuda:
+        raise RuntimeError("mgunet GAT runs only on a HIP device (MI355X); there is deliberately no CPU fallback")
+    if X.dtype != torch.float32:
+        raise TypeError(f"expected float32 node features, got {X.dtype}")
+    if X.dim() != 2:
+        raise ValueError("node_features must be (N, F)")
+    dev = X.device
+    N, Fin = X.shape
+    H = len(heads)
+    Fh = heads[0].out_features
+    if Fh % 4:
+        raise ValueError("per-head output width must be a multiple of 4 (16-byte lanes)")
+    W = torch.cat([h.W.weight for h in heads], 0).detach()          # (H*Fh, Fin)
+    a = torch.cat([h.a.weight for h in heads], 0).detach()          # (H, 2*Fh)
+    if W.shape[1] != Fin:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({N}x{Fin} and {W.shape[1]}x{Fh})")
+    Xc = X.detach().contiguous()
+    if Fin % 4:  # zero-pad K to a multiple of 4: exact
+        pad = 4 - Fin % 4
+        Xc, W = F.pad(Xc, (0, pad)), F.pad(W, (0, pad))
+    W, a = W.contiguous(), a.contiguous()
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, N, str(edge_index.device))
+    ent = cache.get(key)
+    if ent is None:
+        rowptr, col = coo_to_csr_device(edge_index.to(dev), N)
+        cache.clear()
+        ent = cache[key] = (rowptr, col, edge_index)  # keep the key tensor alive so data_ptr stays unique
+    rowptr, col = ent[0], ent[1]
+    G, gp_ptr = 1, None
+    if graph_ptr is not None:
+        gp = graph_ptr.to(device=dev, dtype=torch.int32).contiguous()
+        G, gp_ptr = gp.numel() - 1, gp.data_ptr()
+    out = torch.empty((N, H * Fh if concat else Fh), device=dev, dtype=torch.float32)
+    ctx = _context(dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mgu_gat_layer_forward(ctx.handle, Xc.data_ptr(), N, Xc.shape[1], rowptr.data_ptr(),
+                                              col.data_ptr() if col.numel() else None, col.numel(), gp_ptr, G,
+                                              W.data_ptr(), a.data_ptr(), H, Fh, 1 if concat else 0, float(alpha),
+                                              out.data_ptr(), _lib.current_stream_ptr(dev))
+    _lib.check(rc, ctx.handle)
+    return out
+
+
+class MultiHeadGATLayer(nn.Module):
+    """graph_attention.py:120-160: all heads in one launch sequence; concat (:155) or mean (:158)."""
+
+    def __init__(self, in_features, out_features, num_heads, dropout_rate, alpha, concat=True):
+        super().__init__()
+        self.num_heads, self.concat = num_heads, concat
+        self.alpha, self.dropout_rate = alpha, dropout_rate
+        if concat:
+            assert out_features % num_heads == 0, "out_features must be divisible by num_heads if concatenating"
+            self.head_out_features = out_features // num_heads
+        else:
+            self.head_out_features = out_features
+        self.heads = nn.ModuleList(
+            [GraphAttentionLayer(in_features, self.head_out_features, dropout_rate, alpha) for _ in range(num_heads)])
+        self.dropout = nn.Dropout(dropout_rate)
+
+    def forward(self, node_features, edge_index, graph_ptr=None):
+        return _gat_layer_forward(list(self.heads), node_features, edge_index, self.concat, self.alpha,
+                                  self.training, self.dropout_rate, graph_ptr, _csr_cache(self))
+
+
+class GATNetwork(nn.Module):
+    """Drop-in for graph_attention.py:162-192 (same layer wiring, including the reference's
+    multi-layer width mismatch: num_gat_layers >= 2 only works with num_heads == 1)."""
+
+    def __init__(self, node_feature_dim, hidden_dim, output_dim, num_heads, num_gat_layers=1, dropout_rate=0.1,
+                 alpha=0.2):
+        super().__init__()
+        self.num_gat_layers = num_gat_layers
+        self.gat_layers = nn.ModuleList()
+        if num_gat_layers == 1:
+            self.gat_layers.append(MultiHeadGATLayer(node_feature_dim, output_dim, num_heads, dropout_rate, alpha, concat=False))
+        else:
+            self.gat_layers.append(MultiHeadGATLayer(node_feature_dim, hidden_dim, num_heads, dropout_rate, alpha, concat=True))
+            for _ in range(num_gat_layers - 2):
+                self.gat_layers.append(MultiHeadGATLayer(hidden_dim * num_heads, hidden_dim, num_heads, dropout_rate, alpha, concat=True))
+            self.gat_layers.append(MultiHeadGATLayer(hidden_dim * num_heads, output_dim, num_heads, dropout_rate, alpha, concat=False))
+
+    def forward(self, node_features, edge_index, graph_ptr=None):
+        h = node_features
+        for layer in self.gat_layers:
+            h = layer(h, edge_index, graph_ptr)
+        return h

@@ -1,0 +1,130 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/mgunet.h declares, the
+host-side index routines are bit-exact, and the Python mirror keeps the reference's API surface.
+No compute call is made here (no GPU in this tier)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import mgunet
+import mgunet_oracle as O
+from mgunet import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "mgunet.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mgu_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = header_symbols()
+    assert len(syms) >= 15
+    L = _lib.lib()
+    for s in syms:
+        assert hasattr(L, s), f"libmgunet.so does not export {s}"
+        assert s in _lib._PROTOS, f"ctypes prototype missing for {s}"
+    assert sorted(_lib._PROTOS) == syms
+
+
+def test_create_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = _lib.lib().mgu_create(0, C.byref(h))
+    assert rc == _lib.MGU_ERR_HIP
+    assert b"no CPU fallback" in _lib.lib().mgu_last_error(None)
+    with pytest.raises(RuntimeError):
+        _lib.Context(0)
+
+
+@pytest.mark.parametrize("tag,H,W,p", [("g128", 128, 128, 32), ("g130", 130, 140, 32), ("g512", 512, 512, 16),
+                                        ("g1024", 1024, 1024, 16), ("g1", 16, 16, 16), ("grow", 16, 80, 16)])
+def test_patch_graph_build_bit_exact(golden, tag, H, W, p):
+    pgc = mgunet.PatchGraphConstructor(p)
+    nph, npw = O.patch_grid(H, W, p)
+    feats = torch.zeros(nph * npw, 3)
+    f2, ei = pgc.construct_patch_graph(torch.zeros(1, H, W), feats)
+    assert f2 is feats
+    assert ei.dtype == torch.int64 and tuple(ei.shape) == golden["patch_graph"][tag].shape
+    assert np.array_equal(ei.numpy(), golden["patch_graph"][tag])
+    coo, rowptr, col, a, b = pgc._maps(H, W)
+    orp, ocol, _ = O.coo_to_csr(O.patch_graph_edges(H, W, p), nph * npw)
+    assert (a, b) == (nph, npw) and np.array_equal(rowptr, orp) and np.array_equal(col, ocol)
+
+
+def test_patch_graph_feature_count_mismatch_raises_valueerror():
+    with pytest.raises(ValueError, match="does not match expected number of patches"):
+        mgunet.PatchGraphConstructor(32).construct_patch_graph(torch.zeros(3, 128, 128), torch.zeros(15, 4))
+
+
+def test_coo_to_csr_host_random_graph():
+    rng = np.random.default_rng(0)
+    N, E = 97, 1000
+    coo = rng.integers(0, N, size=(2, E)).astype(np.int64)
+    rp, cl = np.empty(N + 1, np.int32), np.empty(E, np.int32)
+    rc = _lib.lib().mgu_coo_to_csr(coo.ctypes.data_as(C.c_void_p), E, N, rp.ctypes.data_as(C.c_void_p),
+                                   cl.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    orp, ocol, _ = O.coo_to_csr(coo, N)
+    assert np.array_equal(rp, orp) and np.array_equal(cl, ocol)
+    bad = coo.copy()
+    bad[1, 5] = N
+    assert _lib.lib().mgu_coo_to_csr(bad.ctypes.data_as(C.c_void_p), E, N, rp.ctypes.data_as(C.c_void_p),
+                                     cl.ctypes.data_as(C.c_void_p)) == _lib.MGU_ERR_INVALID
+
+
+def test_image_to_patches_matches_oracle():
+    img = torch.from_numpy(O.formula_normal("graph/img", (5, 37, 45), seed=2))
+    a, (h, w) = mgunet.PatchGraphConstructor(16).image_to_patches(img)
+    b, (oh, ow) = O.image_to_patches(img, 16)
+    assert (h, w) == (oh, ow) == (3, 3) and torch.equal(a, b)
+
+
+def test_state_dict_keys_match_reference_names():
+    m = mgunet.UNet(3, 2, 32, 4)
+    assert list(m.state_dict().keys()) == list(O.unet_param_shapes(3, 2, 32, 4).keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(O.unet_param_shapes(3, 2, 32, 4)[k]), k
+    assert sum(p.numel() for p in m.parameters()) == 7766018
+    m.load_state_dict(O.make_unet_params(3, 2, 32, 4))  # bare state_dict layout (infer_segmentation.py:92-95)
+    g = mgunet.GATNetwork(20, 128, 64, 4, 1)
+    shapes, _ = O.gat_param_shapes(20, 128, 64, 4, 1)
+    assert list(g.state_dict().keys()) == list(shapes.keys())
+    g2 = mgunet.GATNetwork(32, 24, 8, 1, num_gat_layers=2)
+    shapes2, _ = O.gat_param_shapes(32, 24, 8, 1, 2)
+    assert {k: tuple(v.shape) for k, v in g2.state_dict().items()} == dict(shapes2)
+
+
+def test_cpu_inputs_are_refused_not_silently_computed():
+    m = mgunet.UNet(1, 2, 8, 2).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 32, 32))
+    g = mgunet.GATNetwork(8, 8, 8, 2).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        g(torch.zeros(4, 8), torch.zeros(2, 0, dtype=torch.long))
+    with pytest.raises(ValueError):
+        mgunet.UNet(3, 2, 30, 4)
+
+
+def test_config_keys_and_builder():
+    mc = mgunet.load_config(mgunet.config.DEFAULT_CONFIG_DIR, "model.yaml")
+    assert mgunet.get_config_recursively(mc, "unet.init_features") == 32
+    assert mgunet.get_config_recursively(mc, "gat.nope", 7) == 7
+    u, g, pgc, mc, tc = mgunet.build_from_config()
+    assert (u.in_channels, u.num_classes, u.init_features, u.depth) == (3, 2, 32, 4)
+    assert pgc.patch_size == 16 and tc["learning_rate"] == 0.001 and tc["weight_decay"] == 0.0001
+
+
+def test_shard_batch_covers_batch_exactly():
+    for gb in (1, 7, 8, 64, 33):
+        for ws in (1, 2, 3, 8):
+            spans = [mgunet.shard_batch(gb, r, ws) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == gb
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1

@@ -1,0 +1,125 @@
+"""Kernel-level parity through the building-block C-ABI entry points (mgu_conv2d_nhwc,
+mgu_conv_transpose2x2_nhwc, mgu_maxpool2x2_nhwc) against plain torch fp32 CPU ops.  These isolate the
+implicit-GEMM tile configurations (N <= 32, <= 64, > 64), the K tail, the M tail, image borders and the
+channel-slice (concat) stores."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mgunet_oracle as O
+from mgunet import _lib
+from mgunet.gat import _context
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def conv_gpu(cuda, x, w, b, k, relu, ld_out=None, c_off=0, scale=None, shift=None):
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    ld_out = ld_out or Cout
+    xin, wd, bd = nhwc(x).to(cuda), w.contiguous().to(cuda), b.to(cuda)
+    out = torch.full((B, H, W, ld_out), -7.0, device=cuda)
+    sc = scale.to(cuda) if scale is not None else None
+    sh = shift.to(cuda) if shift is not None else None
+    ctx = _context(cuda)
+    rc = _lib.lib().mgu_conv2d_nhwc(ctx.handle, xin.data_ptr(), B, H, W, Cin, wd.data_ptr(), bd.data_ptr(),
+                                    sc.data_ptr() if sc is not None else None, sh.data_ptr() if sh is not None else None,
+                                    Cout, k, relu, out.data_ptr(), ld_out, c_off, _lib.current_stream_ptr(cuda))
+    _lib.check(rc, ctx.handle)
+    return out.cpu()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k", [
+    (1, 8, 8, 4, 8, 3),        # K=36: K tail inside a 32-step, tiny M
+    (2, 13, 17, 8, 32, 3),     # odd sizes, N == 32 tile
+    (1, 20, 24, 32, 64, 3),    # N == 64 tile
+    (1, 9, 31, 64, 160, 3),    # N > 128: two N tiles + N tail, M tail
+    (1, 16, 16, 128, 128, 3),  # tap-uniform K steps
+    (3, 7, 5, 16, 2, 1),       # 1x1 head: N = 2
+    (1, 33, 9, 36, 40, 1),     # 1x1, K = 36
+    (1, 40, 40, 12, 20, 3),    # Cp = 12: taps straddle K steps
+])
+def test_conv2d_vs_torch(cuda, B, H, W, Cin, Cout, k):
+    x = torch.from_numpy(O.formula_normal("kc/x", (B, Cin, H, W), seed=Cin))
+    w = torch.from_numpy(O.formula_uniform("kc/w", (Cout, Cin, k, k), -0.2, 0.2, seed=Cout))
+    b = torch.from_numpy(O.formula_uniform("kc/b", (Cout,), -0.5, 0.5, seed=3))
+    ref = F.conv2d(x, w, b, padding=k // 2)
+    got = conv_gpu(cuda, x, w, b, k, 0)
+    assert float((got.permute(0, 3, 1, 2) - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    got = conv_gpu(cuda, x, w, b, k, 1)
+    assert float((got.permute(0, 3, 1, 2) - F.relu(ref)).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv2d_exact_integer_data_asymmetric(cuda):
+    """Small-integer operands: every product and partial sum is exact in fp32, so the MFMA tile
+    mapping (row/col, k order, tap order) must reproduce torch bit for bit.  Asymmetric weights catch
+    transposed fragments; a delta input catches tap flips."""
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(rng.integers(-3, 4, size=(2, 8, 11, 14)).astype(np.float32))
+    w = torch.from_numpy(rng.integers(-2, 3, size=(40, 8, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(rng.integers(-5, 6, size=(40,)).astype(np.float32))
+    ref = F.conv2d(x, w, b, padding=1)
+    got = conv_gpu(cuda, x, w, b, 3, 0).permute(0, 3, 1, 2)
+    assert torch.equal(got, ref)
+    d = torch.zeros(1, 4, 9, 9)
+    d[0, 1, 4, 4] = 1.0
+    w2 = torch.arange(4 * 4 * 9, dtype=torch.float32).reshape(4, 4, 3, 3)
+    assert torch.equal(conv_gpu(cuda, d, w2, torch.zeros(4), 3, 0).permute(0, 3, 1, 2), F.conv2d(d, w2, None, padding=1))
+
+
+def test_conv2d_scale_shift_relu_and_channel_slice_store(cuda):
+    x = torch.from_numpy(O.formula_normal("ks/x", (1, 16, 12, 10), seed=1))
+    w = torch.from_numpy(O.formula_uniform("ks/w", (24, 16, 3, 3), -0.2, 0.2, seed=1))
+    b = torch.zeros(24)
+    sc = torch.from_numpy(O.formula_uniform("ks/sc", (24,), 0.5, 1.5, seed=1))
+    sh = torch.from_numpy(O.formula_uniform("ks/sh", (24,), -0.5, 0.5, seed=1))
+    ref = F.relu(F.conv2d(x, w, None, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    got = conv_gpu(cuda, x, w, b, 3, 1, ld_out=64, c_off=32, scale=sc, shift=sh)
+    assert float((got[..., 32:56].permute(0, 3, 1, 2) - ref).abs().max()) <= 2e-5
+    assert torch.all(got[..., :32] == -7.0) and torch.all(got[..., 56:] == -7.0)  # neighbours untouched
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 4, 4, 8, 4), (2, 5, 7, 32, 16), (1, 8, 8, 64, 32), (1, 3, 9, 256, 128)])
+def test_conv_transpose2x2_vs_torch(cuda, B, H, W, Cin, Cout):
+    x = torch.from_numpy(O.formula_normal("kt/x", (B, Cin, H, W), seed=Cin))
+    w = torch.from_numpy(O.formula_uniform("kt/w", (Cin, Cout, 2, 2), -0.2, 0.2, seed=Cout))
+    b = torch.from_numpy(O.formula_uniform("kt/b", (Cout,), -0.5, 0.5, seed=3))
+    ref = F.conv_transpose2d(x, w, b, stride=2)
+    ld, off = 2 * Cout, Cout
+    out = torch.full((B, 2 * H, 2 * W, ld), -7.0, device=cuda)
+    xin, wd, bd = nhwc(x).to(cuda), w.contiguous().to(cuda), b.to(cuda)
+    ctx = _context(cuda)
+    rc = _lib.lib().mgu_conv_transpose2x2_nhwc(ctx.handle, xin.data_ptr(), B, H, W, Cin, wd.data_ptr(), bd.data_ptr(), Cout,
+                                               out.data_ptr(), ld, off, _lib.current_stream_ptr(cuda))
+    _lib.check(rc, ctx.handle)
+    out = out.cpu()
+    assert float((out[..., off:].permute(0, 3, 1, 2) - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.all(out[..., :off] == -7.0)
+
+
+@pytest.mark.parametrize("B,H,W,Cc,ld", [(1, 8, 8, 4, 4), (2, 9, 13, 8, 16), (1, 6, 4, 32, 64)])
+def test_maxpool_vs_torch(cuda, B, H, W, Cc, ld):
+    x = torch.from_numpy(O.formula_normal("kp/x", (B, ld, H, W), seed=H))
+    xin = nhwc(x).to(cuda)
+    out = torch.empty((B, H // 2, W // 2, Cc), device=cuda)
+    ctx = _context(cuda)
+    rc = _lib.lib().mgu_maxpool2x2_nhwc(ctx.handle, xin.data_ptr(), ld, B, H, W, Cc, out.data_ptr(), _lib.current_stream_ptr(cuda))
+    _lib.check(rc, ctx.handle)
+    assert torch.equal(out.cpu().permute(0, 3, 1, 2), F.max_pool2d(x[:, :Cc], 2, 2))
+
+
+def test_invalid_arguments_return_errors_not_faults(cuda):
+    ctx = _context(cuda)
+    t = torch.zeros(64, device=cuda)
+    L = _lib.lib()
+    assert L.mgu_conv2d_nhwc(ctx.handle, t.data_ptr(), 1, 4, 4, 3, t.data_ptr(), None, None, None, 4, 3, 0, t.data_ptr(), 4, 0, None) == _lib.MGU_ERR_INVALID
+    assert L.mgu_conv2d_nhwc(ctx.handle, t.data_ptr(), 1, 4, 4, 4, t.data_ptr(), None, None, None, 4, 5, 0, t.data_ptr(), 4, 0, None) == _lib.MGU_ERR_INVALID
+    assert L.mgu_conv2d_nhwc(ctx.handle, t.data_ptr(), 1, 4, 4, 4, t.data_ptr(), None, None, None, 4, 3, 0, t.data_ptr(), 2, 0, None) == _lib.MGU_ERR_INVALID
+    assert b"ld_out" in L.mgu_last_error(ctx.handle)

@@ -1,0 +1,117 @@
+"""The oracle restatement (oracle/mgunet_oracle.py) against the fixtures generated FROM THE REFERENCE
+(oracle/make_golden.py).  CPU only.  This is what pins the oracle on boxes without /root/reference."""
+import numpy as np
+import pytest
+import torch
+
+import mgunet_oracle as O
+
+
+def sample_idx(name, numel, n):
+    u = O.formula_uniform(name, (n,), 0.0, 1.0, 7).astype(np.float64)
+    return np.minimum((u * numel).astype(np.int64), numel - 1)
+
+
+@pytest.mark.parametrize("tag,cfg,shape", [("a", (1, 2, 8, 2), (1, 1, 32, 32)), ("b", (3, 3, 8, 2), (2, 3, 37, 45)),
+                                           ("c", (3, 2, 8, 3), (2, 3, 64, 48))])
+def test_unet_tiny_eval_and_train(golden, tag, cfg, shape):
+    g = golden["unet_tiny"]
+    p = O.make_unet_params(*cfg, seed=11)
+    x = torch.from_numpy(O.formula_normal(f"tiny/{tag}/x", shape, seed=11))
+    with torch.no_grad():
+        lg, sk, ft = O.unet_forward(p, x, cfg[3])
+        stats = {}
+        lgt, _, _ = O.unet_forward(p, x, cfg[3], training=True, new_stats=stats)
+    assert np.abs(lg.numpy() - g[f"{tag}_logits"]).max() <= 1e-5
+    for i in range(cfg[3]):
+        assert np.abs(sk[i].numpy() - g[f"{tag}_skip{i}"]).max() <= 1e-5
+        assert np.abs(ft[i].numpy() - g[f"{tag}_feat{i}"]).max() <= 1e-5
+    assert np.abs(lgt.numpy() - g[f"{tag}_train_logits"]).max() <= 2e-5
+    assert np.abs(stats["encoder.encoder_blocks.0.bn1.running_mean"].numpy() - g[f"{tag}_bn_rm_first"]).max() <= 1e-6
+    assert np.abs(stats["encoder.encoder_blocks.0.bn1.running_var"].numpy() - g[f"{tag}_bn_rv_first"]).max() <= 1e-6
+
+
+def test_unet_param_count_and_keys():
+    shapes = O.unet_param_shapes(3, 2, 32, 4)
+    n = sum(int(np.prod(s)) for k, s in shapes.items() if "running_" not in k and "num_batches" not in k)
+    assert n == 7766018  # SURVEY section 4, measured on the reference
+
+
+def test_gat_small(golden):
+    g = golden["gat_small"]
+    e10 = torch.from_numpy(g["edge10"])
+    X10 = torch.from_numpy(O.formula_normal("gat/x10", (10, 32), seed=3))
+    cases = [("g10", (32, 64, 16, 4), X10, e10, 1.0, 1),
+             ("iso", (32, 64, 16, 4), torch.from_numpy(O.formula_normal("gat/x12", (12, 32), seed=3)),
+              torch.from_numpy(g["edge_iso"]), 1.0, 1),
+             ("wide", (32, 64, 16, 2), torch.from_numpy(O.formula_normal("gat/xw", (10, 32), seed=4)) * 4.0, e10, 3.0, 1),
+             ("mid", (32, 64, 16, 4), torch.from_numpy(O.formula_normal("gat/xm", (10, 32), seed=6)) * 2.0, e10, 1.5, 1),
+             ("l2h1", (32, 24, 8, 1), X10, e10, 1.0, 2)]
+    for tag, cfg, X, ei, scale, layers in cases:
+        p = O.make_gat_params(cfg[0], cfg[1], cfg[2], cfg[3], layers, seed=3, scale=scale)
+        with torch.no_grad():
+            y = O.gat_network_forward(p, X, ei, cfg[3], layers)
+        assert np.abs(y.numpy() - g[tag + "_out"]).max() <= 1e-5, tag
+    assert np.all(g["iso_out"][10:] == 0.0)  # targets without in-edges are exactly zero
+
+
+@pytest.mark.parametrize("tag,H,W,p,nodes,edges", [("g128", 128, 128, 32, 16, 48), ("g130", 130, 140, 32, 25, 80),
+                                                    ("g512", 512, 512, 16, 1024, 3968),
+                                                    ("g1024", 1024, 1024, 16, 4096, 16128), ("g1", 16, 16, 16, 1, 0),
+                                                    ("grow", 16, 80, 16, 5, 8)])
+def test_patch_graph_bit_exact(golden, tag, H, W, p, nodes, edges):
+    ei = O.patch_graph_edges(H, W, p)
+    ref = golden["patch_graph"][tag]
+    assert ei.dtype == np.int64 and ei.shape == (2, edges) and ref.shape == (2, edges)
+    assert np.array_equal(ei, ref)
+    nph, npw = O.patch_grid(H, W, p)
+    assert nph * npw == nodes
+    if tag == "g512":  # SURVEY section 4 known answer
+        assert ei[:, :8].tolist() == [[0, 1, 0, 32, 1, 2, 1, 33], [1, 0, 32, 0, 2, 1, 33, 1]]
+
+
+def test_patch_mean_non_divisible(golden):
+    img = torch.from_numpy(O.formula_normal("graph/img", (5, 37, 45), seed=2))
+    got = O.patch_mean_features(img, 16).numpy()
+    assert np.abs(got - golden["patch_graph"]["patches_37x45_mean"]).max() <= 1e-6
+
+
+def test_c1_sampled_logits(golden):
+    g = golden["c1"]
+    p = O.make_unet_params(1, 2, 32, 4, seed=0)
+    x = torch.from_numpy(O.formula_normal("c1/x", (1, 1, 256, 256), seed=0))
+    with torch.no_grad():
+        lg, sk, ft = O.unet_forward(p, x, 4)
+    assert np.array_equal(g["idx"], sample_idx("c1/idx", lg.numel(), 4096))
+    assert np.abs(lg.reshape(-1)[g["idx"]].numpy() - g["logits"]).max() <= 1e-5
+    sums = np.array([[float(t.double().sum()), float(t.double().abs().sum())] for t in [lg] + sk + ft])
+    assert np.allclose(sums, g["sums"], rtol=1e-6, atol=1e-3)
+
+
+def test_c2_image0_and_gat(golden):
+    g = golden["c2"]
+    p = O.make_unet_params(3, 2, 32, 4, seed=0)
+    gp = O.make_gat_params(32, 128, 64, 4, 1, seed=0)
+    x = torch.from_numpy(O.formula_normal("c2/x/0", (1, 3, 512, 512), seed=1))
+    ei = torch.from_numpy(O.patch_graph_edges(512, 512, 16))
+    with torch.no_grad():
+        lg, _, ft = O.unet_forward(p, x, 4)
+        X = O.patch_mean_features(ft[0][0], 16)
+        y = O.gat_network_forward(gp, X, ei, 4)
+    assert np.abs(lg.reshape(-1)[g["idx_0"]].numpy() - g["logits_0"]).max() <= 1e-5
+    assert np.abs(y.reshape(-1)[g["gidx_0"]].numpy() - g["gat_0"]).max() <= 1e-5
+
+
+def test_c5_small_train_step(golden):
+    g = golden["c5"]
+    p = O.make_unet_params(3, 2, 32, 4, seed=0)
+    x = torch.from_numpy(O.formula_normal("c5/s/x", (2, 3, 128, 128), seed=4))
+    y = torch.from_numpy(O.formula_labels("c5/s/y", (2, 128, 128), 2, seed=5))
+    loss, grads, newp, stats, _, _ = O.train_step(p, x, y, 4)
+    assert abs(float(loss) - float(g["s_loss"])) <= 1e-5
+    names = [str(n) for n in g["param_names"]]
+    gn = np.array([float(grads[k].norm()) for k in names])
+    assert np.allclose(gn, g["s_grad_norms"], rtol=2e-3, atol=1e-7)
+    flat_p = torch.cat([newp[k].reshape(-1) for k in names])
+    assert np.abs(flat_p[g["s_idx"]].numpy() - g["s_param_s"]).max() <= 2e-5
+    assert np.abs(stats["encoder.encoder_blocks.0.bn1.running_mean"].numpy() - g["s_bn_rm"]).max() <= 1e-5
