@@ -29,11 +29,23 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(batch, H, W, iters):
     """The oracle (CPU restatement of the reference path, same aten/oneDNN kernels the reference's
     modules dispatch to) timed on this box's host cores on a bounded sample of the same workload."""
     import mgunet_oracle as O
-    threads = os.cpu_count() or 1
+    threads = min(host_cores(), int(os.environ.get("MGU_CPU_THREADS", "16")))  # the 1-GPU box's CPU share is 16
     torch.set_num_threads(threads)
     p = O.make_unet_params(3, 2, 32, 4, seed=0)
     gp = O.make_gat_params(32, 128, 64, 4, 1, seed=0)

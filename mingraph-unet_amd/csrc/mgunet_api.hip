@@ -368,7 +368,7 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
                      void* hip_stream) {
   if (!c) return MGU_ERR_INVALID;
   if (!c->configured || !c->loaded) return fail(c, MGU_ERR_STATE, "configure + load_weights must precede forward");
-  if (training) return fail(c, MGU_ERR_INVALID, "training-mode forward (batch-statistics BatchNorm) is not built yet");
+  if (training) return fail(c, MGU_ERR_STATE, "training-mode forward (batch-statistics BatchNorm) is not built yet");
   if (!x_dev || !logits_dev || !cat_dev || !feat_dev) return fail(c, MGU_ERR_INVALID, "NULL buffer");
   const int depth = c->depth;
   if (B < 1 || H < (1 << depth) || W < (1 << depth))

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .gat import GATNetwork, _context
+from .gat import GATNetwork, _context, _csr_cache, stacked_head_weights
 from .patch_graph import PatchGraphConstructor
 from .unet import UNet
 
@@ -45,8 +45,7 @@ def gat_forward_csr(gat: GATNetwork, X, rowptr, col, graph_ptr):
             raise RuntimeError("GAT HIP path implements eval mode: call .eval() (see mgunet.gat)")
         heads = list(layer.heads)
         Fh, H = heads[0].out_features, len(heads)
-        W = torch.cat([hd.W.weight for hd in heads], 0).detach().contiguous()
-        a = torch.cat([hd.a.weight for hd in heads], 0).detach().contiguous()
+        W, a = stacked_head_weights(heads, _csr_cache(layer))
         if h.shape[1] % 4 or W.shape[1] != h.shape[1]:
             raise ValueError("node feature width must be a multiple of 4 and match W")
         h = h.contiguous()

@@ -74,6 +74,19 @@ def _context(device: torch.device):
     return ctx
 
 
+def stacked_head_weights(heads, cache):
+    """(H*Fh, Fin4) W panel and (H, 2*Fh) a panel of a layer's heads, rebuilt only when a parameter changes."""
+    sig = tuple((h.W.weight.data_ptr(), h.W.weight._version, h.a.weight.data_ptr(), h.a.weight._version) for h in heads)
+    ent = cache.get("weights")
+    if ent is None or ent[0] != sig:
+        W = torch.cat([h.W.weight for h in heads], 0).detach()
+        a = torch.cat([h.a.weight for h in heads], 0).detach().contiguous()
+        if W.shape[1] % 4:
+            W = F.pad(W, (0, 4 - W.shape[1] % 4))
+        ent = cache["weights"] = (sig, W.contiguous(), a)
+    return ent[1], ent[2]
+
+
 def _gat_layer_forward(heads, X, edge_index, concat, alpha, training, dropout_rate, graph_ptr, cache):
     if training and dropout_rate > 0:
         raise RuntimeError("train-mode GAT applies torch-RNG dropout to attention coefficients "
@@ -91,22 +104,18 @@ def _gat_layer_forward(heads, X, edge_index, concat, alpha, training, dropout_ra
     Fh = heads[0].out_features
     if Fh % 4:
         raise ValueError("per-head output width must be a multiple of 4 (16-byte lanes)")
-    W = torch.cat([h.W.weight for h in heads], 0).detach()          # (H*Fh, Fin)
-    a = torch.cat([h.a.weight for h in heads], 0).detach()          # (H, 2*Fh)
-    if W.shape[1] != Fin:
-        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({N}x{Fin} and {W.shape[1]}x{Fh})")
+    W, a = stacked_head_weights(heads, cache)
+    if heads[0].W.weight.shape[1] != Fin:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({N}x{Fin} and {heads[0].W.weight.shape[1]}x{Fh})")
     Xc = X.detach().contiguous()
-    if Fin % 4:  # zero-pad K to a multiple of 4: exact
-        pad = 4 - Fin % 4
-        Xc, W = F.pad(Xc, (0, pad)), F.pad(W, (0, pad))
-    W, a = W.contiguous(), a.contiguous()
+    if Fin % 4:  # zero-pad K to a multiple of 4: exact (W is padded the same way in stacked_head_weights)
+        Xc = F.pad(Xc, (0, 4 - Fin % 4))
     key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, N, str(edge_index.device))
-    ent = cache.get(key)
-    if ent is None:
+    ent = cache.get("csr")
+    if ent is None or ent[0] != key:
         rowptr, col = coo_to_csr_device(edge_index.to(dev), N)
-        cache.clear()
-        ent = cache[key] = (rowptr, col, edge_index)  # keep the key tensor alive so data_ptr stays unique
-    rowptr, col = ent[0], ent[1]
+        ent = cache["csr"] = (key, rowptr, col, edge_index)  # keep the key tensor alive so data_ptr stays unique
+    rowptr, col = ent[1], ent[2]
     G, gp_ptr = 1, None
     if graph_ptr is not None:
         gp = graph_ptr.to(device=dev, dtype=torch.int32).contiguous()
