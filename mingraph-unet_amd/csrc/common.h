@@ -38,6 +38,7 @@ struct IgemmDesc {
 };
 
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
+void set_use_halo(bool on);
 
 // elementwise.hip
 hipError_t launch_pack_input(const float* x, float* out, int B, int C, int Cp, int H, int W, int64_t sn, int64_t sc,

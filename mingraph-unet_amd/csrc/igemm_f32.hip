@@ -25,6 +25,9 @@ namespace mgu {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+static bool g_use_halo = true;   // MGU_NO_HALO=1 forces the generic gather kernel (A/B comparisons)
+void set_use_halo(bool on) { g_use_halo = on; }
+
 constexpr int CK = 32;           // K elements per pipeline step
 constexpr int LDS_LD = CK + 4;   // LDS row pitch in floats (144 B, keeps 16-B alignment)
 
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
     if (ks + 1 < nk) load_tiles((ks + 1) * CK);
 #pragma unroll
     for (int kk = 0; kk < CK / 8; ++kk) {
+      if (ks * CK + kk * 8 >= d.K) break;  // zero K tail (block-uniform): nothing to accumulate
       f32x4 a[WMT], b[WNT];
 #pragma unroll
       for (int mi = 0; mi < WMT; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(Ap + mi * 32 * LDS_LD + kk * 8);
@@ -185,6 +189,187 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
   }
 }
 
+
+// =================================================================================================
+// conv3x3 with an LDS-resident input halo (Cin % 32 == 0).
+//
+// The generic kernel above re-gathers the A tile from L2/HBM once per tap: 9x the input bytes, and at
+// full resolution those re-reads miss the 4 MiB XCD L2 (rocprofv3 r01: dec3.conv1 fetched 4.0 GB for a
+// 0.54 GB input, L2 hit 28 %).  Here a workgroup owns a TH x 16 pixel patch of one image: per 32-channel
+// chunk it stages the (TH+2) x 18 halo ONCE into LDS and all 9 taps read their shifted A operands from
+// it (a tap is just a constant LDS address offset).  Only the small per-tap weight tile streams through a
+// double-buffered LDS panel, so there is a single s_barrier per tap.  The halo of the next chunk is
+// prefetched into registers while the current chunk computes.
+// =================================================================================================
+template <int TH, int WAVES_M, int WAVES_N, int WMT, int WNT>
+__global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y) {
+  constexpr int TW = 16, HWID = TW + 2, HP = (TH + 2) * HWID;
+  constexpr int BM = TH * TW;
+  constexpr int BN = WAVES_N * WNT * 32;
+  static_assert(BM == WAVES_M * WMT * 32 && WAVES_M * WAVES_N == 4, "tile/wave mismatch");
+  constexpr int HR = (HP + 31) / 32;  // halo pixels staged per thread
+  constexpr int BR = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Hs = smem;                  // [HP][36]
+  float* Bs = smem + HP * LDS_LD;    // [2][BN][36]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N;
+  const int wn = wave % WAVES_N;
+  const int kq = tid & 7;
+  const int r0 = tid >> 3;
+  const int bid = blockIdx.x;
+  const int tx = bid % tiles_x;
+  const int ty = (bid / tiles_x) % tiles_y;
+  const int img = bid / (tiles_x * tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int bn0 = blockIdx.y * BN;
+  const float* img_base = d.in + (size_t)img * d.H * d.W * d.ldin;
+
+  // halo staging map: thread -> (halo pixel r0 + 32 i, float4 kq); offset < 0: outside the image (zero)
+  int hoff[HR];
+#pragma unroll
+  for (int i = 0; i < HR; ++i) {
+    const int hp = r0 + 32 * i;
+    const int hy = hp / HWID, hx = hp - hy * HWID;
+    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+    hoff[i] = (hp < HP && y >= 0 && y < d.H && x >= 0 && x < d.W) ? (y * d.W + x) * d.ldin + kq * 4 : -1;
+  }
+  const float* wrow[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) wrow[i] = d.w + (size_t)(bn0 + r0 + 32 * i) * d.Kp + kq * 4;
+
+  f32x4 hreg[HR];
+  f32x4 breg[BR];
+  auto load_halo = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < HR; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (hoff[i] >= 0) v = *reinterpret_cast<const f32x4*>(img_base + hoff[i] + c * CK);
+      hreg[i] = v;
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int i = 0; i < HR; ++i)
+      if (r0 + 32 * i < HP) *reinterpret_cast<f32x4*>(Hs + (r0 + 32 * i) * LDS_LD + kq * 4) = hreg[i];
+  };
+  auto load_b = [&](int c, int tap) {
+    const int k0 = tap * d.Cp + c * CK;
+#pragma unroll
+    for (int i = 0; i < BR; ++i) breg[i] = *reinterpret_cast<const f32x4*>(wrow[i] + k0);
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < BR; ++i)
+      *reinterpret_cast<f32x4*>(Bs + buf * BN * LDS_LD + (r0 + 32 * i) * LDS_LD + kq * 4) = breg[i];
+  };
+
+  f32x16 acc[WMT][WNT];
+#pragma unroll
+  for (int mi = 0; mi < WMT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < WNT; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int lr = lane & 31;
+  const int lh = lane >> 5;
+  int aoff[WMT];  // float offset of this lane's A row (tap 0,0) inside Hs
+#pragma unroll
+  for (int mi = 0; mi < WMT; ++mi) {
+    const int p = (wm * WMT + mi) * 32 + lr;
+    aoff[mi] = ((p >> 4) * HWID + (p & 15)) * LDS_LD + lh * 4;
+  }
+  const int boff = (wn * WNT * 32 + lr) * LDS_LD + lh * 4;
+
+  const int nchunks = d.Cp / CK;
+  const int nsteps = nchunks * 9;
+  load_halo(0);
+  load_b(0, 0);
+  store_halo();
+  store_b(0);
+  if (nsteps > 1) load_b(0, 1);
+  int c = 0, tap = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    __syncthreads();  // Bs[st&1] (and a fresh halo when tap == 0) visible; Bs[(st+1)&1] no longer read
+    if (st + 1 < nsteps) store_b((st + 1) & 1);
+    if (st + 2 < nsteps) {
+      int t2 = tap + 2, c2 = c;
+      if (t2 >= 9) { t2 -= 9; ++c2; }
+      load_b(c2, t2);
+    }
+    if (tap == 0 && c + 1 < nchunks) load_halo(c + 1);
+    const int r = tap / 3, s = tap - 3 * r;
+    const float* Ap = Hs + (r * HWID + s) * LDS_LD;
+    const float* Bp = Bs + (st & 1) * BN * LDS_LD + boff;
+#pragma unroll
+    for (int kk = 0; kk < CK / 8; ++kk) {
+      f32x4 a[WMT], b[WNT];
+#pragma unroll
+      for (int mi = 0; mi < WMT; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(Ap + aoff[mi] + kk * 8);
+#pragma unroll
+      for (int ni = 0; ni < WNT; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(Bp + ni * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mi = 0; mi < WMT; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < WNT; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], b[ni][t], acc[mi][ni], 0, 0, 0);
+    }
+    if (++tap == 9) {
+      tap = 0;
+      ++c;
+      if (c < nchunks) {
+        __syncthreads();  // every wave is done with the old halo
+        store_halo();
+      }
+    }
+  }
+
+#pragma unroll
+  for (int ni = 0; ni < WNT; ++ni) {
+    const int n = bn0 + (wn * WNT + ni) * 32 + lr;
+    const bool nvalid = n < d.N;
+    const float sc = (nvalid && d.scale) ? d.scale[n] : 1.f;
+    const float sh = (nvalid && d.shift) ? d.shift[n] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < WMT; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int p = (wm * WMT + mi) * 32 + row;
+        const int y = y0 + (p >> 4), x = x0 + (p & 15);
+        if (nvalid && y < d.H && x < d.W) {
+          float v = acc[mi][ni][r] * sc + sh;
+          if (d.relu) v = fmaxf(v, 0.f);
+          d.out[(((size_t)img * d.H + y) * d.W + x) * d.ldout + d.coff + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int TH, int WAVES_M, int WAVES_N, int WMT, int WNT>
+static hipError_t launch_halo(const IgemmDesc& d, hipStream_t s) {
+  constexpr int BN = WAVES_N * WNT * 32;
+  constexpr int HP = (TH + 2) * 18;
+  const int tiles_x = (d.W + 15) / 16, tiles_y = (d.H + TH - 1) / TH;
+  const int B = d.M / (d.H * d.W);
+  dim3 grid(tiles_x * tiles_y * B, (d.N + BN - 1) / BN);
+  const size_t lds = (size_t)(HP + 2 * BN) * LDS_LD * sizeof(float);
+  hipLaunchKernelGGL((conv3x3_halo_f32_kernel<TH, WAVES_M, WAVES_N, WMT, WNT>), grid, dim3(256), lds, s, d, tiles_x, tiles_y);
+  return hipGetLastError();
+}
+
+static bool halo_applicable(const IgemmDesc& d) {
+  return d.KS == 3 && d.out_mode == 0 && (d.Cp % CK) == 0 && d.K == 9 * d.Cp && d.ldin == d.Cp &&
+         (long)d.H * d.W * d.ldin < (1l << 31) && g_use_halo;
+}
+
 template <int KS, int OUTMODE, int WAVES_M, int WAVES_N, int WMT, int WNT>
 static hipError_t launch_cfg(const IgemmDesc& d, hipStream_t s) {
   constexpr int BM = WAVES_M * WMT * 32;
@@ -208,6 +393,11 @@ hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s) {
   if (d.out_mode == 1) {
     if (d.KS != 1) return hipErrorInvalidValue;
     return launch_tiles<1, 1>(d, s);
+  }
+  if (halo_applicable(d)) {
+    if (d.N > 64) return launch_halo<8, 2, 2, 2, 2>(d, s);    // 8x16 px  x 128 ch, wave 64x64
+    if (d.N > 32) return launch_halo<16, 4, 1, 2, 2>(d, s);   // 16x16 px x 64 ch,  wave 64x64
+    return launch_halo<16, 4, 1, 2, 1>(d, s);                 // 16x16 px x 32 ch,  wave 64x32
   }
   if (d.KS == 3) return launch_tiles<3, 0>(d, s);
   if (d.KS == 1) return launch_tiles<1, 0>(d, s);

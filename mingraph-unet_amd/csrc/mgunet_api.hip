@@ -3,6 +3,7 @@
 // elementwise.hip or gat.hip.  No CPU fallback exists: without a HIP device every call fails.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -161,6 +162,8 @@ int mgu_create(int device_id, mgu_ctx** out) {
   if (e != hipSuccess) return fail(nullptr, MGU_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
   mgu_ctx* c = new mgu_ctx();
   c->device = device_id;
+  const char* nh = getenv("MGU_NO_HALO");
+  set_use_halo(!(nh && nh[0] == '1'));
   *out = c;
   return MGU_OK;
 }

@@ -45,6 +45,10 @@ def conv_gpu(cuda, x, w, b, k, relu, ld_out=None, c_off=0, scale=None, shift=Non
     (3, 7, 5, 16, 2, 1),       # 1x1 head: N = 2
     (1, 33, 9, 36, 40, 1),     # 1x1, K = 36
     (1, 40, 40, 12, 20, 3),    # Cp = 12: taps straddle K steps
+    (2, 13, 17, 32, 24, 3),    # halo kernel, N <= 32 tile, ragged 16x16 patches
+    (1, 40, 33, 64, 32, 3),    # halo kernel, two channel chunks (halo prefetch), N == 32
+    (2, 35, 18, 96, 48, 3),    # halo kernel, three chunks, N <= 64 tile
+    (1, 17, 50, 256, 136, 3),  # halo kernel, 8x16 patches, eight chunks, N tail
 ])
 def test_conv2d_vs_torch(cuda, B, H, W, Cin, Cout, k):
     x = torch.from_numpy(O.formula_normal("kc/x", (B, Cin, H, W), seed=Cin))
@@ -68,6 +72,9 @@ def test_conv2d_exact_integer_data_asymmetric(cuda):
     ref = F.conv2d(x, w, b, padding=1)
     got = conv_gpu(cuda, x, w, b, 3, 0).permute(0, 3, 1, 2)
     assert torch.equal(got, ref)
+    x = torch.from_numpy(rng.integers(-3, 4, size=(2, 64, 19, 21)).astype(np.float32))   # halo kernel path
+    w = torch.from_numpy(rng.integers(-2, 3, size=(40, 64, 3, 3)).astype(np.float32))
+    assert torch.equal(conv_gpu(cuda, x, w, b, 3, 0).permute(0, 3, 1, 2), F.conv2d(x, w, b, padding=1))
     d = torch.zeros(1, 4, 9, 9)
     d[0, 1, 4, 4] = 1.0
     w2 = torch.arange(4 * 4 * 9, dtype=torch.float32).reshape(4, 4, 3, 3)

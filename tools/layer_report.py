@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Per-layer conv timings of the last bench step from a rocprofv3 kernel trace (B=8, 512x512)."""
+import csv, glob, sys
+root = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+rows = list(csv.DictReader(open(sorted(glob.glob(root + "/runc/*kernel_trace.csv"))[-1])))
+ig = [r for r in rows if "igemm" in r["Kernel_Name"] or "halo" in r["Kernel_Name"]]
+last = ig[-24:]
+def convf(h, cin, cout): return 2 * B * h * h * 9 * cin * cout
+layers = []
+h, cin, f = S, 3, 32
+for i in range(4):
+    layers += [("enc%d.c1" % i, convf(h, cin, f)), ("enc%d.c2" % i, convf(h, f, f))]; cin = f; f *= 2; h //= 2
+layers += [("bott.c1", convf(h, cin, f)), ("bott.c2", convf(h, f, f))]
+prev = f
+for b in range(4):
+    c = 32 << (3 - b)
+    layers.append(("dec%d.up" % b, 2 * B * h * h * prev * (prev // 2) * 4)); h *= 2
+    layers += [("dec%d.c1" % b, convf(h, 2 * c, c)), ("dec%d.c2" % b, convf(h, c, c))]; prev = c
+layers.append(("final", 2 * B * S * S * 32 * 2))
+layers.append(("gat.lin", 2 * B * (S // 16) ** 2 * 32 * 256))
+tot = 0
+for (name, fl), r in zip(layers, last):
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot += d
+    kn = ("halo<" if "halo" in r["Kernel_Name"] else "igemm<") + r["Kernel_Name"].split("<")[1].split(">")[0].replace(" ", "") + ">"
+    print(f"{name:9s} {kn:22s} grid={r['Grid_Size_X']:>9s}x{r['Grid_Size_Y']:>4s} {d:8.1f} us {fl/d/1e6:7.1f} TF/s vgpr={r['VGPR_Count']}+{r['Accum_VGPR_Count']} lds={r['LDS_Block_Size']}")
+print("total us", round(tot, 1))
+oth = [r for r in rows if r not in ig]

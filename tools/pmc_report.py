@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc CSVs (gpurun_out/pmc_*/) per kernel family / per conv layer of the last step.
+FETCH_SIZE is doubled (gfx950 counts 128-B requests at 64 B: MI355X_MICROARCH.md, HBM section)."""
+import csv, glob, sys, collections
+
+def load(pat):
+    f = sorted(glob.glob(pat))
+    if not f: return []
+    return list(csv.DictReader(open(f[-1])))
+
+def short(n):
+    if "igemm" in n: return "igemm<" + n.split("<")[1].split(">")[0].replace(" ", "") + ">"
+    if "conv3x3_halo" in n: return "halo<" + n.split("<")[1].split(">")[0].replace(" ", "") + ">"
+    return n.split("(")[0].replace("mgu::", "").replace("void ", "")[:40]
+
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
+per = collections.OrderedDict()
+for tag in ("fetch", "write", "sq"):
+    for r in load(f"{root}/pmc_{tag}/runc/*counter_collection.csv"):
+        key = (int(r["Dispatch_Id"]), short(r["Kernel_Name"]))
+        d = per.setdefault((tag, key), {})
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        d["dur_us"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        d["grid"] = r["Grid_Size"]
+# aggregate by kernel name per tag
+agg = collections.OrderedDict()
+for (tag, (did, name)), d in per.items():
+    a = agg.setdefault(name, collections.defaultdict(float))
+    for k, v in d.items():
+        if k not in ("grid",): a[tag + ":" + k] += v
+    a[tag + ":n"] += 1
+print(f"{'kernel':44s} {'n':>4s} {'us/launch':>9s} {'rd MB':>9s} {'wr MB':>9s} {'L2hit%':>6s} {'mfma_busy%':>10s} {'wait_any%':>9s} {'wait_inst%':>10s} {'active%':>8s} {'ldsconf%':>8s}")
+for name, a in agg.items():
+    n = max(a["fetch:n"], 1)
+    rd = a["fetch:FETCH_SIZE"] * 2 * 1024 / 1e6 / n if a["fetch:n"] else float('nan')  # FETCH_SIZE in KiB -> x2 correction
+    wn = max(a["write:n"], 1)
+    wr = a["write:WRITE_SIZE"] * 1024 / 1e6 / wn
+    hit = a["write:TCC_HIT_sum"] / max(a["write:TCC_HIT_sum"] + a["write:TCC_MISS_sum"], 1) * 100
+    wc = max(a["sq:SQ_WAVE_CYCLES"], 1)
+    busy = a["sq:SQ_BUSY_CYCLES"]
+    print(f"{name:44s} {int(n):4d} {a['fetch:dur_us']/n:9.1f} {rd:9.1f} {wr:9.1f} {hit:6.1f} "
+          f"{a['sq:SQ_VALU_MFMA_BUSY_CYCLES']/max(busy,1)*100/4:10.1f} {a['sq:SQ_WAIT_ANY']/wc*100:9.1f} {a['sq:SQ_WAIT_INST_ANY']/wc*100:10.1f} "
+          f"{a['sq:SQ_ACTIVE_INST_ANY']/wc*100:8.1f} {a['sq:SQ_LDS_BANK_CONFLICT']/max(wc,1)*100:8.2f}")
+# per-dispatch detail for igemm of the last step
+print()
+for tag in ("fetch", "write"):
+    rows = [(k, d) for (t, k), d in per.items() if t == tag and ("igemm" in k[1] or "halo" in k[1])]
+    rows = rows[-24:]
+    print(tag, "last step, per igemm launch:")
+    for (did, name), d in rows:
+        if tag == "fetch":
+            print(f"  {name:28s} grid={d['grid']:>10s} {d['dur_us']:8.1f} us  read {d.get('FETCH_SIZE',0)*2*1024/1e6:8.1f} MB")
+        else:
+            h, m = d.get("TCC_HIT_sum", 0), d.get("TCC_MISS_sum", 0)
+            print(f"  {name:28s} grid={d['grid']:>10s} {d['dur_us']:8.1f} us  write {d.get('WRITE_SIZE',0)*1024/1e6:8.1f} MB  L2 hit {h/max(h+m,1)*100:5.1f}%")
