@@ -69,6 +69,57 @@ def cpu_baseline(batch, H, W, iters):
                       f"({dt:.2f} s/iter), torch {torch.__version__} CPU"}
 
 
+def bench_train(a, world, rank, local_rank, dev, dist):
+    """BASELINE configs[4]: training step, batch 32 over 8 GPUs = 4 images/GPU (weak scaling), fwd+bwd+Adam,
+    mean all-reduce of the flat fp32 gradient over RCCL (DDP semantics).  Mpix/s = images*H*W per step time."""
+    import mgunet
+    import mgunet_oracle as O
+    B = a.batch if a.batch != 8 else 4
+    H = W = a.size
+    model = mgunet.UNet(3, 2, 32, 4)
+    model.load_state_dict(O.make_unet_params(3, 2, 32, 4, seed=0))
+    model = model.to(dev)
+    tr = mgunet.Trainer(model, lr=1e-3, weight_decay=1e-4)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4321 + rank)
+    x = torch.randn((B, 3, H, W), device=dev, generator=gen)
+    y = torch.randint(0, 2, (B, H, W), device=dev, generator=gen)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        loss = tr.train_step(x, y)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.train_step(x, y)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(loss).all())
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        flops = 3.0 * model.flops(B, H, W)  # bwd = dgrad + wgrad ~ 2x fwd (SURVEY 8d)
+        line = {"metric": "segmented Mpix/sec, MinGraph-UNet train step (fwd + CE + bwd + grad all-reduce + Adam), 512x512",
+                "value": round(world * B * H * W * a.steps / dt / 1e6, 3), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic (N(0,1) images, random labels, formula weights)",
+                "config": {"workload": f"BASELINE configs[4]: train step, {B} images/GPU x 3x{H}x{W} fp32, UNet(3,2,32,4), "
+                                       f"CrossEntropy + Adam(1e-3, wd 1e-4), per-shard BatchNorm (DDP semantics)",
+                           "images_per_gpu": B, "global_batch": B * world,
+                           "parallelism": f"dp{world}: one flat {tr.flat.numel() * 4 / 1e6:.1f} MB fp32 gradient all-reduce (RCCL) per step"},
+                "final_loss": round(float(loss), 6),
+                "approx_tflops": round(flops * a.steps / dt / 1e12, 2), "roofline": None, "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +127,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE config 2: 8)")
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer: BASELINE configs[1]/[2] full forward (the headline); train: configs[4] train step "
+                         "(fwd + CE + bwd + RCCL grad all-reduce + Adam), 4 images per GPU unless --batch is given")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
     ap.add_argument("--no-profile-pass", action="store_true")
     a = ap.parse_args()
@@ -100,6 +154,8 @@ def main():
     import mgunet_oracle as O
     from mgunet import _lib
 
+    if a.mode == "train":
+        return bench_train(a, world, rank, local_rank, dev, dist)
     B, H, W = a.batch, a.size, a.size
     unet = mgunet.UNet(3, 2, 32, 4)
     unet.load_state_dict(O.make_unet_params(3, 2, 32, 4, seed=0))     # random-init-scale formula weights

@@ -64,7 +64,8 @@ int mgu_unet_load_weights(mgu_ctx* ctx, const mgu_tensor_desc* named, int n, voi
 int mgu_unet_workspace_bytes(mgu_ctx* ctx, int B, int H, int W, int training, size_t* out);
 /* Pre-allocate that scratch (synchronous); forward does it lazily otherwise. */
 int mgu_unet_reserve(mgu_ctx* ctx, int B, int H, int W, int training);
-/* = logits, skips, dec_feats = UNet.forward(x)  (unet_model.py:34-36), eval mode.
+/* = logits, skips, dec_feats = UNet.forward(x)  (unet_model.py:34-36); training=0: eval mode (BatchNorm folded),
+ * training=1: train mode (see "training step" below).
  *   x_dev      : input, element (n,c,y,x) at x_dev[n*xs_n + c*xs_c + y*xs_h + x*xs_w] (fp32; any layout)
  *   logits_dev : (B,H,W,num_classes) NHWC
  *   cat_dev[i] : i = 0..depth-1 shallow->deep, NHWC buffer (B,H_i,W_i,2*C_i), C_i = init_features<<i,
@@ -95,6 +96,31 @@ int mgu_maxpool2x2_nhwc(mgu_ctx* ctx, const void* in_dev, int ld_in, int B, int 
 /* argmax over classes of NHWC logits -> int64 (B,H,W): experiments/segmentation_performance.py:141 */
 int mgu_argmax_classes(mgu_ctx* ctx, const void* logits_dev, int64_t npix, int num_classes,
                        int64_t* pred_dev, void* hip_stream);
+
+/* ---- training step: replaces the autograd graph of scripts/train_segmentation.py:121-134 ---------- */
+/* mgu_unet_forward(training=1) is the train-mode forward: BatchNorm uses batch statistics (biased
+ * variance), updates running_mean/var IN PLACE in the tensors given to mgu_unet_load_weights (momentum
+ * 0.1, unbiased variance; unet_encoder.py:12-13) and keeps the activations backward needs in library
+ * scratch.  The forward's caller-owned outputs must stay alive until mgu_unet_backward returns.
+ *
+ * Offset (elements) of a parameter in the flat parameter/gradient vector; the order is the reference's
+ * named_parameters() order.  name = state_dict key of a weight/bias; -1 if unknown. */
+int64_t mgu_unet_param_offset(mgu_ctx* ctx, const char* name);
+/* nn.CrossEntropyLoss() (mean reduction) forward + gradient (train_segmentation.py:91,127):
+ * logits_dev (npix, C) NHWC fp32, labels_dev int64 (npix).  Writes *loss_dev = mean_i -log softmax(l_i)[y_i]
+ * and dlogits_dev (npix, 4*ceil(C/4)) = grad_scale * (softmax - onehot), pad columns zero.
+ * grad_scale = 1/npix reproduces loss.backward() of the mean loss. */
+int mgu_cross_entropy(mgu_ctx* ctx, const void* logits_dev, const int64_t* labels_dev, int64_t npix, int num_classes,
+                      float grad_scale, void* dlogits_dev, float* loss_dev, void* hip_stream);
+/* loss.backward() (train_segmentation.py:133) for the last mgu_unet_forward(training=1): dlogits_dev as
+ * produced by mgu_cross_entropy; every element of flat_grad_dev (mgu_unet_param_count floats) is written. */
+int mgu_unet_backward(mgu_ctx* ctx, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream);
+/* torch.optim.Adam.step() with L2 weight decay folded into the gradient (train_segmentation.py:96):
+ * g = grad_scale*grad + wd*p; m,v moments; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  step t >= 1.
+ * grad_scale lets the caller fold the 1/world_size of an all-reduce SUM into the update. */
+int mgu_adam_step(mgu_ctx* ctx, void* flat_param_dev, const void* flat_grad_dev, void* exp_avg_dev, void* exp_avg_sq_dev,
+                  int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                  float grad_scale, void* hip_stream);
 
 /* ---- patch graph: replaces preprocessing/graph_construction/patch_graph_construction.py:49-102 -- */
 /* HOST routine (index maps are tiny and static per image size).  Emits the COO edge_index in the

@@ -40,6 +40,48 @@ struct IgemmDesc {
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
 void set_use_halo(bool on);
 
+// wgrad_f32.hip:  Dw[n][k] += sum_m Z[m][n] * A(m,k)   (A = the forward kernels' im2col gather)
+struct WgradDesc {
+  const float* z;   // Z[m][n] at z[m*ldz + zoff + n]
+  int ldz, zoff;
+  const float* in;  // gather source (NHWC), channels [inoff, inoff+Cp) of a pixel with pitch ldin
+  int ldin, inoff, Cp;
+  int KS;           // 1 | 3 (pad 1) | 2 (stride-2 2x2 gather from an Hs x Ws grid: ConvTranspose2d)
+  int M, H, W;      // rows enumerate (img, y, x) over H x W
+  int Hs, Ws;       // KS == 2 source grid
+  int N, K, Kp;     // Dw panel [>=N][Kp]
+  float* dw;        // accumulated with float atomics: zero it first
+  int rows_per_split;  // set by the launcher
+};
+hipError_t launch_wgrad_f32(const WgradDesc& d, hipStream_t s);
+
+// train_kernels.hip
+hipError_t launch_bn_stats(const float* z, int ldz, int64_t M, int C, double* sum, double* sumsq, hipStream_t s);
+hipError_t launch_bn_finalize(const double* sum, const double* sumsq, int64_t M, float eps, float momentum,
+                              const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
+                              float* shift, float* run_mean, float* run_var, int C, hipStream_t s);
+hipError_t launch_bn_apply_relu(const float* z, const float* scale, const float* shift, float* y, int ldy, int64_t M, int C,
+                                hipStream_t s);
+hipError_t launch_bn_bwd_reduce(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz,
+                                const float* mean, const float* invstd, int64_t M, int C, double* sum_g, double* sum_gx,
+                                hipStream_t s);
+hipError_t launch_bn_bwd_apply(const float* dy, int lddy, const float* y, int ldy, const float* z, const float* mean,
+                               const float* invstd, const float* gamma, const double* sum_g, const double* sum_gx,
+                               int64_t M, int C, float* dz, float* dgamma, float* dbeta, hipStream_t s);
+hipError_t launch_colsum(const float* z, int ldz, int64_t M, int C, double* sum, hipStream_t s);
+hipError_t launch_d2f(const double* in, float* out, int n, hipStream_t s);
+hipError_t launch_maxpool2_bwd_add(const float* y, int ldy, const float* dpool, float* dskip, int ldd, int B, int H, int W,
+                                   int C, hipStream_t s);
+hipError_t launch_zero_pad_region(float* buf, int ld, int coff, int C, int B, int H, int W, int h2, int w2, hipStream_t s);
+hipError_t launch_ce(const float* logits, const int64_t* labels, int64_t M, int C, float grad_scale, float* dlogits, int ldd,
+                     double* loss_sum, float* loss_out, hipStream_t s);
+hipError_t launch_pack_dgrad_w(const float* w, float* wp, int Cout, int Cin, int Cop, int KS, int Kp, hipStream_t s);
+hipError_t launch_pack_convt_dgrad_w(const float* w, float* wp, int Cin, int Cout, int Kp, hipStream_t s);
+hipError_t launch_unpack_conv_grad(const float* dwp, float* g, int Cout, int Cin, int Cp, int KS, int Kp, hipStream_t s);
+hipError_t launch_unpack_convt_grad(const float* dwp, float* g, int Cin, int Cout, int Kp, hipStream_t s);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                       float wd, int step, float grad_scale, hipStream_t s);
+
 // elementwise.hip
 hipError_t launch_pack_input(const float* x, float* out, int B, int C, int Cp, int H, int W, int64_t sn, int64_t sc,
                              int64_t sh, int64_t sw, hipStream_t s);

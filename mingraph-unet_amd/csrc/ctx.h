@@ -1,0 +1,140 @@
+// Internal: context and helpers shared by mgunet_api.hip and mgunet_train.hip (not part of the ABI).
+#pragma once
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mgunet.h"
+#include "common.h"
+
+struct Layer {
+  std::string prefix;   // state_dict prefix, e.g. "encoder.encoder_blocks.0."
+  std::string conv;     // "conv1" | "conv2" | "upsample" | "final_conv"
+  std::string bn;       // "bn1" | "bn2" | ""
+  int Cin = 0, Cp = 0, Cout = 0, KS = 3;
+  bool convt = false;
+  int K = 0, Kp = 0, N = 0, Np = 0;
+  float *wp = nullptr, *scale = nullptr, *shift = nullptr;
+  // caller-owned parameter tensors recorded by load_weights (used by the training path)
+  const float *w_src = nullptr, *b_src = nullptr, *gamma = nullptr, *beta = nullptr;
+  float *run_mean = nullptr, *run_var = nullptr;
+  // offsets (elements) into the flat parameter / gradient vector, named_parameters() order
+  int64_t off_w = 0, off_b = 0, off_gamma = 0, off_beta = 0;
+  // batch statistics of the last training forward (library scratch)
+  float *mean = nullptr, *invstd = nullptr, *tscale = nullptr, *tshift = nullptr;
+  // tensors of the last training forward
+  const float* t_in = nullptr;  // conv input
+  int t_ldin = 0;
+  float* t_z = nullptr;         // raw conv output (dense, pitch Cout)
+  float* t_y = nullptr;         // relu(bn(z)) with pitch t_ldy
+  int t_ldy = 0;
+  int t_B = 0, t_H = 0, t_W = 0;  // grid the conv ran on (input grid for convT)
+};
+
+struct mgu_ctx {
+  int device = 0;
+  std::string err;
+  bool configured = false, loaded = false;
+  int in_ch = 0, ncls = 0, feat = 0, depth = 0, dtype = 0, Cp0 = 0;
+  std::vector<Layer> layers;  // enc[i].conv1, enc[i].conv2 ..., bott.conv1, bott.conv2, dec[b].up, dec[b].conv1, dec[b].conv2 ..., final
+  int64_t nparams = 0;
+  float* arena = nullptr;
+  size_t arena_floats = 0;
+  void* ws = nullptr;   // eval scratch
+  size_t ws_bytes = 0;
+  void* gws = nullptr;  // GAT / building-block scratch
+  size_t gws_bytes = 0;
+  void* tws = nullptr;  // training scratch (saved activations + backward temporaries)
+  size_t tws_bytes = 0;
+  // last training forward
+  bool have_train_fwd = false;
+  int tB = 0, tH = 0, tW = 0;
+  std::vector<float*> t_cat, t_feat, t_pooled;
+  float* t_logits = nullptr;
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  int ev_used = 0;
+  hipEvent_t ev_total[2] = {nullptr, nullptr};
+};
+
+namespace mgud {
+
+inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+extern std::string g_create_err;
+
+inline int fail(mgu_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_err = buf;
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                                       \
+  do {                                                                                                        \
+    hipError_t e_ = (call);                                                                                   \
+    if (e_ != hipSuccess) return mgud::fail(c, MGU_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));   \
+  } while (0)
+
+inline int ensure(mgu_ctx* c, void** p, size_t* have, size_t need) {
+  if (*have >= need) return MGU_OK;
+  if (*p) {
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+  }
+  hipError_t e = hipMalloc(p, need);
+  if (e != hipSuccess) return fail(c, MGU_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+  *have = need;
+  return MGU_OK;
+}
+
+struct ProfScope {  // records an event pair around one conv/GEMM launch when profiling is on
+  mgu_ctx* c;
+  hipStream_t s;
+  int idx = -1;
+  ProfScope(mgu_ctx* c_, hipStream_t s_) : c(c_), s(s_) {
+    if (!c->prof) return;
+    if ((size_t)(2 * c->ev_used + 2) > c->ev.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      c->ev.push_back(a);
+      c->ev.push_back(b);
+    }
+    idx = c->ev_used++;
+    (void)hipEventRecord(c->ev[2 * idx], s);
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(c->ev[2 * idx + 1], s);
+  }
+};
+
+inline void level_dims(int H, int W, int depth, std::vector<int>& hs, std::vector<int>& wsz) {
+  hs.assign(depth + 1, 0);
+  wsz.assign(depth + 1, 0);
+  hs[0] = H;
+  wsz[0] = W;
+  for (int i = 1; i <= depth; ++i) {
+    hs[i] = hs[i - 1] / 2;  // MaxPool2d(2,2) floor mode, unet_encoder.py:48
+    wsz[i] = wsz[i - 1] / 2;
+  }
+}
+
+// one fused conv / convT / 1x1 launch described by a Layer (scale/shift chosen by the caller)
+int run_layer(mgu_ctx* c, const Layer& L, const float* in, int ldin, int B, int H, int W, float* out, int ldout, int coff,
+              int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s);
+
+// training path (mgunet_train.hip)
+int unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int64_t xs_w, int B, int H,
+                       int W, float* logits, void* const* cat_dev, void* const* feat_dev, hipStream_t s);
+
+}  // namespace mgud

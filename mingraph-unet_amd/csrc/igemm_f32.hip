@@ -63,7 +63,16 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
     amask[i] = 0u;
     if (m < d.M) {
       abase[i] = d.in + (size_t)m * d.ldin;
-      if (KS == 3) {
+      if (KS == 2) {
+        // stride-2 2x2 gather (ConvTranspose2d dgrad): row m = (img, y, x) over H x W reads the four
+        // pixels (2y+dy, 2x+dx) of the Hout x Wout source grid; every tap is in range (Hout >= 2H).
+        const int img = m / HW;
+        const int rem = m - img * HW;
+        const int oy = rem / d.W;
+        const int ox = rem - oy * d.W;
+        abase[i] = d.in + (((size_t)img * d.Hout + 2 * oy) * d.Wout + 2 * ox) * d.ldin;
+        amask[i] = 0xFu;
+      } else if (KS == 3) {
         const int rem = m % HW;
         const int oy = rem / d.W;
         const int ox = rem - oy * d.W;
@@ -95,6 +104,10 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
       const int r = tap / 3;
       const int s = tap - 3 * r;
       delta = (long)((r - 1) * d.W + (s - 1)) * d.ldin + c;
+    } else if (KS == 2) {
+      tap = k / d.Cp;
+      const int c = k - tap * d.Cp;
+      delta = (long)((tap >> 1) * d.Wout + (tap & 1)) * d.ldin + c;
     }
     const bool kvalid = k < d.K;
 #pragma unroll
@@ -401,6 +414,7 @@ hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s) {
   }
   if (d.KS == 3) return launch_tiles<3, 0>(d, s);
   if (d.KS == 1) return launch_tiles<1, 0>(d, s);
+  if (d.KS == 2) return launch_tiles<2, 0>(d, s);
   return hipErrorInvalidValue;
 }
 

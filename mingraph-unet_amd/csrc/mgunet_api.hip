@@ -1,120 +1,16 @@
 // C-ABI of libmgunet.so (see include/mgunet.h): context, weight repacking, U-Net forward schedule,
 // GAT layer schedule.  Host orchestration only -- every arithmetic op is a kernel in igemm_f32.hip,
 // elementwise.hip or gat.hip.  No CPU fallback exists: without a HIP device every call fails.
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/mgunet.h"
-#include "common.h"
+#include "ctx.h"
 
 using namespace mgu;
+using namespace mgud;
 
-namespace {
-
-struct Layer {
-  std::string prefix;   // state_dict prefix, e.g. "encoder.encoder_blocks.0."
-  std::string conv;     // "conv1" | "conv2" | "upsample" | "final_conv"
-  std::string bn;       // "bn1" | "bn2" | ""
-  int Cin = 0, Cp = 0, Cout = 0, KS = 3;
-  bool convt = false;
-  int K = 0, Kp = 0, N = 0, Np = 0;
-  float *wp = nullptr, *scale = nullptr, *shift = nullptr;
-};
-
-inline int rup(int v, int m) { return (v + m - 1) / m * m; }
-
+namespace mgud {
 std::string g_create_err;
-
-}  // namespace
-
-struct mgu_ctx {
-  int device = 0;
-  std::string err;
-  // U-Net
-  bool configured = false, loaded = false;
-  int in_ch = 0, ncls = 0, feat = 0, depth = 0, dtype = 0, Cp0 = 0;
-  std::vector<Layer> layers;  // enc[i].conv1, enc[i].conv2 ..., bott.conv1, bott.conv2, dec[b].up, dec[b].conv1, dec[b].conv2 ..., final
-  float* arena = nullptr;
-  size_t arena_floats = 0;
-  void* ws = nullptr;
-  size_t ws_bytes = 0;
-  void* gws = nullptr;  // GAT scratch
-  size_t gws_bytes = 0;
-  // profiling
-  bool prof = false;
-  std::vector<hipEvent_t> ev;  // pairs
-  int ev_used = 0;
-  hipEvent_t ev_total[2] = {nullptr, nullptr};
-};
+}
 
 namespace {
-
-int fail(mgu_ctx* c, int code, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  if (c) c->err = buf; else g_create_err = buf;
-  return code;
-}
-
-#define HIPCHK(c, call)                                                                          \
-  do {                                                                                           \
-    hipError_t e_ = (call);                                                                      \
-    if (e_ != hipSuccess) return fail(c, MGU_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
-  } while (0)
-
-int ensure(mgu_ctx* c, void** p, size_t* have, size_t need) {
-  if (*have >= need) return MGU_OK;
-  if (*p) {
-    HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipFree(*p));
-    *p = nullptr;
-    *have = 0;
-  }
-  hipError_t e = hipMalloc(p, need);
-  if (e != hipSuccess) return fail(c, MGU_ERR_NOMEM, "hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
-  *have = need;
-  return MGU_OK;
-}
-
-struct ProfScope {  // records an event pair around one conv/GEMM launch when profiling is on
-  mgu_ctx* c;
-  hipStream_t s;
-  int idx = -1;
-  ProfScope(mgu_ctx* c_, hipStream_t s_) : c(c_), s(s_) {
-    if (!c->prof) return;
-    if ((size_t)(2 * c->ev_used + 2) > c->ev.size()) {
-      hipEvent_t a, b;
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-      c->ev.push_back(a);
-      c->ev.push_back(b);
-    }
-    idx = c->ev_used++;
-    (void)hipEventRecord(c->ev[2 * idx], s);
-  }
-  ~ProfScope() {
-    if (idx >= 0) (void)hipEventRecord(c->ev[2 * idx + 1], s);
-  }
-};
-
-void level_dims(int H, int W, int depth, std::vector<int>& hs, std::vector<int>& wsz) {
-  hs.assign(depth + 1, 0);
-  wsz.assign(depth + 1, 0);
-  hs[0] = H;
-  wsz[0] = W;
-  for (int i = 1; i <= depth; ++i) {
-    hs[i] = hs[i - 1] / 2;  // MaxPool2d(2,2) floor mode, unet_encoder.py:48
-    wsz[i] = wsz[i - 1] / 2;
-  }
-}
 
 struct WsPlan {
   size_t xin, tmp, bott, total;
@@ -175,6 +71,7 @@ void mgu_destroy(mgu_ctx* c) {
   if (c->arena) (void)hipFree(c->arena);
   if (c->ws) (void)hipFree(c->ws);
   if (c->gws) (void)hipFree(c->gws);
+  if (c->tws) (void)hipFree(c->tws);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   for (auto e : c->ev_total)
     if (e) (void)hipEventDestroy(e);
@@ -241,7 +138,34 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     L.Kp = rup(L.K, 32);
     L.N = L.convt ? 4 * L.Cout : L.Cout;
     L.Np = rup(L.N, 128);
-    total += (size_t)L.Np * L.Kp + 2 * (size_t)L.Np;
+    total += (size_t)L.Np * L.Kp + 2 * (size_t)L.Np + (L.bn.empty() ? 0 : 4 * (size_t)L.Np);
+  }
+  // flat parameter order = the reference's named_parameters(): per ConvBlock conv1.{w,b}, conv2.{w,b},
+  // bn1.{w,b}, bn2.{w,b} (unet_encoder.py:7-13); decoder block: upsample.{w,b} then its conv_block; final.
+  {
+    int64_t off = 0;
+    size_t i = 0;
+    auto wsize = [](const Layer& L) { return (int64_t)L.Cout * L.Cin * L.KS * L.KS * (L.convt ? 4 : 1); };
+    while (i < c->layers.size()) {
+      Layer& A = c->layers[i];
+      if (!A.bn.empty()) {  // ConvBlock = two consecutive layers
+        Layer& B2 = c->layers[i + 1];
+        A.off_w = off, off += wsize(A);
+        A.off_b = off, off += A.Cout;
+        B2.off_w = off, off += wsize(B2);
+        B2.off_b = off, off += B2.Cout;
+        A.off_gamma = off, off += A.Cout;
+        A.off_beta = off, off += A.Cout;
+        B2.off_gamma = off, off += B2.Cout;
+        B2.off_beta = off, off += B2.Cout;
+        i += 2;
+      } else {
+        A.off_w = off, off += wsize(A);
+        A.off_b = off, off += A.Cout;
+        i += 1;
+      }
+    }
+    c->nparams = off;
   }
   if (c->arena) HIPCHK(c, hipFree(c->arena));
   c->arena = nullptr;
@@ -256,20 +180,36 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     p += L.Np;
     L.shift = p;
     p += L.Np;
+    if (!L.bn.empty()) {
+      L.mean = p, p += L.Np;
+      L.invstd = p, p += L.Np;
+      L.tscale = p, p += L.Np;
+      L.tshift = p, p += L.Np;
+    }
   }
   c->configured = true;
+  c->have_train_fwd = false;
   c->loaded = false;
   return MGU_OK;
 }
 
 int64_t mgu_unet_param_count(mgu_ctx* c) {
   if (!c || !c->configured) return -1;
-  int64_t n = 0;
+  return c->nparams;
+}
+
+int64_t mgu_unet_param_offset(mgu_ctx* c, const char* name) {
+  if (!c || !c->configured || !name) return -1;
+  const std::string key(name);
   for (auto& L : c->layers) {
-    n += (int64_t)L.Cout * L.Cin * L.KS * L.KS * (L.convt ? 4 : 1) + L.Cout;
-    if (!L.bn.empty()) n += 2 * (int64_t)L.Cout;
+    if (key == L.prefix + L.conv + ".weight") return L.off_w;
+    if (key == L.prefix + L.conv + ".bias") return L.off_b;
+    if (!L.bn.empty()) {
+      if (key == L.prefix + L.bn + ".weight") return L.off_gamma;
+      if (key == L.prefix + L.bn + ".bias") return L.off_beta;
+    }
   }
-  return n;
+  return -1;
 }
 
 int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void* hip_stream) {
@@ -298,11 +238,13 @@ int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void*
     if (L.convt) {
       if ((rc = get(cw + ".weight", (int64_t)L.Cin * L.Cout * 4, &w))) return rc;
       if ((rc = get(cw + ".bias", L.Cout, &b))) return rc;
+      L.w_src = w, L.b_src = b;
       HIPCHK(c, launch_pack_convt_w(w, L.wp, L.Cin, L.Cout, L.Kp, s));
       HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 4, s));  // scale unused (nullptr at launch)
     } else {
       if ((rc = get(cw + ".weight", (int64_t)L.Cout * L.Cin * L.KS * L.KS, &w))) return rc;
       if ((rc = get(cw + ".bias", L.Cout, &b))) return rc;
+      L.w_src = w, L.b_src = b;
       HIPCHK(c, launch_pack_conv_w(w, L.wp, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
       if (!L.bn.empty()) {
         const float *g, *be, *rm, *rv;
@@ -311,6 +253,7 @@ int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void*
         if ((rc = get(bn + ".bias", L.Cout, &be))) return rc;
         if ((rc = get(bn + ".running_mean", L.Cout, &rm))) return rc;
         if ((rc = get(bn + ".running_var", L.Cout, &rv))) return rc;
+        L.gamma = g, L.beta = be, L.run_mean = const_cast<float*>(rm), L.run_var = const_cast<float*>(rv);
         HIPCHK(c, launch_bn_fold(b, g, be, rm, rv, 1e-5f, L.scale, L.shift, L.Cout, s));
       } else {
         HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 1, s));
@@ -337,13 +280,16 @@ int mgu_unet_reserve(mgu_ctx* c, int B, int H, int W, int training) {
   return ensure(c, &c->ws, &c->ws_bytes, need);
 }
 
-static int run_conv(mgu_ctx* c, const Layer& L, const float* in, int ldin, int B, int H, int W, float* out, int ldout,
-                    int coff, int relu, int Hout, int Wout, hipStream_t s) {
+}  // extern "C"
+
+int mgud::run_layer(mgu_ctx* c, const Layer& L, const float* in, int ldin, int B, int H, int W, float* out, int ldout,
+                    int coff, int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s) {
   IgemmDesc d;
+  memset(&d, 0, sizeof d);
   d.in = in;
   d.w = L.wp;
-  d.scale = L.bn.empty() ? nullptr : L.scale;
-  d.shift = L.shift;
+  d.scale = scale;
+  d.shift = shift;
   d.out = out;
   d.M = B * H * W;
   d.H = H;
@@ -366,12 +312,18 @@ static int run_conv(mgu_ctx* c, const Layer& L, const float* in, int ldin, int B
   return MGU_OK;
 }
 
+static int run_conv(mgu_ctx* c, const Layer& L, const float* in, int ldin, int B, int H, int W, float* out, int ldout,
+                    int coff, int relu, int Hout, int Wout, hipStream_t s) {  // eval: folded BN scale/shift
+  return run_layer(c, L, in, ldin, B, H, W, out, ldout, coff, relu, L.bn.empty() ? nullptr : L.scale, L.shift, Hout, Wout, s);
+}
+
+extern "C" {
+
 int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t xs_n, int64_t xs_c, int64_t xs_h,
                      int64_t xs_w, void* logits_dev, void* const* cat_dev, void* const* feat_dev, int training,
                      void* hip_stream) {
   if (!c) return MGU_ERR_INVALID;
   if (!c->configured || !c->loaded) return fail(c, MGU_ERR_STATE, "configure + load_weights must precede forward");
-  if (training) return fail(c, MGU_ERR_STATE, "training-mode forward (batch-statistics BatchNorm) is not built yet");
   if (!x_dev || !logits_dev || !cat_dev || !feat_dev) return fail(c, MGU_ERR_INVALID, "NULL buffer");
   const int depth = c->depth;
   if (B < 1 || H < (1 << depth) || W < (1 << depth))
@@ -381,6 +333,8 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
     if (!cat_dev[i] || !feat_dev[i]) return fail(c, MGU_ERR_INVALID, "NULL cat/feat buffer %d", i);
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)hip_stream;
+  if (training)  // batch-statistics BatchNorm, running-stat update, activations kept for mgu_unet_backward
+    return unet_forward_train(c, (const float*)x_dev, xs_n, xs_c, xs_h, xs_w, B, H, W, (float*)logits_dev, cat_dev, feat_dev, s);
   const WsPlan plan = plan_ws(c, B, H, W);
   int rc = ensure(c, &c->ws, &c->ws_bytes, plan.total);
   if (rc) return rc;

@@ -1,0 +1,413 @@
+// HBM-bound kernels of the training step (scripts/train_segmentation.py:117-137): train-mode
+// BatchNorm (batch statistics, running-stat update, backward), ReLU mask, MaxPool backward,
+// softmax cross-entropy forward+backward, weight-panel packing for dgrad, gradient unpacking, Adam.
+// All tensors NHWC fp32 with an explicit pixel pitch (ld) so channel slices of the concat buffers work.
+#include "common.h"
+
+namespace mgu {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int nblk(int64_t work, int threads, int cap = 256 * 8) {
+  int64_t b = (work + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-channel reductions over the M pixels of an NHWC tensor.  Thread (q = t % (C/4), pl = t / (C/4))
+// accumulates float4 channel quads over rows pl, pl+npl, ... of the block's slab in fp32, the block
+// combines through LDS and adds ONE double per channel per block (global_atomic_add_f64).
+//   mode 0: acc0 = sum z,               acc1 = sum z*z                    (BatchNorm batch statistics)
+//   mode 1: g = dy * (y > 0); xh = (z - mean) * invstd;  acc0 = sum g, acc1 = sum g*xh   (BN backward)
+//   mode 2: acc0 = sum z (column sums: bias gradients)
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ dy,
+                                                          int lddy, const float* __restrict__ y, int ldy,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          int64_t M, int C, int rows_per_block, double* __restrict__ out0,
+                                                          double* __restrict__ out1) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][npl][C]
+  const int q = C >> 2, npl = 256 / q, t = threadIdx.x;
+  const int cq = t % q, pl = t / q;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r_end = min(M, r_begin + rows_per_block);
+  if (pl < npl) {
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+    if (MODE == 1) {
+      mu = *reinterpret_cast<const f32x4*>(mean + cq * 4);
+      is = *reinterpret_cast<const f32x4*>(invstd + cq * 4);
+    }
+    for (int64_t r = r_begin + pl; r < r_end; r += npl) {
+      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + r * ldz + cq * 4);
+      if (MODE == 0) {
+        a0 += zv;
+        a1 += zv * zv;
+      } else if (MODE == 1) {
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + r * lddy + cq * 4);
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + cq * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g = yv[j] > 0.f ? dv[j] : 0.f;
+          a0[j] += g;
+          a1[j] += g * ((zv[j] - mu[j]) * is[j]);
+        }
+      } else {
+        a0 += zv;
+      }
+    }
+    *reinterpret_cast<f32x4*>(red + pl * C + cq * 4) = a0;
+    if (MODE != 2) *reinterpret_cast<f32x4*>(red + (npl + pl) * C + cq * 4) = a1;
+  }
+  __syncthreads();
+  if (t < C) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = 0; i < npl; ++i) {
+      s0 += (double)red[i * C + t];
+      if (MODE != 2) s1 += (double)red[(npl + i) * C + t];
+    }
+    atomicAdd(out0 + t, s0);
+    if (MODE != 2) atomicAdd(out1 + t, s1);
+  }
+}
+
+static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const float* dy, int lddy, const float* y, int ldy,
+                                     const float* mean, const float* invstd, int64_t M, int C, double* out0, double* out1,
+                                     hipStream_t s) {
+  if ((C & 3) || C < 4 || C > 1024 || (ldz & 3)) return hipErrorInvalidValue;
+  if (C > 256) {  // process 256-channel slabs (npl >= 1 requires C/4 <= 256; keep LDS rows short)
+    for (int c0 = 0; c0 < C; c0 += 256) {
+      const int cc = min(256, C - c0);
+      hipError_t e = launch_chan_reduce(mode, z + c0, ldz, dy ? dy + c0 : nullptr, lddy, y ? y + c0 : nullptr, ldy,
+                                        mean ? mean + c0 : nullptr, invstd ? invstd + c0 : nullptr, M, cc, out0 + c0,
+                                        out1 ? out1 + c0 : nullptr, s);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  const int npl = 256 / (C >> 2);
+  int rows = 2048;
+  int blocks = (int)((M + rows - 1) / rows);
+  if (blocks > 2048) { blocks = 2048; rows = (int)((M + blocks - 1) / blocks); }
+  blocks = (int)((M + rows - 1) / rows);
+  const size_t lds = (size_t)2 * npl * C * sizeof(float);
+  if (mode == 0) hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(blocks), dim3(256), lds, s, z, ldz, dy, lddy, y, ldy, mean, invstd, M, C, rows, out0, out1);
+  else if (mode == 1) hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(blocks), dim3(256), lds, s, z, ldz, dy, lddy, y, ldy, mean, invstd, M, C, rows, out0, out1);
+  else hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3(blocks), dim3(256), lds, s, z, ldz, dy, lddy, y, ldy, mean, invstd, M, C, rows, out0, out1);
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_stats(const float* z, int ldz, int64_t M, int C, double* sum, double* sumsq, hipStream_t s) {
+  return launch_chan_reduce(0, z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, sum, sumsq, s);
+}
+hipError_t launch_bn_bwd_reduce(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz,
+                                const float* mean, const float* invstd, int64_t M, int C, double* sum_g, double* sum_gx,
+                                hipStream_t s) {
+  return launch_chan_reduce(1, z, ldz, dy, lddy, y, ldy, mean, invstd, M, C, sum_g, sum_gx, s);
+}
+hipError_t launch_colsum(const float* z, int ldz, int64_t M, int C, double* sum, hipStream_t s) {
+  return launch_chan_reduce(2, z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, sum, nullptr, s);
+}
+
+// ---- BatchNorm2d training forward, finalize (unet_encoder.py:12-13: eps 1e-5, momentum 0.1) -------------
+// mean, biased var from the double sums; running stats updated IN PLACE with the unbiased variance.
+__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, double M, float eps,
+                                   float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ run_mean, float* __restrict__ run_var, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  const double mu = sum[i] / M;
+  double var = sumsq[i] / M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[i] = (float)mu;
+  invstd[i] = is;
+  const float sc = gamma[i] * is;
+  scale[i] = sc;
+  shift[i] = beta[i] - (float)mu * sc;
+  if (run_mean) {
+    const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+    run_mean[i] = (1.f - momentum) * run_mean[i] + momentum * (float)mu;
+    run_var[i] = (1.f - momentum) * run_var[i] + momentum * (float)unb;
+  }
+}
+
+hipError_t launch_bn_finalize(const double* sum, const double* sumsq, int64_t M, float eps, float momentum,
+                              const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
+                              float* shift, float* run_mean, float* run_var, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, sum, sumsq, (double)M, eps, momentum,
+                     gamma, beta, mean, invstd, scale, shift, run_mean, run_var, C);
+  return hipGetLastError();
+}
+
+// ---- y = relu(scale*z + shift), output with pitch/offset ---------------------------------------------
+__global__ void bn_apply_relu_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, float* __restrict__ y, int ldy, int64_t M, int C) {
+  const int q = C >> 2;
+  const int64_t total = M * q;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / q;
+    const int c0 = (int)(i - r * q) * 4;
+    const f32x4 zv = *reinterpret_cast<const f32x4*>(z + r * C + c0);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c0);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c0);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf(zv[j] * sc[j] + sh[j], 0.f);
+    *reinterpret_cast<f32x4*>(y + r * ldy + c0) = o;
+  }
+}
+
+hipError_t launch_bn_apply_relu(const float* z, const float* scale, const float* shift, float* y, int ldy, int64_t M, int C,
+                                hipStream_t s) {
+  hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(nblk(M * (C >> 2), 256)), dim3(256), 0, s, z, scale, shift, y, ldy, M, C);
+  return hipGetLastError();
+}
+
+// ---- BN backward apply: dz = gamma*invstd * (g - sum_g/M - xh * sum_gx/M), g = dy*(y>0) -------------------
+// also emits dgamma = sum_gx, dbeta = sum_g (fp32) when block 0 runs.
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                    const float* __restrict__ z, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const double* __restrict__ sum_g, const double* __restrict__ sum_gx, int64_t M, int C,
+                                    float* __restrict__ dz, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int q = C >> 2;
+  const int64_t total = M * q;
+  const float invM = (float)(1.0 / (double)M);
+  if (blockIdx.x == 0)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      dgamma[c] = (float)sum_gx[c];
+      dbeta[c] = (float)sum_g[c];
+    }
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / q;
+    const int c0 = (int)(i - r * q) * 4;
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + r * lddy + c0);
+    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + c0);
+    const f32x4 zv = *reinterpret_cast<const f32x4*>(z + r * C + c0);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c0 + j;
+      const float g = yv[j] > 0.f ? dv[j] : 0.f;
+      const float xh = (zv[j] - mean[c]) * invstd[c];
+      o[j] = gamma[c] * invstd[c] * (g - (float)sum_g[c] * invM - xh * ((float)sum_gx[c] * invM));
+    }
+    *reinterpret_cast<f32x4*>(dz + r * C + c0) = o;
+  }
+}
+
+hipError_t launch_bn_bwd_apply(const float* dy, int lddy, const float* y, int ldy, const float* z, const float* mean,
+                               const float* invstd, const float* gamma, const double* sum_g, const double* sum_gx,
+                               int64_t M, int C, float* dz, float* dgamma, float* dbeta, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(M * (C >> 2), 256)), dim3(256), 0, s, dy, lddy, y, ldy, z, mean, invstd,
+                     gamma, sum_g, sum_gx, M, C, dz, dgamma, dbeta);
+  return hipGetLastError();
+}
+
+// ---- double -> float copy (bias gradients from column sums) --------------------------------------------
+__global__ void d2f_kernel(const double* __restrict__ in, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+hipError_t launch_d2f(const double* in, float* out, int n, hipStream_t s) {
+  hipLaunchKernelGGL(d2f_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
+  return hipGetLastError();
+}
+
+// ---- MaxPool2d(2,2) backward, accumulated into dskip (first maximum wins, like aten) ------------------
+__global__ void maxpool2_bwd_add_kernel(const float* __restrict__ ypre, int ldy, const float* __restrict__ dpool,
+                                        float* __restrict__ dskip, int ldd, int B, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1, q = C >> 2;
+  const int64_t total = (int64_t)B * Ho * Wo * q;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % q) * 4;
+    int64_t pix = i / q;
+    const int xo = (int)(pix % Wo);
+    pix /= Wo;
+    const int yo = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    const int64_t p00 = ((int64_t)n * H + 2 * yo) * W + 2 * xo;
+    const int64_t offs[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(ypre + offs[k] * ldy + c0);
+    const f32x4 dp = *reinterpret_cast<const f32x4*>(dpool + (((int64_t)n * Ho + yo) * Wo + xo) * C + c0);
+    f32x4 add[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int best = 0;
+      float bv = v[0][j];
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (v[k][j] > bv) { bv = v[k][j]; best = k; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) add[k][j] = (k == best) ? dp[j] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4* p = reinterpret_cast<f32x4*>(dskip + offs[k] * ldd + c0);
+      *p = *p + add[k];
+    }
+  }
+}
+
+hipError_t launch_maxpool2_bwd_add(const float* y, int ldy, const float* dpool, float* dskip, int ldd, int B, int H, int W,
+                                   int C, hipStream_t s) {
+  const int64_t total = (int64_t)B * (H >> 1) * (W >> 1) * (C >> 2);
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(maxpool2_bwd_add_kernel, dim3(nblk(total, 256)), dim3(256), 0, s, y, ldy, dpool, dskip, ldd, B, H, W, C);
+  return hipGetLastError();
+}
+
+// ---- zero channels [coff, coff+C) of the pixels outside the h2 x w2 top-left region (F.pad backward) ----
+__global__ void zero_pad_region_kernel(float* __restrict__ buf, int ld, int coff, int C, int B, int H, int W, int h2, int w2) {
+  const int64_t total = (int64_t)B * H * W;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    if (y >= h2 || x >= w2)
+      for (int c = 0; c < C; ++c) buf[i * ld + coff + c] = 0.f;
+  }
+}
+hipError_t launch_zero_pad_region(float* buf, int ld, int coff, int C, int B, int H, int W, int h2, int w2, hipStream_t s) {
+  hipLaunchKernelGGL(zero_pad_region_kernel, dim3(nblk((int64_t)B * H * W, 256)), dim3(256), 0, s, buf, ld, coff, C, B, H, W, h2, w2);
+  return hipGetLastError();
+}
+
+// ---- nn.CrossEntropyLoss (mean) forward + gradient w.r.t. logits (train_segmentation.py:91,127) --------
+// logits NHWC (M, C); labels int64 (M); dlogits written with pitch ldd >= C (pad columns zeroed),
+// scaled by grad_scale (= 1/M for the mean reduction); loss_sum accumulates sum_i -log p_i[y_i] in double.
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                         int64_t M, int C, float grad_scale, float* __restrict__ dlogits,
+                                                         int ldd, double* __restrict__ loss_sum) {
+  __shared__ double red[256];
+  double local = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* p = logits + i * C;
+    float mx = p[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
+    const float lse = mx + logf(se);
+    const int y = (int)labels[i];
+    local += (double)(lse - p[y]);
+    const float inv = 1.f / se;
+    for (int c = 0; c < ldd; ++c) {
+      float g = 0.f;
+      if (c < C) g = (expf(p[c] - mx) * inv - (c == y ? 1.f : 0.f)) * grad_scale;
+      dlogits[i * ldd + c] = g;
+    }
+  }
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(loss_sum, red[0]);
+}
+
+__global__ void ce_finalize_kernel(const double* loss_sum, double M, float* loss_out) { *loss_out = (float)(*loss_sum / M); }
+
+hipError_t launch_ce(const float* logits, const int64_t* labels, int64_t M, int C, float grad_scale, float* dlogits, int ldd,
+                     double* loss_sum, float* loss_out, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(nblk(M, 256, 2048)), dim3(256), 0, s, logits, labels, M, C, grad_scale, dlogits,
+                     ldd, loss_sum);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, s, loss_sum, (double)M, loss_out);
+  return hipGetLastError();
+}
+
+// ---- dgrad weight panels -----------------------------------------------------------------------------
+// conv3x3 / 1x1: din = conv(dz, W') with W'[ci][(2-r,2-s), co] = W[co][ci][r][s]:
+// panel [Cin][Kp], k = tap'*Cop + co  (Cop = Cout rounded up to 4, zero padded)
+__global__ void pack_dgrad_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int Cop, int KS,
+                                    int Kp) {
+  const int64_t total = (int64_t)Cin * Kp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i / Kp), k = (int)(i - (int64_t)ci * Kp);
+    const int tap = k / Cop, co = k - tap * Cop;
+    float v = 0.f;
+    if (tap < KS * KS && co < Cout) v = w[((int64_t)co * Cin + ci) * KS * KS + (KS * KS - 1 - tap)];
+    wp[i] = v;
+  }
+}
+hipError_t launch_pack_dgrad_w(const float* w, float* wp, int Cout, int Cin, int Cop, int KS, int Kp, hipStream_t s) {
+  hipLaunchKernelGGL(pack_dgrad_w_kernel, dim3(nblk((int64_t)Cin * Kp, 256)), dim3(256), 0, s, w, wp, Cout, Cin, Cop, KS, Kp);
+  return hipGetLastError();
+}
+// ConvTranspose2d dgrad: dprev[m][ci] = sum_{q,co} dup[pix(m,q)][co] * W[ci][co][q]: panel [Cin][Kp], k = q*Cout + co
+__global__ void pack_convt_dgrad_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int Kp) {
+  const int64_t total = (int64_t)Cin * Kp;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i / Kp), k = (int)(i - (int64_t)ci * Kp);
+    const int q = k / Cout, co = k - q * Cout;
+    wp[i] = (q < 4) ? w[((int64_t)ci * Cout + co) * 4 + q] : 0.f;
+  }
+}
+hipError_t launch_pack_convt_dgrad_w(const float* w, float* wp, int Cin, int Cout, int Kp, hipStream_t s) {
+  hipLaunchKernelGGL(pack_convt_dgrad_w_kernel, dim3(nblk((int64_t)Cin * Kp, 256)), dim3(256), 0, s, w, wp, Cin, Cout, Kp);
+  return hipGetLastError();
+}
+
+// ---- gradient panels -> the reference's parameter layouts ---------------------------------------------
+// conv: panel [Cout][Kp], k = tap*Cp + c  ->  OIHW (Cout, Cin, KS, KS)
+__global__ void unpack_conv_grad_kernel(const float* __restrict__ dwp, float* __restrict__ g, int Cout, int Cin, int Cp, int KS,
+                                        int Kp) {
+  const int64_t total = (int64_t)Cout * Cin * KS * KS;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % (KS * KS));
+    const int64_t r = i / (KS * KS);
+    const int ci = (int)(r % Cin), co = (int)(r / Cin);
+    g[i] = dwp[(int64_t)co * Kp + tap * Cp + ci];
+  }
+}
+hipError_t launch_unpack_conv_grad(const float* dwp, float* g, int Cout, int Cin, int Cp, int KS, int Kp, hipStream_t s) {
+  hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(nblk((int64_t)Cout * Cin * KS * KS, 256)), dim3(256), 0, s, dwp, g, Cout, Cin,
+                     Cp, KS, Kp);
+  return hipGetLastError();
+}
+// convT: panel [Cin][Kp], k = q*Cout + co  ->  (Cin, Cout, 2, 2)
+__global__ void unpack_convt_grad_kernel(const float* __restrict__ dwp, float* __restrict__ g, int Cin, int Cout, int Kp) {
+  const int64_t total = (int64_t)Cin * Cout * 4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 3);
+    const int64_t r = i >> 2;
+    const int co = (int)(r % Cout), ci = (int)(r / Cout);
+    g[i] = dwp[(int64_t)ci * Kp + q * Cout + co];
+  }
+}
+hipError_t launch_unpack_convt_grad(const float* dwp, float* g, int Cin, int Cout, int Kp, hipStream_t s) {
+  hipLaunchKernelGGL(unpack_convt_grad_kernel, dim3(nblk((int64_t)Cin * Cout * 4, 256)), dim3(256), 0, s, dwp, g, Cin, Cout, Kp);
+  return hipGetLastError();
+}
+
+// ---- torch.optim.Adam (L2 weight decay folded into the gradient), train_segmentation.py:96 --------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                            float grad_scale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    const float gi = g[i] * grad_scale + wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                       float wd, int step, float grad_scale, hipStream_t s) {
+  const float bc1 = 1.f - powf(b1, (float)step);
+  const float bc2 = 1.f - powf(b2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, sqrtf(bc2),
+                     grad_scale);
+  return hipGetLastError();
+}
+
+}  // namespace mgu

@@ -1,7 +1,7 @@
 """mgunet: MI355X-native MinGraph-UNet segmentation hot path (host-side mirror of the reference's
 model/ API over libmgunet.so).  Importing works without a GPU; running anything needs one."""
 from .config import build_from_config, get_config_recursively, load_config  # noqa: F401
-from .engine import MinGraphUNet, argmax_classes, gat_forward_csr, segment_batch, shard_batch  # noqa: F401
+from .engine import MinGraphUNet, Trainer, allreduce_mean_, argmax_classes, gat_forward_csr, segment_batch, shard_batch  # noqa: F401
 from .gat import GATNetwork, GraphAttentionLayer, MultiHeadGATLayer  # noqa: F401
 from .patch_graph import PatchGraphConstructor  # noqa: F401
 from .unet import ConvBlock, DecoderBlock, UNet, UNetDecoder, UNetEncoder  # noqa: F401
@@ -9,4 +9,4 @@ from ._lib import build, lib  # noqa: F401
 
 __all__ = ["UNet", "UNetEncoder", "UNetDecoder", "ConvBlock", "DecoderBlock", "GATNetwork", "MultiHeadGATLayer",
            "GraphAttentionLayer", "PatchGraphConstructor", "MinGraphUNet", "segment_batch", "argmax_classes",
-           "gat_forward_csr", "shard_batch", "load_config", "get_config_recursively", "build_from_config", "build", "lib"]
+           "gat_forward_csr", "shard_batch", "Trainer", "allreduce_mean_", "load_config", "get_config_recursively", "build_from_config", "build", "lib"]

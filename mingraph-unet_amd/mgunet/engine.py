@@ -89,3 +89,101 @@ def shard_batch(global_batch: int, rank: int, world_size: int):
     base, rem = divmod(global_batch, world_size)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def allreduce_mean_(flat: torch.Tensor, group=None) -> float:
+    """Sum-all-reduce `flat` in place over the ranks (RCCL over xGMI when the backend is "nccl") and return
+    the factor (1/world) that turns the sum into the mean; 1.0 and no collective for a single process.
+    One flat pre-packed buffer = one collective per step (31 MB for UNet(3,2,32,4))."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 1.0
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world
+
+
+class Trainer:
+    """The train step of scripts/train_segmentation.py:117-137 on the HIP path:
+    zero_grad -> logits = model(images) (train-mode BatchNorm) -> CrossEntropyLoss (mean) -> backward ->
+    [mean all-reduce of the flat gradient over the data-parallel ranks] -> Adam(lr, weight_decay as L2).
+    Parameters are re-homed as views of ONE flat fp32 buffer (named_parameters() order) so the optimizer is
+    a single kernel and the gradient exchange a single collective.  Each rank normalises BatchNorm over its
+    own shard (DDP semantics)."""
+
+    def __init__(self, model: UNet, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+        params = list(model.named_parameters())
+        if not params or not params[0][1].is_cuda:
+            raise RuntimeError("move the model to a HIP device before building a Trainer (no CPU fallback)")
+        self.model, self.group = model, process_group
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        dev = params[0][1].device
+        self.device = dev
+        ctx = model._context(dev)
+        n = int(_lib.lib().mgu_unet_param_count(ctx.handle))
+        if n != sum(p.numel() for _, p in params):
+            raise RuntimeError("parameter count mismatch between the module tree and libmgunet")
+        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        off = 0
+        for name, p in params:  # named_parameters() order must be the library's flat order
+            lo = int(_lib.lib().mgu_unet_param_offset(ctx.handle, name.encode()))
+            if lo != off:
+                raise RuntimeError(f"flat parameter layout mismatch at {name}: {lo} != {off}")
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p)
+            p.grad = self.grad[off:off + k].view_as(p)
+            off += k
+        model.mark_parameters_changed()
+        model._slots = None
+        self.step_count = 0
+        self._loss = torch.zeros(1, device=dev, dtype=torch.float32)
+
+    def set_lr(self, lr: float) -> None:  # StepLR etc. live on the host (train_segmentation.py:105,143)
+        self.lr = lr
+
+    def forward_backward(self, images: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
+        """Fills self.grad with d(mean CE)/d(params) of this rank's shard; returns the loss (device scalar)."""
+        model, dev = self.model, self.device
+        if masks.dtype != torch.int64 or not masks.is_cuda:
+            raise TypeError("masks must be an int64 tensor on the HIP device")
+        model.train()
+        logits, _, _ = model(images)
+        B, Cc, H, W = logits.shape
+        if tuple(masks.shape) != (B, H, W):
+            raise ValueError(f"masks shape {tuple(masks.shape)} does not match logits {(B, H, W)}")
+        ctx = model._context(dev)
+        L = _lib.lib()
+        nhwc = logits.permute(0, 2, 3, 1)
+        assert nhwc.is_contiguous()
+        masks = masks.contiguous()
+        npix = B * H * W
+        dlogits = torch.empty((npix, (Cc + 3) // 4 * 4), device=dev, dtype=torch.float32)
+        stream = _lib.current_stream_ptr(dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.mgu_cross_entropy(ctx.handle, nhwc.data_ptr(), masks.data_ptr(), npix, Cc, 1.0 / npix,
+                                           dlogits.data_ptr(), self._loss.data_ptr(), stream), ctx.handle)
+            _lib.check(L.mgu_unet_backward(ctx.handle, dlogits.data_ptr(), self.grad.data_ptr(), stream), ctx.handle)
+        return self._loss
+
+    def optimizer_step(self, grad_scale: float = 1.0) -> None:
+        model, dev = self.model, self.device
+        ctx = model._context(dev)
+        self.step_count += 1
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgu_adam_step(ctx.handle, self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                self.exp_avg_sq.data_ptr(), self.flat.numel(), self.lr, self.betas[0],
+                                                self.betas[1], self.eps, self.wd, self.step_count, grad_scale,
+                                                _lib.current_stream_ptr(dev)), ctx.handle)
+        model.mark_parameters_changed()
+
+    def train_step(self, images: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
+        loss = self.forward_backward(images, masks)
+        scale = allreduce_mean_(self.grad, self.group)   # the only data-path collective of the build
+        self.optimizer_step(scale)
+        return loss

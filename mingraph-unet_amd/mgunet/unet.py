@@ -93,6 +93,7 @@ class UNet(nn.Module):
     def __getstate__(self):  # contexts hold device handles: never pickled / deep-copied
         d = self.__dict__.copy()
         d["_ctx"], d["_loaded_sig"], d["_slots"] = {}, {}, None
+        d.pop("_train_outputs", None)
         return d
 
     def _context(self, device: torch.device) -> "_lib.Context":
@@ -138,6 +139,14 @@ class UNet(nn.Module):
                    ctx.handle)
         self._loaded_sig[ctx.device_index] = sig
 
+    def mark_parameters_changed(self) -> None:
+        """Parameters/buffers were modified behind torch's back (Adam step or BN running stats written by
+        the library through raw pointers): repack on the next forward."""
+        self._loaded_sig.clear()
+
+    def _bn_counters(self):
+        return [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+
     def flops(self, B, H, W) -> float:
         """2*MAC of the convolutions of one forward."""
         ctx = next(iter(self._ctx.values()), None)
@@ -177,5 +186,11 @@ class UNet(nn.Module):
                                             cat_ptrs, feat_ptrs, 1 if self.training else 0,
                                             _lib.current_stream_ptr(dev))
         _lib.check(rc, ctx.handle)
+        if self.training:
+            # the library updated running_mean/var in place through raw pointers: bump the counters the
+            # reference's BatchNorm bumps (num_batches_tracked) and drop the folded eval scale/shift
+            torch._foreach_add_(self._bn_counters(), 1)
+            self.mark_parameters_changed()
+            self._train_outputs = (logits, cats, feats)  # kept alive for mgu_unet_backward
         skips = [cats[i].permute(0, 3, 1, 2)[:, : (f << i)] for i in range(d)]
         return logits.permute(0, 3, 1, 2), skips, [t.permute(0, 3, 1, 2) for t in feats]

@@ -284,6 +284,20 @@ def gen_c5():
             gn.append(rn)
         for k, v in ostats.items():
             assert float((v - sd[k]).abs().max()) <= 1e-5, k
+        # the same step with the reference module in float64: train-mode BatchNorm + ReLU masks make the
+        # fp32 gradients ill-conditioned (a 1e-7 perturbation flips masks), so the fixture records how far
+        # the reference's OWN fp32 gradients sit from its fp64 gradients; tests scale their tolerance by it
+        m64 = ref_unet(cfg, p, train=True).double()
+        lg64, _, _ = m64(x.double())
+        loss64 = torch.nn.CrossEntropyLoss()(lg64, y)
+        loss64.backward()
+        g64 = {k: v.grad.detach() for k, v in m64.named_parameters()}
+        cond = np.array([float((grads[k].double() - g64[k]).norm() / (g64[k].norm() + 1e-300)) for k in names])
+        print(f"   [{tag}] fp32-vs-fp64 reference gradient deviation: median {np.median(cond):.2e} max(non-bias) "
+              f"{max(c for c, k in zip(cond, names) if not (k.endswith('.bias') and 'conv' in k and 'bn' not in k)):.2e}")
+        out[f"{tag}_loss64"] = np.float64(float(loss64))
+        out[f"{tag}_grad_norms64"] = np.array([float(g64[k].norm()) for k in names], dtype=np.float64)
+        out[f"{tag}_cond"] = cond
         out[f"{tag}_loss"] = np.float64(float(loss))
         out[f"{tag}_grad_norms"] = np.array(gn, dtype=np.float64)
         flat_g = torch.cat([grads[k].reshape(-1) for k in names])
@@ -291,6 +305,7 @@ def gen_c5():
         idx = sample_idx(f"c5/{tag}/idx", flat_g.numel(), 4096)
         out[f"{tag}_idx"] = idx
         out[f"{tag}_grad_s"] = flat_g[idx].numpy()
+        out[f"{tag}_grad_s64"] = torch.cat([g64[k].reshape(-1) for k in names])[idx].numpy()
         out[f"{tag}_param_s"] = flat_p[idx].numpy()
         out[f"{tag}_bn_rm"] = sd["encoder.encoder_blocks.0.bn1.running_mean"].numpy()
         out[f"{tag}_bn_rv"] = sd["encoder.encoder_blocks.0.bn1.running_var"].numpy()

@@ -211,7 +211,7 @@ def test_errors_surface_as_python_exceptions(cuda):
     with pytest.raises(TypeError):
         m(torch.zeros(1, 3, 32, 32, device=cuda, dtype=torch.float16))
     with pytest.raises(RuntimeError):
-        m.train()(torch.zeros(1, 3, 32, 32, device=cuda))  # train-mode BN not built yet: loud, not silent
+        m(torch.zeros(1, 4, 32, 32, device=cuda))          # wrong channel count
 
 
 def test_weights_are_repacked_after_update(cuda):
