@@ -56,20 +56,20 @@ struct WgradDesc {
 hipError_t launch_wgrad_f32(const WgradDesc& d, hipStream_t s);
 
 // train_kernels.hip
-hipError_t launch_bn_stats(const float* z, int ldz, int64_t M, int C, double* sum, double* sumsq, hipStream_t s);
+size_t chan_reduce_work_bytes(int Cmax);
+hipError_t launch_bn_stats(const float* z, int ldz, int64_t M, int C, double* work, double* sums, hipStream_t s);
 hipError_t launch_bn_finalize(const double* sum, const double* sumsq, int64_t M, float eps, float momentum,
                               const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
                               float* shift, float* run_mean, float* run_var, int C, hipStream_t s);
 hipError_t launch_bn_apply_relu(const float* z, const float* scale, const float* shift, float* y, int ldy, int64_t M, int C,
                                 hipStream_t s);
 hipError_t launch_bn_bwd_reduce(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz,
-                                const float* mean, const float* invstd, int64_t M, int C, double* sum_g, double* sum_gx,
-                                hipStream_t s);
+                                const float* mean, const float* invstd, int64_t M, int C, double* work, double* sums,
+                                float* dbeta, float* dgamma, hipStream_t s);
 hipError_t launch_bn_bwd_apply(const float* dy, int lddy, const float* y, int ldy, const float* z, const float* mean,
-                               const float* invstd, const float* gamma, const double* sum_g, const double* sum_gx,
-                               int64_t M, int C, float* dz, float* dgamma, float* dbeta, hipStream_t s);
-hipError_t launch_colsum(const float* z, int ldz, int64_t M, int C, double* sum, hipStream_t s);
-hipError_t launch_d2f(const double* in, float* out, int n, hipStream_t s);
+                               const float* invstd, const float* gamma, const double* sums, int64_t M, int C, float* dz,
+                               double* work, float* dbias, hipStream_t s);
+hipError_t launch_colsum(const float* z, int ldz, int64_t M, int C, double* work, float* out, hipStream_t s);
 hipError_t launch_maxpool2_bwd_add(const float* y, int ldy, const float* dpool, float* dskip, int ldd, int B, int H, int W,
                                    int C, hipStream_t s);
 hipError_t launch_zero_pad_region(float* buf, int ld, int coff, int C, int B, int H, int W, int h2, int w2, hipStream_t s);

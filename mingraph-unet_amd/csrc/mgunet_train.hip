@@ -13,7 +13,7 @@ using namespace mgud;
 namespace {
 
 struct TPlan {
-  size_t xin = 0, bott = 0, ta = 0, tb = 0, tc = 0, dwp = 0, dgp = 0, sums = 0, total = 0;
+  size_t xin = 0, bott = 0, ta = 0, tb = 0, tc = 0, dwp = 0, dgp = 0, sums = 0, red = 0, total = 0;
   std::vector<size_t> z, y1, pooled, dcat;
 };
 
@@ -59,6 +59,7 @@ TPlan plan_train(const mgu_ctx* c, int B, int H, int W) {
   p.dwp = fl(pmax);
   p.dgp = fl(pmax);
   p.sums = take(sizeof(double) * 2 * ((size_t)c->feat << d) + 64);
+  p.red = take(chan_reduce_work_bytes(c->feat << d));
   p.total = off;
   return p;
 }
@@ -67,13 +68,12 @@ inline float* at(mgu_ctx* c, size_t off) { return (float*)((char*)c->tws + off);
 
 // conv (+bias) -> z ; batch statistics ; y = relu(bn(z)) written with pitch ldy
 int conv_bn_relu_train(mgu_ctx* c, Layer& L, const float* in, int ldin, int B, int H, int W, float* z, float* y, int ldy,
-                       double* sums, hipStream_t s) {
+                       double* sums, double* red, hipStream_t s) {
   const int64_t M = (int64_t)B * H * W;
   const int C = L.Cout;
   int rc = run_layer(c, L, in, ldin, B, H, W, z, C, 0, 0, nullptr, L.b_src, 0, 0, s);  // unet_encoder.py:16 / :20
   if (rc) return rc;
-  HIPCHK(c, hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s));
-  HIPCHK(c, launch_bn_stats(z, C, M, C, sums, sums + C, s));
+  HIPCHK(c, launch_bn_stats(z, C, M, C, red, sums, s));
   HIPCHK(c, launch_bn_finalize(sums, sums + C, M, 1e-5f, 0.1f, L.gamma, L.beta, L.mean, L.invstd, L.tscale, L.tshift,
                                L.run_mean, L.run_var, C, s));  // nn.BatchNorm2d defaults, unet_encoder.py:12-13
   HIPCHK(c, launch_bn_apply_relu(z, L.tscale, L.tshift, y, ldy, M, C, s));
@@ -85,7 +85,7 @@ struct Bwd {
   mgu_ctx* c;
   hipStream_t s;
   float *ta, *tb, *dwp, *dgp, *flat;
-  double* sums;
+  double *sums, *red;
 };
 
 // weight gradient of a conv layer into flat[off_w]: Z = dz (dense, pitch Cout), A = gather of the layer's input
@@ -130,13 +130,11 @@ int bn_relu_bwd(Bwd& w, const Layer& L, const float* dy, int lddy, float* dz) {
   mgu_ctx* c = w.c;
   const int64_t M = (int64_t)L.t_B * L.t_H * L.t_W;
   const int C = L.Cout;
-  HIPCHK(c, hipMemsetAsync(w.sums, 0, sizeof(double) * 2 * C, w.s));
-  HIPCHK(c, launch_bn_bwd_reduce(dy, lddy, L.t_y, L.t_ldy, L.t_z, C, L.mean, L.invstd, M, C, w.sums, w.sums + C, w.s));
-  HIPCHK(c, launch_bn_bwd_apply(dy, lddy, L.t_y, L.t_ldy, L.t_z, L.mean, L.invstd, L.gamma, w.sums, w.sums + C, M, C, dz,
-                                w.flat + L.off_gamma, w.flat + L.off_beta, w.s));
-  HIPCHK(c, hipMemsetAsync(w.sums, 0, sizeof(double) * C, w.s));
-  HIPCHK(c, launch_colsum(dz, C, M, C, w.sums, w.s));  // conv bias grad = sum of dz (analytically ~0 under BN)
-  HIPCHK(c, launch_d2f(w.sums, w.flat + L.off_b, C, w.s));
+  HIPCHK(c, launch_bn_bwd_reduce(dy, lddy, L.t_y, L.t_ldy, L.t_z, C, L.mean, L.invstd, M, C, w.red, w.sums,
+                                 w.flat + L.off_beta, w.flat + L.off_gamma, w.s));
+  // dz and, fused, the conv bias gradient = column sum of dz (analytically ~0 under BatchNorm)
+  HIPCHK(c, launch_bn_bwd_apply(dy, lddy, L.t_y, L.t_ldy, L.t_z, L.mean, L.invstd, L.gamma, w.sums, M, C, dz, w.red,
+                                w.flat + L.off_b, w.s));
   return MGU_OK;
 }
 
@@ -167,6 +165,7 @@ int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t x
   std::vector<int> hs, ws;
   level_dims(H, W, d, hs, ws);
   double* sums = (double*)((char*)c->tws + p.sums);
+  double* red = (double*)((char*)c->tws + p.red);
   for (int i = 0; i < d; ++i)
     if (2 * hs[i + 1] != hs[i] || 2 * ws[i + 1] != ws[i])
       HIPCHK(c, hipMemsetAsync(cat_dev[i], 0, (size_t)B * hs[i] * ws[i] * 2 * ((size_t)c->feat << i) * sizeof(float), s));
@@ -181,8 +180,8 @@ int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t x
   for (int i = 0; i < d; ++i) {  // encoder
     const int C = c->feat << i, li = 2 * i;
     float* cat = (float*)cat_dev[i];
-    if ((rc = conv_bn_relu_train(c, c->layers[li], cur, ld, B, hs[i], ws[i], at(c, p.z[li]), at(c, p.y1[li]), C, sums, s))) return rc;
-    if ((rc = conv_bn_relu_train(c, c->layers[li + 1], at(c, p.y1[li]), C, B, hs[i], ws[i], at(c, p.z[li + 1]), cat, 2 * C, sums, s))) return rc;
+    if ((rc = conv_bn_relu_train(c, c->layers[li], cur, ld, B, hs[i], ws[i], at(c, p.z[li]), at(c, p.y1[li]), C, sums, red, s))) return rc;
+    if ((rc = conv_bn_relu_train(c, c->layers[li + 1], at(c, p.y1[li]), C, B, hs[i], ws[i], at(c, p.z[li + 1]), cat, 2 * C, sums, red, s))) return rc;
     float* pooled = at(c, p.pooled[i]);
     HIPCHK(c, launch_maxpool2(cat, 2 * C, pooled, B, hs[i], ws[i], C, s));
     c->t_cat[i] = cat, c->t_pooled[i] = pooled;
@@ -191,8 +190,8 @@ int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t x
   {  // bottleneck
     const int C = c->feat << d, li = 2 * d;
     float* bott = at(c, p.bott);
-    if ((rc = conv_bn_relu_train(c, c->layers[li], cur, ld, B, hs[d], ws[d], at(c, p.z[li]), at(c, p.y1[li]), C, sums, s))) return rc;
-    if ((rc = conv_bn_relu_train(c, c->layers[li + 1], at(c, p.y1[li]), C, B, hs[d], ws[d], at(c, p.z[li + 1]), bott, C, sums, s))) return rc;
+    if ((rc = conv_bn_relu_train(c, c->layers[li], cur, ld, B, hs[d], ws[d], at(c, p.z[li]), at(c, p.y1[li]), C, sums, red, s))) return rc;
+    if ((rc = conv_bn_relu_train(c, c->layers[li + 1], at(c, p.y1[li]), C, B, hs[d], ws[d], at(c, p.z[li + 1]), bott, C, sums, red, s))) return rc;
     cur = bott, ld = C;
   }
   for (int b = 0; b < d; ++b) {  // decoder
@@ -202,8 +201,8 @@ int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t x
     Layer& U = c->layers[lu];
     if ((rc = run_layer(c, U, cur, ld, B, hs[i + 1], ws[i + 1], cat, 2 * C, C, 0, nullptr, U.shift, hs[i], ws[i], s))) return rc;
     U.t_in = cur, U.t_ldin = ld, U.t_B = B, U.t_H = hs[i + 1], U.t_W = ws[i + 1];
-    if ((rc = conv_bn_relu_train(c, c->layers[lu + 1], cat, 2 * C, B, hs[i], ws[i], at(c, p.z[lu + 1]), at(c, p.y1[lu + 1]), C, sums, s))) return rc;
-    if ((rc = conv_bn_relu_train(c, c->layers[lu + 2], at(c, p.y1[lu + 1]), C, B, hs[i], ws[i], at(c, p.z[lu + 2]), feat, C, sums, s))) return rc;
+    if ((rc = conv_bn_relu_train(c, c->layers[lu + 1], cat, 2 * C, B, hs[i], ws[i], at(c, p.z[lu + 1]), at(c, p.y1[lu + 1]), C, sums, red, s))) return rc;
+    if ((rc = conv_bn_relu_train(c, c->layers[lu + 2], at(c, p.y1[lu + 1]), C, B, hs[i], ws[i], at(c, p.z[lu + 2]), feat, C, sums, red, s))) return rc;
     c->t_feat[i] = feat;
     cur = feat, ld = C;
   }
@@ -248,6 +247,7 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
   w.ta = at(c, p.ta), w.tb = at(c, p.tb), w.dwp = at(c, p.dwp), w.dgp = at(c, p.dgp);
   w.flat = (float*)flat_grad_dev;
   w.sums = (double*)((char*)c->tws + p.sums);
+  w.red = (double*)((char*)c->tws + p.red);
   float* tc = at(c, p.tc);
   int rc;
 
@@ -256,9 +256,8 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
   const int64_t M0 = (int64_t)B * H * W;
   const int ldd = rup(c->ncls, 4), C0 = F.Cin;
   const float* dlog = (const float*)dlogits_dev;
-  HIPCHK(c, hipMemsetAsync(w.sums, 0, sizeof(double) * ldd, s));
-  HIPCHK(c, launch_colsum(dlog, ldd, M0, ldd, w.sums, s));
-  HIPCHK(c, launch_d2f(w.sums, w.flat + F.off_b, c->ncls, s));
+  HIPCHK(c, launch_colsum(dlog, ldd, M0, ldd, w.red, (float*)w.sums, s));   // padded to ldd columns, then trimmed
+  HIPCHK(c, hipMemcpyAsync(w.flat + F.off_b, w.sums, sizeof(float) * c->ncls, hipMemcpyDeviceToDevice, s));
   {
     WgradDesc g;
     memset(&g, 0, sizeof g);
@@ -288,9 +287,7 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
     const int64_t Mi = (int64_t)B * hs[i] * ws[i];
     if (2 * hs[i + 1] != hs[i] || 2 * ws[i + 1] != ws[i])  // F.pad backward (unet_decoder.py:46-47) drops the pad row/col
       HIPCHK(c, launch_zero_pad_region(dcat, 2 * C, C, C, B, hs[i], ws[i], 2 * hs[i + 1], 2 * ws[i + 1], s));
-    HIPCHK(c, hipMemsetAsync(w.sums, 0, sizeof(double) * C, s));
-    HIPCHK(c, launch_colsum(dcat + C, 2 * C, Mi, C, w.sums, s));
-    HIPCHK(c, launch_d2f(w.sums, w.flat + U.off_b, C, s));
+    HIPCHK(c, launch_colsum(dcat + C, 2 * C, Mi, C, w.red, w.flat + U.off_b, s));
     const int Kt = 4 * C, Kpt = rup(Kt, 32);
     {
       WgradDesc g;

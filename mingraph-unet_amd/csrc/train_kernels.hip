@@ -18,98 +18,153 @@ static inline int nblk(int64_t work, int threads, int cap = 256 * 8) {
 // ------------------------------------------------------------------------------------------------
 // Per-channel reductions over the M pixels of an NHWC tensor.  Thread (q = t % (C/4), pl = t / (C/4))
 // accumulates float4 channel quads over rows pl, pl+npl, ... of the block's slab in fp32, the block
-// combines through LDS and adds ONE double per channel per block (global_atomic_add_f64).
+// combines through LDS and adds ONE double per channel into slot (blockIdx % RED_SLOTS) of a slotted
+// accumulator [RED_SLOTS][2*C] (same-line double atomics serialise at ~12 ns each -- MI355X_MICROARCH.md
+// "fanin" -- so the adds are spread over 64 x 2C addresses); slot_reduce_kernel then folds the slots.
 //   mode 0: acc0 = sum z,               acc1 = sum z*z                    (BatchNorm batch statistics)
 //   mode 1: g = dy * (y > 0); xh = (z - mean) * invstd;  acc0 = sum g, acc1 = sum g*xh   (BN backward)
 //   mode 2: acc0 = sum z (column sums: bias gradients)
+//   mode 3: BN backward apply: dz = gamma*invstd*(g - sum_g/M - xh*sum_gx/M) written to `dz`, acc0 = sum dz
 // ------------------------------------------------------------------------------------------------
+constexpr int RED_SLOTS = 64;
+
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ dy,
                                                           int lddy, const float* __restrict__ y, int ldy,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                          int64_t M, int C, int rows_per_block, double* __restrict__ out0,
-                                                          double* __restrict__ out1) {
+                                                          const float* __restrict__ gamma, const double* __restrict__ sums,
+                                                          float* __restrict__ dz, int64_t M, int C, int rows_per_block,
+                                                          double* __restrict__ slots) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2][npl][C]
+  constexpr bool TWO = (MODE == 0 || MODE == 1);
   const int q = C >> 2, npl = 256 / q, t = threadIdx.x;
   const int cq = t % q, pl = t / q;
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r_end = min(M, r_begin + rows_per_block);
   if (pl < npl) {
-    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
-    if (MODE == 1) {
-      mu = *reinterpret_cast<const f32x4*>(mean + cq * 4);
-      is = *reinterpret_cast<const f32x4*>(invstd + cq * 4);
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f}, k0 = mu, k1 = mu, k2 = mu;
+    if (MODE == 1 || MODE == 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mu[j] = mean[cq * 4 + j];
+        is[j] = invstd[cq * 4 + j];
+      }
+    }
+    if (MODE == 3) {
+      const float invM = (float)(1.0 / (double)M);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        k0[j] = gamma[cq * 4 + j] * is[j];
+        k1[j] = (float)sums[cq * 4 + j] * invM;        // sum_g / M
+        k2[j] = (float)sums[C + cq * 4 + j] * invM;    // sum_gx / M
+      }
     }
     for (int64_t r = r_begin + pl; r < r_end; r += npl) {
       const f32x4 zv = *reinterpret_cast<const f32x4*>(z + r * ldz + cq * 4);
       if (MODE == 0) {
         a0 += zv;
         a1 += zv * zv;
-      } else if (MODE == 1) {
+      } else if (MODE == 1 || MODE == 3) {
         const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + r * lddy + cq * 4);
         const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + cq * 4);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float g = yv[j] > 0.f ? dv[j] : 0.f;
-          a0[j] += g;
-          a1[j] += g * ((zv[j] - mu[j]) * is[j]);
+          const float xh = (zv[j] - mu[j]) * is[j];
+          if (MODE == 1) {
+            a0[j] += g;
+            a1[j] += g * xh;
+          } else {
+            o[j] = k0[j] * (g - k1[j] - xh * k2[j]);
+            a0[j] += o[j];
+          }
         }
+        if (MODE == 3) *reinterpret_cast<f32x4*>(dz + r * C + cq * 4) = o;
       } else {
         a0 += zv;
       }
     }
     *reinterpret_cast<f32x4*>(red + pl * C + cq * 4) = a0;
-    if (MODE != 2) *reinterpret_cast<f32x4*>(red + (npl + pl) * C + cq * 4) = a1;
+    if (TWO) *reinterpret_cast<f32x4*>(red + (npl + pl) * C + cq * 4) = a1;
   }
   __syncthreads();
-  if (t < C) {
+  double* slot = slots + (size_t)(blockIdx.x % RED_SLOTS) * 2 * C;
+  for (int c = t; c < C; c += 256) {
     double s0 = 0.0, s1 = 0.0;
     for (int i = 0; i < npl; ++i) {
-      s0 += (double)red[i * C + t];
-      if (MODE != 2) s1 += (double)red[(npl + i) * C + t];
+      s0 += (double)red[i * C + c];
+      if (TWO) s1 += (double)red[(npl + i) * C + c];
     }
-    atomicAdd(out0 + t, s0);
-    if (MODE != 2) atomicAdd(out1 + t, s1);
+    atomicAdd(slot + c, s0);
+    if (TWO) atomicAdd(slot + C + c, s1);
   }
 }
 
-static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const float* dy, int lddy, const float* y, int ldy,
-                                     const float* mean, const float* invstd, int64_t M, int C, double* out0, double* out1,
-                                     hipStream_t s) {
-  if ((C & 3) || C < 4 || C > 1024 || (ldz & 3)) return hipErrorInvalidValue;
-  if (C > 256) {  // process 256-channel slabs (npl >= 1 requires C/4 <= 256; keep LDS rows short)
-    for (int c0 = 0; c0 < C; c0 += 256) {
-      const int cc = min(256, C - c0);
-      hipError_t e = launch_chan_reduce(mode, z + c0, ldz, dy ? dy + c0 : nullptr, lddy, y ? y + c0 : nullptr, ldy,
-                                        mean ? mean + c0 : nullptr, invstd ? invstd + c0 : nullptr, M, cc, out0 + c0,
-                                        out1 ? out1 + c0 : nullptr, s);
-      if (e != hipSuccess) return e;
-    }
-    return hipSuccess;
+// outd[j] = sum over slots (j < n, slot pitch = pitch); optional fp32 copies: outf0[j] for j < n0, outf1[j-n0] beyond
+__global__ void slot_reduce_kernel(const double* __restrict__ slots, int n, int pitch, double* __restrict__ outd,
+                                   float* __restrict__ outf0, int n0, float* __restrict__ outf1) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < RED_SLOTS; ++k) s += slots[(size_t)k * pitch + j];
+  if (outd) outd[j] = s;
+  if (j < n0) {
+    if (outf0) outf0[j] = (float)s;
+  } else if (outf1) {
+    outf1[j - n0] = (float)s;
   }
+}
+
+size_t chan_reduce_work_bytes(int Cmax) { return (size_t)RED_SLOTS * 2 * Cmax * sizeof(double); }
+
+// work: chan_reduce_work_bytes(C) of scratch.  Results: outd[0..n) doubles (n = 2C for modes 0/1, C for 2/3).
+static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const float* dy, int lddy, const float* y, int ldy,
+                                     const float* mean, const float* invstd, const float* gamma, const double* sums,
+                                     float* dz, int64_t M, int C, double* work, double* outd, float* outf0, int n0,
+                                     float* outf1, hipStream_t s) {
+  if ((C & 3) || C < 4 || C > 1024 || (ldz & 3) || M < 1) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(work, 0, chan_reduce_work_bytes(C), s);
+  if (e != hipSuccess) return e;
+  int64_t blocks = (M + 63) / 64;
+  if (blocks > 4096) blocks = 4096;
+  const int rows = (int)((M + blocks - 1) / blocks);
+  blocks = (M + rows - 1) / rows;
   const int npl = 256 / (C >> 2);
-  int rows = 2048;
-  int blocks = (int)((M + rows - 1) / rows);
-  if (blocks > 2048) { blocks = 2048; rows = (int)((M + blocks - 1) / blocks); }
-  blocks = (int)((M + rows - 1) / rows);
   const size_t lds = (size_t)2 * npl * C * sizeof(float);
-  if (mode == 0) hipLaunchKernelGGL(chan_reduce_kernel<0>, dim3(blocks), dim3(256), lds, s, z, ldz, dy, lddy, y, ldy, mean, invstd, M, C, rows, out0, out1);
-  else if (mode == 1) hipLaunchKernelGGL(chan_reduce_kernel<1>, dim3(blocks), dim3(256), lds, s, z, ldz, dy, lddy, y, ldy, mean, invstd, M, C, rows, out0, out1);
-  else hipLaunchKernelGGL(chan_reduce_kernel<2>, dim3(blocks), dim3(256), lds, s, z, ldz, dy, lddy, y, ldy, mean, invstd, M, C, rows, out0, out1);
+  dim3 g((unsigned)blocks), b(256);
+#define MGU_CR(MODE) hipLaunchKernelGGL(chan_reduce_kernel<MODE>, g, b, lds, s, z, ldz, dy, lddy, y, ldy, mean, invstd, gamma, sums, dz, M, C, rows, work)
+  if (mode == 0) MGU_CR(0);
+  else if (mode == 1) MGU_CR(1);
+  else if (mode == 2) MGU_CR(2);
+  else MGU_CR(3);
+#undef MGU_CR
+  const int n = (mode == 0 || mode == 1) ? 2 * C : C;
+  hipLaunchKernelGGL(slot_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, work, n, 2 * C, outd, outf0, n0, outf1);
   return hipGetLastError();
 }
 
-hipError_t launch_bn_stats(const float* z, int ldz, int64_t M, int C, double* sum, double* sumsq, hipStream_t s) {
-  return launch_chan_reduce(0, z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, sum, sumsq, s);
+hipError_t launch_bn_stats(const float* z, int ldz, int64_t M, int C, double* work, double* sums, hipStream_t s) {
+  return launch_chan_reduce(0, z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, work, sums,
+                            nullptr, 0, nullptr, s);
 }
+// sums[0..C) = sum g (= dbeta), sums[C..2C) = sum g*xhat (= dgamma); fp32 copies go straight to the flat gradient
 hipError_t launch_bn_bwd_reduce(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz,
-                                const float* mean, const float* invstd, int64_t M, int C, double* sum_g, double* sum_gx,
-                                hipStream_t s) {
-  return launch_chan_reduce(1, z, ldz, dy, lddy, y, ldy, mean, invstd, M, C, sum_g, sum_gx, s);
+                                const float* mean, const float* invstd, int64_t M, int C, double* work, double* sums,
+                                float* dbeta, float* dgamma, hipStream_t s) {
+  return launch_chan_reduce(1, z, ldz, dy, lddy, y, ldy, mean, invstd, nullptr, nullptr, nullptr, M, C, work, sums, dbeta, C,
+                            dgamma, s);
 }
-hipError_t launch_colsum(const float* z, int ldz, int64_t M, int C, double* sum, hipStream_t s) {
-  return launch_chan_reduce(2, z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, M, C, sum, nullptr, s);
+// dz (dense, pitch C) and its column sum (the conv bias gradient) in one pass
+hipError_t launch_bn_bwd_apply(const float* dy, int lddy, const float* y, int ldy, const float* z, const float* mean,
+                               const float* invstd, const float* gamma, const double* sums, int64_t M, int C, float* dz,
+                               double* work, float* dbias, hipStream_t s) {
+  return launch_chan_reduce(3, z, C, dy, lddy, y, ldy, mean, invstd, gamma, sums, dz, M, C, work, nullptr, dbias, C, nullptr, s);
+}
+hipError_t launch_colsum(const float* z, int ldz, int64_t M, int C, double* work, float* out, hipStream_t s) {
+  return launch_chan_reduce(2, z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, work, nullptr,
+                            out, C, nullptr, s);
 }
 
 // ---- BatchNorm2d training forward, finalize (unet_encoder.py:12-13: eps 1e-5, momentum 0.1) -------------
@@ -165,57 +220,6 @@ __global__ void bn_apply_relu_kernel(const float* __restrict__ z, const float* _
 hipError_t launch_bn_apply_relu(const float* z, const float* scale, const float* shift, float* y, int ldy, int64_t M, int C,
                                 hipStream_t s) {
   hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(nblk(M * (C >> 2), 256)), dim3(256), 0, s, z, scale, shift, y, ldy, M, C);
-  return hipGetLastError();
-}
-
-// ---- BN backward apply: dz = gamma*invstd * (g - sum_g/M - xh * sum_gx/M), g = dy*(y>0) -------------------
-// also emits dgamma = sum_gx, dbeta = sum_g (fp32) when block 0 runs.
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
-                                    const float* __restrict__ z, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const double* __restrict__ sum_g, const double* __restrict__ sum_gx, int64_t M, int C,
-                                    float* __restrict__ dz, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int q = C >> 2;
-  const int64_t total = M * q;
-  const float invM = (float)(1.0 / (double)M);
-  if (blockIdx.x == 0)
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      dgamma[c] = (float)sum_gx[c];
-      dbeta[c] = (float)sum_g[c];
-    }
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / q;
-    const int c0 = (int)(i - r * q) * 4;
-    const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + r * lddy + c0);
-    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + c0);
-    const f32x4 zv = *reinterpret_cast<const f32x4*>(z + r * C + c0);
-    f32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = c0 + j;
-      const float g = yv[j] > 0.f ? dv[j] : 0.f;
-      const float xh = (zv[j] - mean[c]) * invstd[c];
-      o[j] = gamma[c] * invstd[c] * (g - (float)sum_g[c] * invM - xh * ((float)sum_gx[c] * invM));
-    }
-    *reinterpret_cast<f32x4*>(dz + r * C + c0) = o;
-  }
-}
-
-hipError_t launch_bn_bwd_apply(const float* dy, int lddy, const float* y, int ldy, const float* z, const float* mean,
-                               const float* invstd, const float* gamma, const double* sum_g, const double* sum_gx,
-                               int64_t M, int C, float* dz, float* dgamma, float* dbeta, hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk(M * (C >> 2), 256)), dim3(256), 0, s, dy, lddy, y, ldy, z, mean, invstd,
-                     gamma, sum_g, sum_gx, M, C, dz, dgamma, dbeta);
-  return hipGetLastError();
-}
-
-// ---- double -> float copy (bias gradients from column sums) --------------------------------------------
-__global__ void d2f_kernel(const double* __restrict__ in, float* __restrict__ out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (float)in[i];
-}
-hipError_t launch_d2f(const double* in, float* out, int n, hipStream_t s) {
-  hipLaunchKernelGGL(d2f_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n);
   return hipGetLastError();
 }
 
