@@ -69,6 +69,14 @@ def cpu_baseline(batch, H, W, iters):
                       f"({dt:.2f} s/iter), torch {torch.__version__} CPU"}
 
 
+def max_over_ranks(dt, dist, dev):
+    if dist is None:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def bench_train(a, world, rank, local_rank, dev, dist):
     """BASELINE configs[4]: training step, batch 32 over 8 GPUs = 4 images/GPU (weak scaling), fwd+bwd+Adam,
     mean all-reduce of the flat fp32 gradient over RCCL (DDP semantics).  Mpix/s = images*H*W per step time."""
@@ -86,8 +94,9 @@ def bench_train(a, world, rank, local_rank, dev, dist):
     y = torch.randint(0, 2, (B, H, W), device=dev, generator=gen)
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize(dev)
 
     for _ in range(a.warmup):
@@ -99,10 +108,7 @@ def bench_train(a, world, rank, local_rank, dev, dist):
     barrier()
     dt = time.perf_counter() - t0
     assert bool(torch.isfinite(loss).all())
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt, dist, dev)
     if rank == 0:
         flops = 3.0 * model.flops(B, H, W)  # bwd = dgrad + wgrad ~ 2x fwd
         line = {"metric": "segmented Mpix/sec, MinGraph-UNet train step (fwd + CE + bwd + grad all-reduce + Adam), 512x512",
@@ -142,13 +148,21 @@ def main():
             sys.exit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus}` (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    # MGU_BENCH_REHEARSAL=1: several ranks share GPU 0 over gloo -- only to rehearse the torchrun plumbing on a
+    # one-GPU box (never a measurement; RCCL needs one device per rank)
+    rehearsal = os.environ.get("MGU_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import mgunet
     import mgunet_oracle as O
@@ -167,8 +181,9 @@ def main():
     x = torch.randn((B, 3, H, W), device=dev, generator=gen)           # synthetic batch, resident in HBM
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize(dev)
 
     with torch.no_grad():
@@ -184,10 +199,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
     assert bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[3]).all())
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt, dist, dev)
     ms_step = dt / a.steps * 1e3
     mpix = world * B * H * W * a.steps / dt / 1e6
 

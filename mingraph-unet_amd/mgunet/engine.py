@@ -101,7 +101,12 @@ def allreduce_mean_(flat: torch.Tensor, group=None) -> float:
     world = dist.get_world_size(group)
     if world == 1:
         return 1.0
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":   # rehearsal only: gloo has no device path here
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
 
 
