@@ -35,6 +35,10 @@ struct IgemmDesc {
   int out_mode;
   int ct_cout;     // out_mode 1: Cout (N == 4*Cout)
   int Hout, Wout;  // out_mode 1: output grid (>= 2H, 2W)
+  // optional split epilogue (out_mode 0): columns n >= split_n go to out2[m*ld2 + (n - split_n)] (0 = off)
+  int split_n;
+  float* out2;
+  int ld2;
 };
 
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
@@ -95,11 +99,12 @@ hipError_t launch_bias_tile(const float* bias, float* shift, int C, int reps, hi
 hipError_t launch_argmax(const float* logits, int64_t npix, int C, int64_t* pred, hipStream_t s);
 
 // gat.hip
-hipError_t launch_gat_st(const float* Wh, const float* a, float* st, int N, int heads, int Fh, hipStream_t s);
-hipError_t launch_gat_edge_max(const float* st, const int32_t* rowptr, const int32_t* col, const int32_t* graph_ptr,
-                               int num_graphs, int N, int heads, float alpha, unsigned* gmax_enc, hipStream_t s);
-hipError_t launch_gat_aggregate(const float* Wh, const float* st, const int32_t* rowptr, const int32_t* col,
-                                const int32_t* graph_ptr, int num_graphs, const unsigned* gmax_enc, int N, int heads,
-                                int Fh, int concat, float alpha, float* out, hipStream_t s);
+hipError_t launch_gat_wa_rows(const float* W, const float* a, float* panel, int heads, int Fh, int Fin, int Kp, hipStream_t s);
+hipError_t launch_gat_node_graph(const int32_t* gp, int G, int nodes_per_graph, int N, int32_t* node_graph, hipStream_t s);
+hipError_t launch_gat_edge_max(const float* st, const int32_t* rowptr, const int32_t* col, const int32_t* node_graph, int N,
+                               int heads, float alpha, unsigned* gmax_enc, hipStream_t s);
+hipError_t launch_gat_aggregate(const float* wh, int P, const float* st, const int32_t* rowptr, const int32_t* col,
+                                const int32_t* node_graph, const unsigned* gmax_enc, int N, int heads, int Fh, int concat,
+                                float alpha, float* out, hipStream_t s);
 
 }  // namespace mgu

@@ -8,11 +8,11 @@
 // coalesced wavefront load.  The softmax is the reference's literal form: exp(e - GLOBAL max over the
 // graph's edges) (:86), divided by (segment sum + 1e-10) (:96) -- not a per-target stabilised softmax.
 //
-//   gat_st        : s,t per node and head                         (reads Wh once)
+//   (igemm)       : Whp = X [W | W^T a_src | W^T a_tgt]^T : node table rows [Wh (H*F') | s (H) | t (H)]
 //   gat_edge_max  : per (graph, head) max_e                        (CSR + s,t only; order-encoded atomicMax)
 //   gat_aggregate : CSR-by-target neighbour gather -> weighted sum -> /(D+1e-10) -> ELU -> concat | head-mean
-//                   one wavefront per target row; neighbour ids are fetched 64 at a time (one per
-//                   lane) and broadcast with v_readlane, the head-mean is staged through LDS.
+//                   one wavefront per 4-row CSR segment, 8 row gathers in flight per lane, segmented
+//                   register accumulation, head-mean staged through LDS, XCD-aware workgroup order.
 #include "common.h"
 
 namespace mgu {
@@ -37,56 +37,70 @@ __device__ __forceinline__ int graph_of(const int32_t* __restrict__ gp, int G, i
   return lo;
 }
 
-// ---- s_i[h] = a[h][:Fh] . Wh_i[h], t_i[h] = a[h][Fh:] . Wh_i[h]  (graph_attention.py:61-64, split) ----
+// ---- node -> graph id table (one coalesced kernel instead of a dependent binary search per wavefront) ----
+__global__ void gat_node_graph_kernel(const int32_t* __restrict__ gp, int G, int nodes_per_graph, int N,
+                                      int32_t* __restrict__ node_graph) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < N) node_graph[j] = nodes_per_graph > 0 ? min(j / nodes_per_graph, G - 1) : graph_of(gp, G, j);
+}
+
+hipError_t launch_gat_node_graph(const int32_t* gp, int G, int nodes_per_graph, int N, int32_t* node_graph, hipStream_t s) {
+  hipLaunchKernelGGL(gat_node_graph_kernel, dim3((N + 255) / 256), dim3(256), 0, s, gp, G, nodes_per_graph, N, node_graph);
+  return hipGetLastError();
+}
+
+// ---- extra panel rows so the linear GEMM also emits s and t -------------------------------------------
+// s_i[h] = a[h][:Fh] . (W_h x_i) = (W_h^T a[h][:Fh]) . x_i: rows HF+h (s) and HF+H+h (t) of the weight panel
+// hold W_h^T a_src / W_h^T a_tgt, so ONE GEMM emits the node table Wh (N, HF) and, through the split-column
+// epilogue, the compact attention-scalar table st (N, 2H) = [s | t] (graph_attention.py:53,57-64).
 constexpr int GAT_MAX_HF = 1024;
 
-__global__ __launch_bounds__(256) void gat_st_kernel(const float* __restrict__ Wh, const float* __restrict__ a,
-                                                     float* __restrict__ st, int N, int heads, int Fh) {
-  __shared__ float part[4][2][GAT_MAX_HF / 4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int node = blockIdx.x * 4 + wave;
-  const int HF = heads * Fh, nq = HF >> 2, qh = Fh >> 2;
-  if (node < N) {
-    for (int c = lane; c < nq; c += 64) {
-      const int h = c / qh, f = (c - h * qh) * 4;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(Wh + (size_t)node * HF + c * 4);
-      const f32x4 as = *reinterpret_cast<const f32x4*>(a + h * 2 * Fh + f);
-      const f32x4 at = *reinterpret_cast<const f32x4*>(a + h * 2 * Fh + Fh + f);
-      part[wave][0][c] = v[0] * as[0] + v[1] * as[1] + v[2] * as[2] + v[3] * as[3];
-      part[wave][1][c] = v[0] * at[0] + v[1] * at[1] + v[2] * at[2] + v[3] * at[3];
-    }
-  }
-  __syncthreads();
-  if (node < N && lane < 2 * heads) {
-    const int which = lane / heads, h = lane - which * heads;
+__global__ __launch_bounds__(256) void gat_wa_rows_kernel(const float* __restrict__ W, const float* __restrict__ a,
+                                                          float* __restrict__ panel, int heads, int Fh, int Fin, int Kp) {
+  // one workgroup per output row r = (s|t, head); thread (fl, k): partial dot over f = fl, fl+nfl, ...; LDS fold
+  __shared__ float red[256];
+  const int HF = heads * Fh, r = blockIdx.x;
+  const int which = r / heads, h = r - which * heads;
+  const int kw = min(Fin, 256), nfl = 256 / kw;
+  const int t = threadIdx.x, kl = t % kw, fl = t / kw;
+  for (int k0 = 0; k0 < Fin; k0 += kw) {
+    const int k = k0 + kl;
     float sum = 0.f;
-    for (int c = h * qh; c < (h + 1) * qh; ++c) sum += part[wave][which][c];
-    st[(size_t)which * N * heads + (size_t)node * heads + h] = sum;
+    if (fl < nfl && k < Fin)
+      for (int f = fl; f < Fh; f += nfl) sum += a[h * 2 * Fh + which * Fh + f] * W[(size_t)(h * Fh + f) * Fin + k];
+    red[t] = sum;
+    __syncthreads();
+    if (fl == 0 && k < Fin) {
+      float tot = 0.f;
+      for (int i = 0; i < nfl; ++i) tot += red[i * kw + kl];
+      panel[(size_t)(HF + r) * Kp + k] = tot;
+    }
+    __syncthreads();
   }
 }
 
-hipError_t launch_gat_st(const float* Wh, const float* a, float* st, int N, int heads, int Fh, hipStream_t s) {
-  if (heads * Fh > GAT_MAX_HF || (Fh & 3) || heads > 32) return hipErrorInvalidValue;
-  if (N == 0) return hipSuccess;
-  hipLaunchKernelGGL(gat_st_kernel, dim3((N + 3) / 4), dim3(256), 0, s, Wh, a, st, N, heads, Fh);
+hipError_t launch_gat_wa_rows(const float* W, const float* a, float* panel, int heads, int Fh, int Fin, int Kp, hipStream_t s) {
+  hipLaunchKernelGGL(gat_wa_rows_kernel, dim3(2 * heads), dim3(256), 0, s, W, a, panel, heads, Fh, Fin, Kp);
   return hipGetLastError();
 }
 
 // ---- per (graph, head): max over edges of LeakyReLU(s_src + t_tgt)  (torch.max(e), :86) -----------
-__global__ __launch_bounds__(256) void gat_edge_max_kernel(const float* __restrict__ st, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(256) void gat_edge_max_kernel(const float* __restrict__ st,
+                                                           const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col,
-                                                           const int32_t* __restrict__ gp, int G, int N, int heads,
+                                                           const int32_t* __restrict__ node_graph, int N, int heads,
                                                            float alpha, unsigned* __restrict__ gmax) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int wave_first = j - lane;
   if (wave_first >= N) return;  // wave-uniform
   const bool valid = j < N;
-  const int g = graph_of(gp, G, valid ? j : wave_first);
+  const int g = node_graph ? node_graph[valid ? j : wave_first] : 0;
   const int g0 = __builtin_amdgcn_readfirstlane(g);
   const bool uniform = __all(g == g0);
+  const int P = 2 * heads;
   const float* s = st;
-  const float* t = st + (size_t)N * heads;
+  const float* t = st + heads;
   int start = 0, end = 0;
   if (valid) {
     start = rowptr[j];
@@ -94,10 +108,10 @@ __global__ __launch_bounds__(256) void gat_edge_max_kernel(const float* __restri
   }
   for (int h = 0; h < heads; ++h) {
     float m = -INFINITY;
-    for (int k = start; k < end; ++k) m = fmaxf(m, s[(size_t)col[k] * heads + h]);
+    for (int k = start; k < end; ++k) m = fmaxf(m, s[(size_t)col[k] * P + h]);
     float e = -INFINITY;
     if (end > start) {
-      e = m + t[(size_t)j * heads + h];
+      e = m + t[(size_t)j * P + h];
       e = e > 0.f ? e : alpha * e;  // LeakyReLU is monotone: max commutes with it
     }
     if (uniform) {
@@ -110,101 +124,147 @@ __global__ __launch_bounds__(256) void gat_edge_max_kernel(const float* __restri
   }
 }
 
-hipError_t launch_gat_edge_max(const float* st, const int32_t* rowptr, const int32_t* col, const int32_t* graph_ptr,
-                               int num_graphs, int N, int heads, float alpha, unsigned* gmax_enc, hipStream_t s) {
+hipError_t launch_gat_edge_max(const float* st, const int32_t* rowptr, const int32_t* col, const int32_t* node_graph, int N,
+                               int heads, float alpha, unsigned* gmax_enc, hipStream_t s) {
   if (N == 0) return hipSuccess;
-  hipLaunchKernelGGL(gat_edge_max_kernel, dim3((N + 255) / 256), dim3(256), 0, s, st, rowptr, col, graph_ptr,
-                     num_graphs, N, heads, alpha, gmax_enc);
+  hipLaunchKernelGGL(gat_edge_max_kernel, dim3((N + 255) / 256), dim3(256), 0, s, st, rowptr, col, node_graph, N, heads, alpha,
+                     gmax_enc);
   return hipGetLastError();
 }
 
 // ---- neighbour gather + attention-weighted aggregate + normalise + ELU + concat/mean --------------
+// One wavefront owns R consecutive target rows (a CSR segment of R rows).  The neighbour ids of the whole
+// segment are fetched with one coalesced load (one id per lane); source rows are then gathered EIGHT AT A
+// TIME (8 independent 16-byte-per-lane loads in flight per lane = 8 KiB per wave) before any of them is
+// consumed, and each edge is accumulated into the register accumulator of the row that owns it (segmented
+// reduction by a wave-uniform row index).  The head mean is staged through a per-wave LDS row.  Workgroup
+// ids are remapped so each XCD (private 4 MiB L2) works on a contiguous range of rows: neighbouring patch
+// rows (j +- 1, j +- npw) then hit the same L2 instead of being re-fetched by other XCDs.
 template <int NCH>
-__global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restrict__ Wh, const float* __restrict__ st,
+__global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restrict__ wh, int P, const float* __restrict__ st,
                                                             const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col,
-                                                            const int32_t* __restrict__ gp, int G,
+                                                            const int32_t* __restrict__ node_graph,
                                                             const unsigned* __restrict__ gmax, int N, int heads, int Fh,
                                                             int concat, float alpha, float* __restrict__ out) {
+  constexpr int R = 4;    // rows (one CSR segment) per wavefront
+  constexpr int EB = 8;   // row gathers in flight per lane
   __shared__ __attribute__((aligned(16))) float stage[4][NCH * 256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = blockIdx.x * 4 + wave;
-  if (j >= N) return;  // wave-uniform; no block-level barrier below
-  const int HF = heads * Fh, nq = HF >> 2, qh = Fh >> 2;
-  const int g = graph_of(gp, G, j);
-  const float* s = st;
-  const float* t = st + (size_t)N * heads;
-  const int start = rowptr[j], end = rowptr[j + 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // XCD-aware bijective remap of the workgroup id (blocks b, b+8, ... share an XCD)
+  const int nblk = gridDim.x, b = blockIdx.x;
+  const int xcd = b & 7, qn = nblk >> 3, rn = nblk & 7;
+  const int blk = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (b >> 3);
+  const int j0 = (blk * 4 + wave) * R;
+  if (j0 >= N) return;  // wave-uniform; no block-level barrier below
+  const int HF = heads * Fh, nq = HF >> 2, qh = Fh >> 2, H2 = 2 * heads;
+  const float inv_heads = 1.f / (float)heads;
+
+  // CSR segment of the R rows: lanes 0..R hold rowptr[j0 .. j0+R]; each row's neighbour ids sit one per lane
+  const int rpv = rowptr[min(j0 + min(lane, R), N)];
+  const int start = __builtin_amdgcn_readlane(rpv, 0);
+  const int ne = __builtin_amdgcn_readlane(rpv, R) - start;
+  const int seg_ids = (lane < ne) ? col[start + lane] : 0;   // whole segment when it has <= 64 edges (the usual case)
 
   int head[NCH];
-  float tj[NCH], gm[NCH], D[NCH];
-  f32x4 acc[NCH];
   bool on[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
     on[i] = c < nq;
     head[i] = on[i] ? c / qh : 0;
-    tj[i] = t[(size_t)j * heads + head[i]];
-    gm[i] = dec_ordered(gmax[g * heads + head[i]]);
-    D[i] = 0.f;
-    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int base = start; base < end; base += 64) {
-    const int mine = (base + lane < end) ? col[base + lane] : 0;
-    const int cnt = min(64, end - base);
-    for (int e = 0; e < cnt; ++e) {
-      const int src = __builtin_amdgcn_readlane(mine, e);
+#pragma unroll 1
+  for (int r = 0; r < R; ++r) {
+    const int j = j0 + r;
+    if (j >= N) break;                         // wave-uniform
+    const int s0 = __builtin_amdgcn_readlane(rpv, r);
+    const int deg = __builtin_amdgcn_readlane(rpv, r + 1) - s0;
+    float tj[NCH], gm[NCH], D[NCH];
+    f32x4 acc[NCH];
+    const int g = node_graph ? node_graph[j] : 0;
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        if (on[i]) {
-          float ev = s[(size_t)src * heads + head[i]] + tj[i];
-          ev = ev > 0.f ? ev : alpha * ev;                       // LeakyReLU (:65)
-          const float x = expf(ev - gm[i]);                      // exp(e - max(e)) (:86)
-          const f32x4 v = *reinterpret_cast<const f32x4*>(Wh + (size_t)src * HF + (lane + 64 * i) * 4);
-          D[i] += x;                                             // scatter_add of exp_e (:90-91)
-          acc[i] += x * v;                                       // scatter_add of alpha*Wh_src (:104-112)
+    for (int i = 0; i < NCH; ++i) {
+      tj[i] = st[(size_t)j * H2 + heads + head[i]];
+      gm[i] = dec_ordered(gmax[g * heads + head[i]]);
+      D[i] = 0.f;
+      acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int base = 0; base < deg; base += 64) {
+      const bool in_seg = ne <= 64;            // wave-uniform: ids already in seg_ids at lane (s0 - start) + e
+      const int ids = in_seg ? seg_ids : ((base + lane < deg) ? col[s0 + base + lane] : 0);
+      const int lane0 = in_seg ? s0 - start : 0;
+      const int cnt = min(64, deg - base);
+#pragma unroll 1
+      for (int eb = 0; eb < cnt; eb += EB) {
+        f32x4 v[EB][NCH];
+        float sv[EB][NCH];
+        // NO branch around the gathers (a conditional load makes hipcc wait per element): slots past the end of the
+        // row re-read its last neighbour and get weight 0.
+#pragma unroll
+        for (int k = 0; k < EB; ++k) {
+          const int src = __builtin_amdgcn_readlane(ids, lane0 + min(eb + k, cnt - 1));
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) {
+            const int c = on[i] ? lane + 64 * i : 0;
+            v[k][i] = *reinterpret_cast<const f32x4*>(wh + (size_t)src * P + c * 4);
+            sv[k][i] = st[(size_t)src * H2 + head[i]];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < EB; ++k) {
+          const bool live = eb + k < cnt;        // wave-uniform
+#pragma unroll
+          for (int i = 0; i < NCH; ++i) {
+            float ev = sv[k][i] + tj[i];
+            ev = ev > 0.f ? ev : alpha * ev;                        // LeakyReLU (:65)
+            const float x = (live && on[i]) ? __expf(ev - gm[i]) : 0.f;   // exp(e - max(e)) (:86)
+            D[i] += x;                                              // scatter_add of exp_e (:90-91)
+            acc[i] += x * v[k][i];                                  // scatter_add of alpha*Wh_src (:104-112)
+          }
         }
       }
     }
-  }
-
+    // /(D + 1e-10) (:96), ELU (:118), concat (:155) or head mean (:158)
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    if (on[i]) {
-      const float inv = 1.f / (D[i] + 1e-10f);                   // (:96)
-      f32x4 o = acc[i] * inv;
+    for (int i = 0; i < NCH; ++i) {
+      if (on[i]) {
+        const float inv = __frcp_rn(D[i] + 1e-10f);
+        f32x4 o = acc[i] * inv;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : expm1f(o[q]);  // ELU (:118)
-      if (concat)
-        *reinterpret_cast<f32x4*>(out + (size_t)j * HF + (lane + 64 * i) * 4) = o;   // torch.cat (:155)
-      else
-        *reinterpret_cast<f32x4*>(&stage[wave][(lane + 64 * i) * 4]) = o;
+        for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : (__expf(o[q]) - 1.f);
+        if (concat)
+          *reinterpret_cast<f32x4*>(out + (size_t)j * HF + (lane + 64 * i) * 4) = o;
+        else
+          *reinterpret_cast<f32x4*>(&stage[wave][(lane + 64 * i) * 4]) = o;
+      }
     }
-  }
-  if (!concat) {
-    // head mean (:158): lanes 0..Fh/4-1 each own one float4 of the output row.  Only this wave touches
-    // stage[wave], and a wavefront's LDS ops complete in order, so no barrier is required.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    for (int c = lane; c < qh; c += 64) {
-      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-      for (int h = 0; h < heads; ++h) sum += *reinterpret_cast<const f32x4*>(&stage[wave][h * Fh + c * 4]);
-      *reinterpret_cast<f32x4*>(out + (size_t)j * Fh + c * 4) = sum / (float)heads;
+    if (!concat) {
+      // only this wave touches stage[wave]; a wavefront's LDS operations complete in order
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      for (int c = lane; c < qh; c += 64) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < heads; ++h) sum += *reinterpret_cast<const f32x4*>(&stage[wave][h * Fh + c * 4]);
+        *reinterpret_cast<f32x4*>(out + (size_t)j * Fh + c * 4) = sum * inv_heads;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
 }
 
-hipError_t launch_gat_aggregate(const float* Wh, const float* st, const int32_t* rowptr, const int32_t* col,
-                                const int32_t* graph_ptr, int num_graphs, const unsigned* gmax_enc, int N, int heads,
-                                int Fh, int concat, float alpha, float* out, hipStream_t s) {
+hipError_t launch_gat_aggregate(const float* wh, int P, const float* st, const int32_t* rowptr, const int32_t* col,
+                                const int32_t* node_graph, const unsigned* gmax_enc, int N, int heads, int Fh, int concat,
+                                float alpha, float* out, hipStream_t s) {
   const int HF = heads * Fh;
-  if (HF > GAT_MAX_HF || (Fh & 3)) return hipErrorInvalidValue;
+  if (HF > GAT_MAX_HF || (Fh & 3) || (P & 3)) return hipErrorInvalidValue;
   if (N == 0) return hipSuccess;
-  dim3 grid((N + 3) / 4), block(256);
-#define MGU_AGG(NCH)                                                                                             \
-  hipLaunchKernelGGL(gat_aggregate_kernel<NCH>, grid, block, 0, s, Wh, st, rowptr, col, graph_ptr, num_graphs,   \
-                     gmax_enc, N, heads, Fh, concat, alpha, out)
+  dim3 block(256);
+#define MGU_AGG(NCH)                                                                                              \
+  hipLaunchKernelGGL(gat_aggregate_kernel<NCH>, dim3((N + 15) / 16), block, 0, s, wh, P, st, rowptr, col, node_graph, gmax_enc, \
+                     N, heads, Fh, concat, alpha, out)
   if (HF <= 256) MGU_AGG(1);
   else if (HF <= 512) MGU_AGG(2);
   else MGU_AGG(4);

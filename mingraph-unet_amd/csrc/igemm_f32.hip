@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
           float v = acc[mi][ni][r] * sc + sh;
           if (d.relu) v = fmaxf(v, 0.f);
           if (OUTMODE == 0) {
-            d.out[(size_t)m * d.ldout + d.coff + n] = v;
+            if (d.split_n > 0 && n >= d.split_n) d.out2[(size_t)m * d.ld2 + (n - d.split_n)] = v;
+            else d.out[(size_t)m * d.ldout + d.coff + n] = v;
           } else {
             const int img = m / HW;
             const int rem = m - img * HW;

@@ -514,43 +514,51 @@ int mgu_gat_layer_forward(mgu_ctx* c, const void* X_dev, int N, int Fin, const i
   if (num_graphs < 1) num_graphs = 1;
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)hip_stream;
-  // scratch: Wh (N,HF) | st (2,N,heads) | packed W panel (HFp, Kp) | gmax (G,heads)
-  const int Kp = rup(Fin, 32), HFp = rup(HF, 128);
+  // scratch: Wh (N, HF) node table | st (N, 2H) attention scalars | packed panel (NPp, Kp) | gmax (G, heads)
+  const int Kp = rup(Fin, 32), NP = HF + 2 * heads, P = HF, NPp = rup(NP, 128);
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
     off += (bytes + 255) / 256 * 256;
     return o;
   };
-  const size_t o_wh = take((size_t)N * HF * 4), o_st = take((size_t)2 * N * heads * 4);
-  const size_t o_wp = take((size_t)HFp * Kp * 4), o_gm = take((size_t)num_graphs * heads * 4);
+  const size_t o_wh = take((size_t)N * P * 4), o_st = take((size_t)N * 2 * heads * 4);
+  const size_t o_wp = take((size_t)NPp * Kp * 4), o_gm = take((size_t)num_graphs * heads * 4);
+  const size_t o_ng = take((size_t)N * 4);
   int rc = ensure(c, &c->gws, &c->gws_bytes, off);
   if (rc) return rc;
   char* g = (char*)c->gws;
-  float* Wh = (float*)(g + o_wh);
+  float* Whp = (float*)(g + o_wh);
   float* st = (float*)(g + o_st);
   float* wp = (float*)(g + o_wp);
   unsigned* gmax = (unsigned*)(g + o_gm);
-  HIPCHK(c, hipMemsetAsync(wp, 0, (size_t)HFp * Kp * 4, s));
+  HIPCHK(c, hipMemsetAsync(wp, 0, (size_t)NPp * Kp * 4, s));
   HIPCHK(c, hipMemsetAsync(gmax, 0, (size_t)num_graphs * heads * 4, s));
-  // nn.Linear weight (F',Fin) stacked over heads is already the [N][K] panel; only pad K to 32
+  // nn.Linear weight (F',Fin) stacked over heads is already the [N][K] panel (K padded to 32); rows HF.. hold
+  // W^T a_src / W^T a_tgt so the same GEMM emits the attention scalars s, t (graph_attention.py:53,57-64)
   HIPCHK(c, launch_pack_conv_w((const float*)W_dev, wp, HF, Fin, Fin, 1, Kp, s));
+  HIPCHK(c, launch_gat_wa_rows((const float*)W_dev, (const float*)a_dev, wp, heads, Fout_head, Fin, Kp, s));
   IgemmDesc d;
   memset(&d, 0, sizeof d);
   d.in = (const float*)X_dev;
   d.w = wp;
-  d.out = Wh;
+  d.out = Whp;
   d.M = N, d.H = 1, d.W = N;
   d.Cp = Fin, d.ldin = Fin, d.KS = 1, d.K = Fin, d.Kp = Kp;
-  d.N = HF, d.ldout = HF;
+  d.N = NP, d.ldout = P;
+  d.split_n = HF, d.out2 = st, d.ld2 = 2 * heads;
   {
     ProfScope ps(c, s);
-    HIPCHK(c, launch_igemm_f32(d, s));  // h = W(X), graph_attention.py:53, all heads at once
+    HIPCHK(c, launch_igemm_f32(d, s));
   }
-  HIPCHK(c, launch_gat_st(Wh, (const float*)a_dev, st, N, heads, Fout_head, s));
-  HIPCHK(c, launch_gat_edge_max(st, rowptr_dev, col_dev, graph_ptr_dev, num_graphs, N, heads, alpha, gmax, s));
-  HIPCHK(c, launch_gat_aggregate(Wh, st, rowptr_dev, col_dev, graph_ptr_dev, num_graphs, gmax, N, heads, Fout_head,
-                                 concat, alpha, (float*)out_dev, s));
+  int32_t* node_graph = nullptr;  // node -> graph id (NULL: a single graph)
+  if (num_graphs > 1 && graph_ptr_dev) {
+    node_graph = (int32_t*)(g + o_ng);
+    HIPCHK(c, launch_gat_node_graph(graph_ptr_dev, num_graphs, 0, N, node_graph, s));
+  }
+  HIPCHK(c, launch_gat_edge_max(st, rowptr_dev, col_dev, node_graph, N, heads, alpha, gmax, s));
+  HIPCHK(c, launch_gat_aggregate(Whp, P, st, rowptr_dev, col_dev, node_graph, gmax, N, heads, Fout_head, concat, alpha,
+                                 (float*)out_dev, s));
   return MGU_OK;
 }
 

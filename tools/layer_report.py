@@ -4,7 +4,8 @@ import csv, glob, sys
 root = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 512
-rows = list(csv.DictReader(open(sorted(glob.glob(root + "/runc/*kernel_trace.csv"))[-1])))
+import os
+rows = list(csv.DictReader(open(max(glob.glob(root + "/runc/*kernel_trace.csv"), key=os.path.getmtime))))
 ig = [r for r in rows if "igemm" in r["Kernel_Name"] or "halo" in r["Kernel_Name"]]
 last = ig[-24:]
 def convf(h, cin, cout): return 2 * B * h * h * 9 * cin * cout
