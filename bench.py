@@ -224,9 +224,17 @@ def main():
             L.mgu_profile_enable(ctx.handle, 0)
         flops = unet.flops(B, H, W)
         ach = flops * nprof / (conv_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the same kernels from the committed PMC passes (rocprofv3 cannot run inside
+        # this process); only quoted when the workload is the one they were collected on
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tj) and (B, H, W) == (8, 512, 512):
+            t = json.load(open(tj))
+            traffic, traffic_src = round(t["hbm_bytes_per_launch"]), "profiles/r01_traffic.json (" + t["correction"].split(" (")[0] + ")"
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "kernel": "igemm_f32_kernel (all conv3x3/convT/1x1 launches of a step)",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                "traffic_source": traffic_src, "algorithmic_flop_per_launch": round(flops / max(launches // nprof, 1)),
+                "kernel": "conv3x3_halo_f32_kernel + igemm_f32_kernel (the 23 conv3x3/convT/1x1 launches of a step)",
                 "launches_per_step": launches // nprof, "kernel_ms_per_step": round(conv_ms / nprof, 4),
                 "unet_ms_per_step_with_events": round(tot_ms / nprof, 4), "gflop_per_step": round(flops / 1e9, 2)}
 
