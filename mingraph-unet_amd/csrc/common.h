@@ -43,6 +43,8 @@ struct IgemmDesc {
 
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
 void set_use_halo(bool on);
+void set_halo_max_ppb(int n);
+void set_halo_tps3(bool on);
 
 // wgrad_f32.hip:  Dw[n][k] += sum_m Z[m][n] * A(m,k)   (A = the forward kernels' im2col gather)
 struct WgradDesc {
@@ -96,6 +98,8 @@ hipError_t launch_pack_convt_w(const float* w_iohw, float* wp, int Cin, int Cout
 hipError_t launch_bn_fold(const float* bias, const float* gamma, const float* beta, const float* mean, const float* var,
                           float eps, float* scale, float* shift, int C, hipStream_t s);
 hipError_t launch_bias_tile(const float* bias, float* shift, int C, int reps, hipStream_t s);
+hipError_t launch_conv1x1_head(const float* in, int ldin, int C, const float* w, const float* bias, float* out, int ldout,
+                               int ncls, int64_t npix, hipStream_t s);
 hipError_t launch_argmax(const float* logits, int64_t npix, int C, int64_t* pred, hipStream_t s);
 
 // gat.hip

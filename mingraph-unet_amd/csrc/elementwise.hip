@@ -174,6 +174,54 @@ hipError_t launch_bias_tile(const float* bias, float* shift, int C, int reps, hi
   return hipGetLastError();
 }
 
+// ---- 1x1 convolution with a handful of output channels (the segmentation head, unet_decoder.py:117,143) ----
+// HBM-bound (0.9 FLOP/B): 8 lanes read one pixel's channels as coalesced float4, each lane accumulates its partial
+// dot products for up to 4 classes, an 8-lane shuffle tree folds them, lane 0 of the group stores.
+template <int NC>
+__global__ __launch_bounds__(256) void conv1x1_head_kernel(const float* __restrict__ in, int ldin, int C,
+                                                           const float* __restrict__ w /*[NC][C]*/,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int ldout, int64_t npix) {
+  const int lane8 = threadIdx.x & 7;
+  const int64_t stride = (int64_t)gridDim.x * 32;
+  for (int64_t p = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); p < npix; p += stride) {   // uniform trip count per 8-lane group
+    float acc[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) acc[k] = 0.f;
+    for (int c = lane8 * 4; c < C; c += 32) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(in + p * ldin + c);
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k * C + c);
+        acc[k] += v[0] * wv[0] + v[1] * wv[1] + v[2] * wv[2] + v[3] * wv[3];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      acc[k] += __shfl_xor(acc[k], 1);
+      acc[k] += __shfl_xor(acc[k], 2);
+      acc[k] += __shfl_xor(acc[k], 4);
+    }
+    if (lane8 == 0) {
+#pragma unroll
+      for (int k = 0; k < NC; ++k) out[p * ldout + k] = acc[k] + (bias ? bias[k] : 0.f);
+    }
+  }
+}
+
+hipError_t launch_conv1x1_head(const float* in, int ldin, int C, const float* w, const float* bias, float* out, int ldout,
+                               int ncls, int64_t npix, hipStream_t s) {
+  if ((C & 3) || (ldin & 3) || ncls < 1 || ncls > 4) return hipErrorInvalidValue;
+  const int blocks = nblocks(npix * 8, 256, 256 * 32);
+#define MGU_HEAD(NC) hipLaunchKernelGGL(conv1x1_head_kernel<NC>, dim3(blocks), dim3(256), 0, s, in, ldin, C, w, bias, out, ldout, npix)
+  if (ncls == 1) MGU_HEAD(1);
+  else if (ncls == 2) MGU_HEAD(2);
+  else if (ncls == 3) MGU_HEAD(3);
+  else MGU_HEAD(4);
+#undef MGU_HEAD
+  return hipGetLastError();
+}
+
 // ---- argmax over classes (first maximal index, like torch.argmax on distinct values) ---------------
 __global__ void argmax_kernel(const float* __restrict__ logits, int64_t npix, int C, int64_t* __restrict__ pred) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {

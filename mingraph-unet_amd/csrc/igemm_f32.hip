@@ -26,7 +26,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static bool g_use_halo = true;   // MGU_NO_HALO=1 forces the generic gather kernel (A/B comparisons)
+static bool g_halo_tps3 = true;   // MGU_HALO_TPS1=1: one tap per barrier on the N <= 32 tile too (A/B)
+void set_halo_tps3(bool on) { g_halo_tps3 = on; }
+static int g_halo_max_ppb = 16;  // MGU_HALO_PPB=n caps the patches a halo workgroup walks (1 = no persistence)
 void set_use_halo(bool on) { g_use_halo = on; }
+void set_halo_max_ppb(int n) { g_halo_max_ppb = n < 1 ? 1 : n; }
 
 constexpr int CK = 32;           // K elements per pipeline step
 constexpr int LDS_LD = CK + 4;   // LDS row pitch in floats (144 B, keeps 16-B alignment)
@@ -110,11 +114,14 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
       delta = (long)((tap >> 1) * d.Wout + (tap & 1)) * d.ldin + c;
     }
     const bool kvalid = k < d.K;
+    // NO branch around the gathers: a conditional load makes hipcc drain vmcnt per element (the loads of a K-step
+    // would serialise).  Invalid taps read d.in[0..3] (always mapped) and are zeroed by a select.
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kvalid && ((amask[i] >> tap) & 1u)) v = *reinterpret_cast<const f32x4*>(abase[i] + delta);
-      areg[i] = v;
+      const bool ok = kvalid && ((amask[i] >> tap) & 1u);
+      const float* src = ok ? abase[i] + delta : d.in;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+      areg[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) breg[i] = *reinterpret_cast<const f32x4*>(wrow[i] + k0);
@@ -166,43 +173,64 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // ConvTranspose (OUTMODE 1): the (img, y, x) decode of a row costs two integer divisions; doing it per
+  // accumulator register made the epilogue ~5000 VALU instructions per wave (the K = 64 full-resolution layer
+  // spent more time there than in its MFMAs).  Each row's output pixel index is computed ONCE per workgroup
+  // into LDS (the tile buffers are free after the last barrier) and read back per register.
+  long long* rowpix = reinterpret_cast<long long*>(smem);
+  if (OUTMODE == 1) {
+    for (int rrow = tid; rrow < BM; rrow += 256) {
+      const int m = bm0 + rrow;
+      long long pix = -1;
+      if (m < d.M) {
+        const int img = m / HW;
+        const int rem = m - img * HW;
+        const int y = rem / d.W;
+        const int x = rem - y * d.W;
+        pix = ((long long)img * d.Hout + 2 * y) * d.Wout + 2 * x;
+      }
+      rowpix[rrow] = pix;
+    }
+    __syncthreads();
+  }
+  // Address arithmetic is kept off the per-element path: a uniform 64-bit tile base + a 32-bit element index
+  // (rows of a tile span < 2^31 elements), and the m < M test only exists on the last (partial) row tile.
+  const bool full_m = bm0 + BM <= d.M;   // block-uniform
+  float* const tile_out = d.out + (size_t)bm0 * d.ldout + d.coff;
 #pragma unroll
   for (int ni = 0; ni < WNT; ++ni) {
     const int n = bn0 + (wn * WNT + ni) * 32 + lr;
     const bool nvalid = n < d.N;
     const float sc = (nvalid && d.scale) ? d.scale[n] : 1.f;
     const float sh = (nvalid && d.shift) ? d.shift[n] : 0.f;
-    int q = 0, co = n;
+    long long qoff = 0;   // OUTMODE 1: pixel offset of tap q = (dy, dx) and the channel inside the pixel
+    int co = n;
     if (OUTMODE == 1) {
-      q = n / d.ct_cout;
+      const int q = n / d.ct_cout;
       co = n - q * d.ct_cout;
+      qoff = (long long)(q >> 1) * d.Wout + (q & 1);
     }
+    const bool split = OUTMODE == 0 && d.split_n > 0 && n >= d.split_n;
 #pragma unroll
     for (int mi = 0; mi < WMT; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = bm0 + (wm * WMT + mi) * 32 + row;
-        if (m < d.M && nvalid) {
+        const int rrow = (wm * WMT + mi) * 32 + row;
+        if (nvalid && (full_m || bm0 + rrow < d.M)) {
           float v = acc[mi][ni][r] * sc + sh;
           if (d.relu) v = fmaxf(v, 0.f);
           if (OUTMODE == 0) {
-            if (d.split_n > 0 && n >= d.split_n) d.out2[(size_t)m * d.ld2 + (n - d.split_n)] = v;
-            else d.out[(size_t)m * d.ldout + d.coff + n] = v;
+            if (split) d.out2[(size_t)(bm0 + rrow) * d.ld2 + (n - d.split_n)] = v;
+            else tile_out[(unsigned)(rrow * d.ldout + n)] = v;
           } else {
-            const int img = m / HW;
-            const int rem = m - img * HW;
-            const int y = rem / d.W;
-            const int x = rem - y * d.W;
-            const size_t pix = ((size_t)img * d.Hout + (2 * y + (q >> 1))) * d.Wout + (2 * x + (q & 1));
-            d.out[pix * d.ldout + d.coff + co] = v;
+            d.out[(size_t)(rowpix[rrow] + qoff) * d.ldout + d.coff + co] = v;
           }
         }
       }
     }
   }
 }
-
 
 // =================================================================================================
 // conv3x3 with an LDS-resident input halo (Cin % 32 == 0).
@@ -215,8 +243,16 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
 // double-buffered LDS panel, so there is a single s_barrier per tap.  The halo of the next chunk is
 // prefetched into registers while the current chunk computes.
 // =================================================================================================
-template <int TH, int WAVES_M, int WAVES_N, int WMT, int WNT>
-__global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y) {
+template <int TH, int WAVES_M, int WAVES_N, int WMT, int WNT, int TPS>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y,
+                                                               const int total_patches, const int patches_per_block) {
+  // A workgroup walks `patches_per_block` consecutive TH x 16 patches (x fastest, then y, then image).  The
+  // unit of the pipeline is an ITEM = (patch, 32-channel chunk) = 9/TPS steps of TPS taps each (one s_barrier per
+  // step: TPS = 3 gives the narrow N <= 32 tile 96 MFMAs per wave between barriers instead of 32); the halo of
+  // item i+1 -- which may belong to the next patch -- is prefetched into registers during item i, so only the
+  // very first halo load of a workgroup is exposed and a patch's epilogue stores overlap the next patch's loads.
+  static_assert(TPS == 1 || TPS == 3, "taps per step");
+  constexpr int SPI = 9 / TPS;  // steps per item
   constexpr int TW = 16, HWID = TW + 2, HP = (TH + 2) * HWID;
   constexpr int BM = TH * TW;
   constexpr int BN = WAVES_N * WNT * 32;
@@ -225,7 +261,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const IgemmDesc d
   constexpr int BR = BN / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;                  // [HP][36]
-  float* Bs = smem + HP * LDS_LD;    // [2][BN][36]
+  float* Bs = smem + HP * LDS_LD;    // [2][TPS][BN][36]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -234,51 +270,71 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const IgemmDesc d
   const int wn = wave % WAVES_N;
   const int kq = tid & 7;
   const int r0 = tid >> 3;
-  const int bid = blockIdx.x;
-  const int tx = bid % tiles_x;
-  const int ty = (bid / tiles_x) % tiles_y;
-  const int img = bid / (tiles_x * tiles_y);
-  const int y0 = ty * TH, x0 = tx * TW;
   const int bn0 = blockIdx.y * BN;
-  const float* img_base = d.in + (size_t)img * d.H * d.W * d.ldin;
+  const int p_begin = blockIdx.x * patches_per_block;
+  const int npatch = min(patches_per_block, total_patches - p_begin);
+  if (npatch <= 0) return;
 
-  // halo staging map: thread -> (halo pixel r0 + 32 i, float4 kq); offset < 0: outside the image (zero)
+  // halo staging map of the patch being LOADED: thread -> (halo pixel r0 + 32 i, float4 kq).  Out-of-image
+  // pixels keep offset 0 (a mapped address: the loads stay unconditional, see the note in igemm_f32_kernel)
+  // and are zeroed by hmask when the registers are written to LDS.
   int hoff[HR];
+  unsigned hmask = 0u, hmask_next = 0u;
+  const float* load_base = d.in;
+  auto setup_patch = [&](int p, int& img, int& y0, int& x0) {
+    const int tx = p % tiles_x;
+    const int ty = (p / tiles_x) % tiles_y;
+    img = p / (tiles_x * tiles_y);
+    y0 = ty * TH;
+    x0 = tx * TW;
+  };
+  auto setup_load = [&](int p) {
+    int img, y0, x0;
+    setup_patch(p, img, y0, x0);
+    load_base = d.in + (size_t)img * d.H * d.W * d.ldin + kq * 4;
+    unsigned mk = 0u;
 #pragma unroll
-  for (int i = 0; i < HR; ++i) {
-    const int hp = r0 + 32 * i;
-    const int hy = hp / HWID, hx = hp - hy * HWID;
-    const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-    hoff[i] = (hp < HP && y >= 0 && y < d.H && x >= 0 && x < d.W) ? (y * d.W + x) * d.ldin + kq * 4 : -1;
-  }
+    for (int i = 0; i < HR; ++i) {
+      const int hp = r0 + 32 * i;
+      const int hy = hp / HWID, hx = hp - hy * HWID;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const bool ok = hp < HP && y >= 0 && y < d.H && x >= 0 && x < d.W;
+      hoff[i] = ok ? (y * d.W + x) * d.ldin : 0;
+      mk |= ok ? (1u << i) : 0u;
+    }
+    hmask_next = mk;
+  };
   const float* wrow[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) wrow[i] = d.w + (size_t)(bn0 + r0 + 32 * i) * d.Kp + kq * 4;
 
   f32x4 hreg[HR];
-  f32x4 breg[BR];
+  f32x4 breg[TPS][BR];
   auto load_halo = [&](int c) {
+    hmask = hmask_next;   // the mask of the patch these registers belong to
 #pragma unroll
-    for (int i = 0; i < HR; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (hoff[i] >= 0) v = *reinterpret_cast<const f32x4*>(img_base + hoff[i] + c * CK);
-      hreg[i] = v;
-    }
+    for (int i = 0; i < HR; ++i) hreg[i] = *reinterpret_cast<const f32x4*>(load_base + hoff[i] + c * CK);
   };
   auto store_halo = [&]() {
 #pragma unroll
     for (int i = 0; i < HR; ++i)
-      if (r0 + 32 * i < HP) *reinterpret_cast<f32x4*>(Hs + (r0 + 32 * i) * LDS_LD + kq * 4) = hreg[i];
+      if (r0 + 32 * i < HP)
+        *reinterpret_cast<f32x4*>(Hs + (r0 + 32 * i) * LDS_LD + kq * 4) = ((hmask >> i) & 1u) ? hreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  auto load_b = [&](int c, int tap) {
-    const int k0 = tap * d.Cp + c * CK;
+  auto load_b = [&](int c, int stp) {   // the TPS weight tiles of step `stp` of chunk c
 #pragma unroll
-    for (int i = 0; i < BR; ++i) breg[i] = *reinterpret_cast<const f32x4*>(wrow[i] + k0);
+    for (int tt = 0; tt < TPS; ++tt) {
+      const int k0 = (stp * TPS + tt) * d.Cp + c * CK;
+#pragma unroll
+      for (int i = 0; i < BR; ++i) breg[tt][i] = *reinterpret_cast<const f32x4*>(wrow[i] + k0);
+    }
   };
   auto store_b = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < BR; ++i)
-      *reinterpret_cast<f32x4*>(Bs + buf * BN * LDS_LD + (r0 + 32 * i) * LDS_LD + kq * 4) = breg[i];
+    for (int tt = 0; tt < TPS; ++tt)
+#pragma unroll
+      for (int i = 0; i < BR; ++i)
+        *reinterpret_cast<f32x4*>(Bs + ((buf * TPS + tt) * BN + r0 + 32 * i) * LDS_LD + kq * 4) = breg[tt][i];
   };
 
   f32x16 acc[WMT][WNT];
@@ -294,94 +350,147 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const IgemmDesc d
   int aoff[WMT];  // float offset of this lane's A row (tap 0,0) inside Hs
 #pragma unroll
   for (int mi = 0; mi < WMT; ++mi) {
-    const int p = (wm * WMT + mi) * 32 + lr;
-    aoff[mi] = ((p >> 4) * HWID + (p & 15)) * LDS_LD + lh * 4;
+    const int pp = (wm * WMT + mi) * 32 + lr;
+    aoff[mi] = ((pp >> 4) * HWID + (pp & 15)) * LDS_LD + lh * 4;
   }
   const int boff = (wn * WNT * 32 + lr) * LDS_LD + lh * 4;
 
   const int nchunks = d.Cp / CK;
-  const int nsteps = nchunks * 9;
+  const int nitems = npatch * nchunks;
+  const int nsteps = nitems * SPI;
+  setup_load(p_begin);
   load_halo(0);
   load_b(0, 0);
   store_halo();
   store_b(0);
-  if (nsteps > 1) load_b(0, 1);
-  int c = 0, tap = 0;
+  load_b(0, 1);              // nsteps >= 3
+  int c = 0, tap = 0, pi = 0;   // chunk / step-in-item / patch of the step being computed
+  int c2 = 0, t2 = 2;           // chunk / step-in-item of step st + 2 (weights depend on (chunk, step) only)
+  if (SPI == 3 && nchunks == 1) { /* t2 = 2 is still inside item 0 */ }
   for (int st = 0; st < nsteps; ++st) {
     __syncthreads();  // Bs[st&1] (and a fresh halo when tap == 0) visible; Bs[(st+1)&1] no longer read
     if (st + 1 < nsteps) store_b((st + 1) & 1);
-    if (st + 2 < nsteps) {
-      int t2 = tap + 2, c2 = c;
-      if (t2 >= 9) { t2 -= 9; ++c2; }
-      load_b(c2, t2);
+    if (st + 2 < nsteps) load_b(c2, t2);
+    if (++t2 == SPI) {
+      t2 = 0;
+      if (++c2 == nchunks) c2 = 0;
     }
-    if (tap == 0 && c + 1 < nchunks) load_halo(c + 1);
-    const int r = tap / 3, s = tap - 3 * r;
-    const float* Ap = Hs + (r * HWID + s) * LDS_LD;
-    const float* Bp = Bs + (st & 1) * BN * LDS_LD + boff;
-#pragma unroll
-    for (int kk = 0; kk < CK / 8; ++kk) {
-      f32x4 a[WMT], b[WNT];
-#pragma unroll
-      for (int mi = 0; mi < WMT; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(Ap + aoff[mi] + kk * 8);
-#pragma unroll
-      for (int ni = 0; ni < WNT; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(Bp + ni * 32 * LDS_LD + kk * 8);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int mi = 0; mi < WMT; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < WNT; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], b[ni][t], acc[mi][ni], 0, 0, 0);
-    }
-    if (++tap == 9) {
-      tap = 0;
-      ++c;
-      if (c < nchunks) {
-        __syncthreads();  // every wave is done with the old halo
-        store_halo();
+    if (tap == 0) {   // prefetch the halo of the next item
+      if (c + 1 < nchunks) {
+        load_halo(c + 1);
+      } else if (pi + 1 < npatch) {
+        setup_load(p_begin + pi + 1);
+        load_halo(0);
       }
     }
-  }
-
+    // operand fetches are software-pipelined one (tap, kk) group ahead of the MFMAs that consume them, so the
+    // ~100-cycle ds_read latency hides under the previous group's MFMAs instead of being exposed 4x per tap
+    {
+      constexpr int NG = TPS * (CK / 8);
+      f32x4 a[2][WMT], b[2][WNT];
+      auto fetch = [&](int gidx, int slot) {
+        const int tt = gidx / (CK / 8), kk = gidx % (CK / 8);
+        const int tp = tap * TPS + tt;            // 3x3 tap index
+        const int r = tp / 3, s = tp - 3 * r;
+        const float* Ap = Hs + (r * HWID + s) * LDS_LD + kk * 8;
+        const float* Bp = Bs + ((st & 1) * TPS + tt) * BN * LDS_LD + boff + kk * 8;
 #pragma unroll
-  for (int ni = 0; ni < WNT; ++ni) {
-    const int n = bn0 + (wn * WNT + ni) * 32 + lr;
-    const bool nvalid = n < d.N;
-    const float sc = (nvalid && d.scale) ? d.scale[n] : 1.f;
-    const float sh = (nvalid && d.shift) ? d.shift[n] : 0.f;
+        for (int mi = 0; mi < WMT; ++mi) a[slot][mi] = *reinterpret_cast<const f32x4*>(Ap + aoff[mi]);
 #pragma unroll
-    for (int mi = 0; mi < WMT; ++mi) {
+        for (int ni = 0; ni < WNT; ++ni) b[slot][ni] = *reinterpret_cast<const f32x4*>(Bp + ni * 32 * LDS_LD);
+      };
+      fetch(0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int p = (wm * WMT + mi) * 32 + row;
-        const int y = y0 + (p >> 4), x = x0 + (p & 15);
-        if (nvalid && y < d.H && x < d.W) {
-          float v = acc[mi][ni][r] * sc + sh;
-          if (d.relu) v = fmaxf(v, 0.f);
-          d.out[(((size_t)img * d.H + y) * d.W + x) * d.ldout + d.coff + n] = v;
+      for (int gidx = 0; gidx < NG; ++gidx) {
+        if (gidx + 1 < NG) fetch(gidx + 1, (gidx + 1) & 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int mi = 0; mi < WMT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WNT; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gidx & 1][mi][t], b[gidx & 1][ni][t], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    if (++tap == SPI) {
+      tap = 0;
+      const bool patch_done = (c + 1 == nchunks);
+      const bool more = patch_done ? (pi + 1 < npatch) : true;
+      if (more) {
+        __syncthreads();  // every wave is done with the old halo
+        store_halo();     // visible after the barrier at the top of the next step
+      }
+      if (patch_done) {
+        // ---- epilogue of patch pi (its stores overlap the next patch's halo, already in LDS/flight) ----
+        int img, y0, x0;
+        setup_patch(p_begin + pi, img, y0, x0);
+        // uniform 64-bit image base + 32-bit element index; per element only one add (row/col constants fold
+        // into scalar multiples of W*ldout and ldout), bounds tests only on patches that cross the image edge
+        float* const img_out = d.out + (size_t)img * d.H * d.W * d.ldout + d.coff;
+        const bool interior = (y0 + TH <= d.H) && (x0 + TW <= d.W);   // block-uniform
+        const unsigned sA = (unsigned)(d.W * d.ldout), sB = (unsigned)d.ldout;
+#pragma unroll
+        for (int ni = 0; ni < WNT; ++ni) {
+          const int n = bn0 + (wn * WNT + ni) * 32 + lr;
+          const bool nvalid = n < d.N;
+          const float sc = (nvalid && d.scale) ? d.scale[n] : 1.f;
+          const float sh = (nvalid && d.shift) ? d.shift[n] : 0.f;
+          const unsigned lane_idx = (unsigned)((y0 * d.W + x0 + 4 * lh) * d.ldout + n);
+#pragma unroll
+          for (int mi = 0; mi < WMT; ++mi) {
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+              // pixel of this accumulator register inside the patch: pp = 32*(wm*WMT+mi) + 8*(rr>>2) + 4*lh + (rr&3)
+              const int pyc = 2 * (wm * WMT + mi) + (rr >> 3);            // patch row    (lane independent)
+              const int pxc = 8 * ((rr >> 2) & 1) + (rr & 3);             // patch column (without the 4*lh part)
+              float v = acc[mi][ni][rr] * sc + sh;
+              if (d.relu) v = fmaxf(v, 0.f);
+              const unsigned idx = lane_idx + (unsigned)pyc * sA + (unsigned)pxc * sB;
+              if (interior) {
+                if (nvalid) img_out[idx] = v;
+              } else if (nvalid && y0 + pyc < d.H && x0 + pxc + 4 * lh < d.W) {
+                img_out[idx] = v;
+              }
+              acc[mi][ni][rr] = 0.f;
+            }
+          }
         }
+        c = 0;
+        ++pi;
+      } else {
+        ++c;
       }
     }
   }
 }
 
-template <int TH, int WAVES_M, int WAVES_N, int WMT, int WNT>
+template <int TH, int WAVES_M, int WAVES_N, int WMT, int WNT, int TPS>
 static hipError_t launch_halo(const IgemmDesc& d, hipStream_t s) {
   constexpr int BN = WAVES_N * WNT * 32;
   constexpr int HP = (TH + 2) * 18;
   const int tiles_x = (d.W + 15) / 16, tiles_y = (d.H + TH - 1) / TH;
   const int B = d.M / (d.H * d.W);
-  dim3 grid(tiles_x * tiles_y * B, (d.N + BN - 1) / BN);
-  const size_t lds = (size_t)(HP + 2 * BN) * LDS_LD * sizeof(float);
-  hipLaunchKernelGGL((conv3x3_halo_f32_kernel<TH, WAVES_M, WAVES_N, WMT, WNT>), grid, dim3(256), lds, s, d, tiles_x, tiles_y);
+  const int total = tiles_x * tiles_y * B, ntn = (d.N + BN - 1) / BN;
+  // patches per workgroup: keep >= ~4 workgroups per CU in the grid (2 are resident), at most 16 patches each
+  int ppb = (int)(((long)total * ntn) / (256 * 4));
+  if (ppb < 1) ppb = 1;
+  if (ppb > g_halo_max_ppb) ppb = g_halo_max_ppb;
+  dim3 grid((total + ppb - 1) / ppb, ntn);
+  const size_t lds = (size_t)(HP + 2 * TPS * BN) * LDS_LD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f32_kernel<TH, WAVES_M, WAVES_N, WMT, WNT, TPS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_halo_f32_kernel<TH, WAVES_M, WAVES_N, WMT, WNT, TPS>), grid, dim3(256), lds, s, d, tiles_x, tiles_y,
+                     total, ppb);
   return hipGetLastError();
 }
 
 static bool halo_applicable(const IgemmDesc& d) {
   return d.KS == 3 && d.out_mode == 0 && (d.Cp % CK) == 0 && d.K == 9 * d.Cp && d.ldin == d.Cp &&
-         (long)d.H * d.W * d.ldin < (1l << 31) && g_use_halo;
+         (long)d.H * d.W * d.ldin < (1l << 31) && (long)d.H * d.W * d.ldout < (1l << 31) && g_use_halo;
 }
 
 template <int KS, int OUTMODE, int WAVES_M, int WAVES_N, int WMT, int WNT>
@@ -409,9 +518,10 @@ hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s) {
     return launch_tiles<1, 1>(d, s);
   }
   if (halo_applicable(d)) {
-    if (d.N > 64) return launch_halo<8, 2, 2, 2, 2>(d, s);    // 8x16 px  x 128 ch, wave 64x64
-    if (d.N > 32) return launch_halo<16, 4, 1, 2, 2>(d, s);   // 16x16 px x 64 ch,  wave 64x64
-    return launch_halo<16, 4, 1, 2, 1>(d, s);                 // 16x16 px x 32 ch,  wave 64x32
+    if (d.N > 64) return launch_halo<8, 2, 2, 2, 2, 1>(d, s);    // 8x16 px  x 128 ch, wave 64x64
+    if (d.N > 32) return launch_halo<16, 4, 1, 2, 2, 1>(d, s);   // 16x16 px x 64 ch,  wave 64x64
+    if (g_halo_tps3) return launch_halo<16, 4, 1, 2, 1, 3>(d, s);  // 16x16 px x 32 ch, wave 64x32, 3 taps per barrier
+    return launch_halo<16, 4, 1, 2, 1, 1>(d, s);
   }
   if (d.KS == 3) return launch_tiles<3, 0>(d, s);
   if (d.KS == 1) return launch_tiles<1, 0>(d, s);

@@ -60,6 +60,10 @@ int mgu_create(int device_id, mgu_ctx** out) {
   c->device = device_id;
   const char* nh = getenv("MGU_NO_HALO");
   set_use_halo(!(nh && nh[0] == '1'));
+  const char* t1 = getenv("MGU_HALO_TPS1");
+  set_halo_tps3(!(t1 && t1[0] == '1'));
+  const char* pp = getenv("MGU_HALO_PPB");
+  if (pp && atoi(pp) > 0) set_halo_max_ppb(atoi(pp));
   *out = c;
   return MGU_OK;
 }
@@ -390,8 +394,16 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
     cur = (const float*)feat_dev[i];
     cur_ld = C;
   }
-  // final 1x1 conv (:143)
-  if ((rc = run_conv(c, c->layers[li++], cur, cur_ld, B, H, W, (float*)logits_dev, c->ncls, 0, 0, 0, 0, s))) return rc;
+  // final 1x1 conv (:143): a few output channels -> HBM-bound head kernel reading the reference's (ncls, C) weight
+  {
+    const Layer& F = c->layers[li++];
+    if (c->ncls <= 4 && F.w_src && F.b_src) {
+      ProfScope ps(c, s);
+      HIPCHK(c, launch_conv1x1_head(cur, cur_ld, F.Cin, F.w_src, F.b_src, (float*)logits_dev, c->ncls, c->ncls, (int64_t)B * H * W, s));
+    } else if ((rc = run_conv(c, F, cur, cur_ld, B, H, W, (float*)logits_dev, c->ncls, 0, 0, 0, 0, s))) {
+      return rc;
+    }
+  }
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev_total[1], s));
   return MGU_OK;
 }

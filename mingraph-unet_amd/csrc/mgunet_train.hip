@@ -207,7 +207,11 @@ int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t x
     cur = feat, ld = C;
   }
   Layer& F = c->layers.back();
-  if ((rc = run_layer(c, F, cur, ld, B, H, W, logits, c->ncls, 0, 0, nullptr, F.shift, 0, 0, s))) return rc;
+  if (c->ncls <= 4) {
+    HIPCHK(c, launch_conv1x1_head(cur, ld, F.Cin, F.w_src, F.b_src, logits, c->ncls, c->ncls, (int64_t)B * H * W, s));
+  } else if ((rc = run_layer(c, F, cur, ld, B, H, W, logits, c->ncls, 0, 0, nullptr, F.shift, 0, 0, s))) {
+    return rc;
+  }
   F.t_in = cur, F.t_ldin = ld, F.t_B = B, F.t_H = H, F.t_W = W;
   c->t_logits = logits;
   c->tB = B, c->tH = H, c->tW = W;

@@ -70,26 +70,26 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradDesc d) {
 
   f32x4 areg[PA], zreg[PZ];
   auto load_step = [&](int mb) {
+    // unconditional loads from a safe address + select (a branch around a load makes hipcc drain vmcnt per element)
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       const int m = mb + ra + 8 * i;
-      if (kvalid && m < m_end) {
-        int sy, sx, SH, SW;
-        if (KS == 2) { sy = 2 * a_y[i] + dy; sx = 2 * a_x[i] + dx; SH = d.Hs; SW = d.Ws; }
-        else         { sy = a_y[i] + dy;     sx = a_x[i] + dx;     SH = d.H;  SW = d.W; }
-        if (sy >= 0 && sy < SH && sx >= 0 && sx < SW)
-          v = *reinterpret_cast<const f32x4*>(d.in + (((size_t)a_img[i] * SH + sy) * SW + sx) * d.ldin + d.inoff + cch);
-      }
-      areg[i] = v;
+      int sy, sx, SH, SW;
+      if (KS == 2) { sy = 2 * a_y[i] + dy; sx = 2 * a_x[i] + dx; SH = d.Hs; SW = d.Ws; }
+      else         { sy = a_y[i] + dy;     sx = a_x[i] + dx;     SH = d.H;  SW = d.W; }
+      const bool ok = kvalid && m < m_end && sy >= 0 && sy < SH && sx >= 0 && sx < SW;
+      const float* src = ok ? d.in + (((size_t)a_img[i] * SH + sy) * SW + sx) * d.ldin + d.inoff + cch : d.in;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+      areg[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int i = 0; i < PZ; ++i) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       const int r = rz + RPZ * i;
       const int m = mb + r;
-      if (zcol_ok && r < WG_MK && m < m_end) v = *reinterpret_cast<const f32x4*>(d.z + (size_t)m * d.ldz + d.zoff + n0 + jz * 4);
-      zreg[i] = v;
+      const bool ok = zcol_ok && r < WG_MK && m < m_end;
+      const float* src = ok ? d.z + (size_t)m * d.ldz + d.zoff + n0 + jz * 4 : d.z;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+      zreg[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto advance_rows = [&]() {  // rows move 32 pixels forward: incremental (img, y, x) update
