@@ -13,6 +13,8 @@
 //   gat_aggregate : CSR-by-target neighbour gather -> weighted sum -> /(D+1e-10) -> ELU -> concat | head-mean
 //                   one wavefront per 4-row CSR segment, 8 row gathers in flight per lane, segmented
 //                   register accumulation, head-mean staged through LDS, XCD-aware workgroup order.
+#include <type_traits>
+
 #include "common.h"
 
 namespace mgu {
@@ -168,12 +170,14 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
   const int seg_ids = (lane < ne) ? col[start + lane] : 0;   // whole segment when it has <= 64 edges (the usual case)
 
   int head[NCH];
+  unsigned coff4[NCH];
   bool on[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
     on[i] = c < nq;
     head[i] = on[i] ? c / qh : 0;
+    coff4[i] = on[i] ? (unsigned)c * 4u : 0u;
   }
 
 #pragma unroll 1
@@ -192,40 +196,49 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
       D[i] = 0.f;
       acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // The kernel is instruction-issue bound (rocprofv3: ~350 VALU+SALU per row at 36 VGPRs), so a row of <= 4
+    // in-edges (every patch-graph row) takes a 4-slot batch and only longer rows the 8-slot one: dead slots cost
+    // full gathers and FMAs.
+    auto batch = [&](auto eb_c, const int ids, const int lane0, const int eb, const int cnt) {
+      constexpr int EBN = decltype(eb_c)::value;
+      f32x4 v[EBN][NCH];
+      float sv[EBN][NCH];
+      // NO branch around the gathers (a conditional load makes hipcc wait per element): slots past the end of the
+      // row re-read its last neighbour and get weight 0.
+#pragma unroll
+      for (int k = 0; k < EBN; ++k) {
+        const int src = __builtin_amdgcn_readlane(ids, lane0 + min(eb + k, cnt - 1));
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          // 32-bit indices (the launcher guarantees N*P < 2^31): the row base is a scalar multiply
+          v[k][i] = *reinterpret_cast<const f32x4*>(wh + (unsigned)(src * P) + coff4[i]);
+          sv[k][i] = st[(unsigned)(src * H2) + head[i]];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < EBN; ++k) {
+        const bool live = eb + k < cnt;        // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          float ev = sv[k][i] + tj[i];
+          ev = ev > 0.f ? ev : alpha * ev;                        // LeakyReLU (:65)
+          const float x = (live && on[i]) ? __expf(ev - gm[i]) : 0.f;   // exp(e - max(e)) (:86)
+          D[i] += x;                                              // scatter_add of exp_e (:90-91)
+          acc[i] += x * v[k][i];                                  // scatter_add of alpha*Wh_src (:104-112)
+        }
+      }
+    };
 #pragma unroll 1
     for (int base = 0; base < deg; base += 64) {
       const bool in_seg = ne <= 64;            // wave-uniform: ids already in seg_ids at lane (s0 - start) + e
       const int ids = in_seg ? seg_ids : ((base + lane < deg) ? col[s0 + base + lane] : 0);
       const int lane0 = in_seg ? s0 - start : 0;
       const int cnt = min(64, deg - base);
+      if (cnt <= 4) {
+        batch(std::integral_constant<int, 4>{}, ids, lane0, 0, cnt);
+      } else {
 #pragma unroll 1
-      for (int eb = 0; eb < cnt; eb += EB) {
-        f32x4 v[EB][NCH];
-        float sv[EB][NCH];
-        // NO branch around the gathers (a conditional load makes hipcc wait per element): slots past the end of the
-        // row re-read its last neighbour and get weight 0.
-#pragma unroll
-        for (int k = 0; k < EB; ++k) {
-          const int src = __builtin_amdgcn_readlane(ids, lane0 + min(eb + k, cnt - 1));
-#pragma unroll
-          for (int i = 0; i < NCH; ++i) {
-            const int c = on[i] ? lane + 64 * i : 0;
-            v[k][i] = *reinterpret_cast<const f32x4*>(wh + (size_t)src * P + c * 4);
-            sv[k][i] = st[(size_t)src * H2 + head[i]];
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < EB; ++k) {
-          const bool live = eb + k < cnt;        // wave-uniform
-#pragma unroll
-          for (int i = 0; i < NCH; ++i) {
-            float ev = sv[k][i] + tj[i];
-            ev = ev > 0.f ? ev : alpha * ev;                        // LeakyReLU (:65)
-            const float x = (live && on[i]) ? __expf(ev - gm[i]) : 0.f;   // exp(e - max(e)) (:86)
-            D[i] += x;                                              // scatter_add of exp_e (:90-91)
-            acc[i] += x * v[k][i];                                  // scatter_add of alpha*Wh_src (:104-112)
-          }
-        }
+        for (int eb = 0; eb < cnt; eb += EB) batch(std::integral_constant<int, EB>{}, ids, lane0, eb, cnt);
       }
     }
     // /(D + 1e-10) (:96), ELU (:118), concat (:155) or head mean (:158)
@@ -259,7 +272,7 @@ hipError_t launch_gat_aggregate(const float* wh, int P, const float* st, const i
                                 const int32_t* node_graph, const unsigned* gmax_enc, int N, int heads, int Fh, int concat,
                                 float alpha, float* out, hipStream_t s) {
   const int HF = heads * Fh;
-  if (HF > GAT_MAX_HF || (Fh & 3) || (P & 3)) return hipErrorInvalidValue;
+  if (HF > GAT_MAX_HF || (Fh & 3) || (P & 3) || (long)N * P >= (1l << 31)) return hipErrorInvalidValue;
   if (N == 0) return hipSuccess;
   dim3 block(256);
 #define MGU_AGG(NCH)                                                                                              \
