@@ -225,3 +225,35 @@ def test_weights_are_repacked_after_update(cuda):
         ref = O.unet_forward(p2, x.cpu(), 2)[0]
     b = m(x)[0]
     assert not torch.equal(a, b) and maxdiff(b, ref.numpy()) <= TOL
+
+
+def test_full_size_properties_c3_c4_shapes(cuda):
+    """BASELINE configs[2] per-GPU shard and configs[3] at FULL size (no oracle at this size): size-independent
+    properties -- an image's logits do not depend on its batch neighbours (bit-exact), the batch-of-32 1024^2
+    forward equals the golden samples of images 0 and 31, outputs are finite, argmax loop == torch.argmax."""
+    unet = make_unet((3, 2, 32, 4), 0, cuda)
+    # configs[3]: batch 32 x 3 x 1024 x 1024 in ONE call (34 M pixels; M = B*H*W close to the int32 row limit / 64)
+    x = torch.empty((32, 3, 1024, 1024), device=cuda)
+    for b in (0, 31):
+        x[b] = torch.from_numpy(O.formula_normal(f"c4/x/{b}", (1, 3, 1024, 1024), seed=2))[0].to(cuda)
+    gen = torch.Generator(device=cuda)
+    gen.manual_seed(7)
+    x[1:31] = torch.randn((30, 3, 1024, 1024), device=cuda, generator=gen)
+    lg, sk, ft = unet(x)
+    assert tuple(lg.shape) == (32, 2, 1024, 1024) and bool(torch.isfinite(lg).all())
+    import numpy as np
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "c4.npz"))
+    for b in (0, 31):
+        got = lg[b].contiguous().reshape(-1)[torch.from_numpy(g[f"idx_{b}"]).to(cuda)]
+        assert maxdiff(got, g[f"logits_{b}"]) <= TOL
+    alone = unet(x[17:18])[0]
+    assert torch.equal(alone[0], lg[17])
+    del lg, sk, ft, alone, x
+    torch.cuda.empty_cache()
+    # configs[2] shard: 8 images of 512^2 inside a batch of 64 (one GPU's share is 8; here all 64 on one GPU)
+    xb = torch.randn((64, 3, 512, 512), device=cuda, generator=gen)
+    lgb = unet(xb)[0]
+    shard = unet(xb[24:32])[0]
+    assert torch.equal(shard, lgb[24:32]) and bool(torch.isfinite(lgb).all())
+    _, pred = mgunet.segment_batch(unet, xb[:4])
+    assert torch.equal(pred, torch.argmax(lgb[:4], dim=1))
