@@ -27,6 +27,7 @@ for _p in (os.path.join(ROOT, "mingraph-unet_amd"), os.path.join(ROOT, "oracle")
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: bf16 MFMA dense (never the 2:1-sparse figure)
 
 
 def host_cores():
@@ -136,6 +137,9 @@ def main():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer: BASELINE configs[1]/[2] full forward (the headline); train: configs[4] train step "
                          "(fwd + CE + bwd + RCCL grad all-reduce + Adam), 4 images per GPU unless --batch is given")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: exact-fp32 MFMA (BASELINE configs[1], the headline); bf16: bf16 storage + fp32 accumulate "
+                         "(configs[2]'s precision; reported as its own config, never as the fp32 number)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
     ap.add_argument("--no-profile-pass", action="store_true")
     a = ap.parse_args()
@@ -171,7 +175,7 @@ def main():
     if a.mode == "train":
         return bench_train(a, world, rank, local_rank, dev, dist)
     B, H, W = a.batch, a.size, a.size
-    unet = mgunet.UNet(3, 2, 32, 4)
+    unet = mgunet.UNet(3, 2, 32, 4, compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     unet.load_state_dict(O.make_unet_params(3, 2, 32, 4, seed=0))     # random-init-scale formula weights
     gat = mgunet.GATNetwork(32, 128, 64, 4, 1)
     gat.load_state_dict(O.make_gat_params(32, 128, 64, 4, 1, seed=0))
@@ -231,8 +235,11 @@ def main():
         if os.path.exists(tj) and (B, H, W) == (8, 512, 512):
             t = json.load(open(tj))
             traffic, traffic_src = round(t["hbm_bytes_per_launch"]), "profiles/r01_traffic.json (" + t["correction"].split(" (")[0] + ")"
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+        peak = PEAK_BF16_MFMA_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        if a.dtype == "bf16":
+            traffic, traffic_src = None, None   # the committed PMC passes are fp32
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_source": traffic_src, "algorithmic_flop_per_launch": round(flops / max(launches // nprof, 1)),
                 "kernel": "conv3x3_halo_f32_kernel + igemm_f32_kernel (the 23 conv3x3/convT/1x1 launches of a step)",
                 "launches_per_step": launches // nprof, "kernel_ms_per_step": round(conv_ms / nprof, 4),
@@ -246,9 +253,11 @@ def main():
         line = {"metric": "segmented Mpix/sec, full MinGraph-UNet forward (U-Net + patch-graph GAT), 512x512 batch",
                 "value": round(mpix, 3), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32", "data": "synthetic (N(0,1) images resident in HBM, formula random-init-scale weights)",
-                "config": {"workload": f"BASELINE configs[1]: batch {B}/GPU x 3x{H}x{W} fp32 full forward "
-                                       f"(UNet(3,2,32,4) + patch16 graph GAT(32->64,4 heads)), eval",
+                "dtype": a.dtype, "data": "synthetic (N(0,1) images resident in HBM, formula random-init-scale weights)",
+                "config": {"workload": (f"BASELINE configs[1]: batch {B}/GPU x 3x{H}x{W} fp32 full forward "
+                                        if a.dtype == "f32" else
+                                        f"BASELINE configs[2] precision: batch {B}/GPU x 3x{H}x{W}, bf16 storage + fp32 accumulate, full forward ")
+                                       + "(UNet(3,2,32,4) + patch16 graph GAT(32->64,4 heads)), eval",
                            "images_per_gpu": B, "global_batch": B * world, "parallelism": f"batch-shard x{world}, no collective"},
                 "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / a.steps, 4),
                 "roofline": roof, "cpu_baseline": cpu}

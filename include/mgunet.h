@@ -31,7 +31,7 @@ extern "C" {
 #define MGU_ERR_NOMEM -4
 
 #define MGU_DTYPE_F32 0
-#define MGU_DTYPE_BF16 1     /* reserved: bf16 storage + fp32 accumulate (BASELINE config 3)   */
+#define MGU_DTYPE_BF16 1     /* bf16 storage + fp32 accumulate, inference only (BASELINE config 3) */
 
 typedef struct mgu_ctx mgu_ctx;
 
@@ -52,7 +52,9 @@ const char* mgu_version(void);
 
 /* ---- U-Net: replaces model/unet/unet_model.py:6-36 (UNet.__init__/forward) ------------------- */
 /* = UNet(in_channels, num_classes, init_features, depth) (unet_model.py:7).  init_features must be
- * a multiple of 4 (NHWC float4 loads).  */
+ * a multiple of 4 (NHWC 16-byte lanes).  dtype MGU_DTYPE_BF16 (init_features % 8 == 0, <= 4 classes): every
+ * activation the forward writes (cat_dev, feat_dev) and the packed weights are bf16, accumulation and the
+ * bias/BatchNorm epilogue stay fp32, x_dev and logits_dev stay fp32; eval mode only. */
 int mgu_unet_configure(mgu_ctx* ctx, int in_channels, int num_classes, int init_features, int depth, int dtype);
 /* Number of fp32 elements of all trainable parameters, in state_dict order (7 766 018 for (3,2,32,4)). */
 int64_t mgu_unet_param_count(mgu_ctx* ctx);
@@ -134,8 +136,8 @@ int mgu_coo_to_csr(const int64_t* coo, int64_t E, int num_nodes, int32_t* rowptr
 /* Node features of the 'full forward' (SURVEY 8a row L3): mean over each patch x patch window of an
  * NHWC feature map, zero padded bottom/right as image_to_patches does (:26-47).
  * out_dev: (B*nph*npw, C) fp32. */
-int mgu_patch_mean(mgu_ctx* ctx, const void* feat_dev, int B, int H, int W, int C, int patch,
-                   void* out_dev, void* hip_stream);
+int mgu_patch_mean(mgu_ctx* ctx, const void* feat_dev, int feat_dtype /* MGU_DTYPE_* */, int B, int H, int W, int C,
+                   int patch, void* out_dev, void* hip_stream);
 
 /* ---- GAT: replaces model/gat/graph_attention.py:40-118, 150-160 (one MultiHeadGATLayer, eval) -- */
 /* X_dev (N,Fin) fp32, Fin % 4 == 0; CSR by target on device (rowptr int32[N+1], col int32[E]);

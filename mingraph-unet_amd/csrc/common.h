@@ -42,6 +42,7 @@ struct IgemmDesc {
 };
 
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
+hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s);  // in / w / out point to bf16, sizes in elements
 void set_use_halo(bool on);
 void set_halo_max_ppb(int n);
 void set_halo_tps3(bool on);
@@ -89,17 +90,18 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, 
                        float wd, int step, float grad_scale, hipStream_t s);
 
 // elementwise.hip
-hipError_t launch_pack_input(const float* x, float* out, int B, int C, int Cp, int H, int W, int64_t sn, int64_t sc,
+// dtype: 0 = fp32, 1 = bf16 storage (MGU_DTYPE_*); void* buffers hold that type
+hipError_t launch_pack_input(const float* x, void* out, int dtype, int B, int C, int Cp, int H, int W, int64_t sn, int64_t sc,
                              int64_t sh, int64_t sw, hipStream_t s);
-hipError_t launch_maxpool2(const float* in, int ldin, float* out, int B, int H, int W, int C, hipStream_t s);
-hipError_t launch_patch_mean(const float* feat, float* out, int B, int H, int W, int C, int patch, hipStream_t s);
-hipError_t launch_pack_conv_w(const float* w_oihw, float* wp, int Cout, int Cin, int Cp, int KS, int Kp, hipStream_t s);
-hipError_t launch_pack_convt_w(const float* w_iohw, float* wp, int Cin, int Cout, int Kp, hipStream_t s);
+hipError_t launch_maxpool2(const void* in, int ldin, void* out, int dtype, int B, int H, int W, int C, hipStream_t s);
+hipError_t launch_patch_mean(const void* feat, int dtype, float* out, int B, int H, int W, int C, int patch, hipStream_t s);
+hipError_t launch_pack_conv_w(const float* w_oihw, void* wp, int dtype, int Cout, int Cin, int Cp, int KS, int Kp, hipStream_t s);
+hipError_t launch_pack_convt_w(const float* w_iohw, void* wp, int dtype, int Cin, int Cout, int Kp, hipStream_t s);
 hipError_t launch_bn_fold(const float* bias, const float* gamma, const float* beta, const float* mean, const float* var,
                           float eps, float* scale, float* shift, int C, hipStream_t s);
 hipError_t launch_bias_tile(const float* bias, float* shift, int C, int reps, hipStream_t s);
-hipError_t launch_conv1x1_head(const float* in, int ldin, int C, const float* w, const float* bias, float* out, int ldout,
-                               int ncls, int64_t npix, hipStream_t s);
+hipError_t launch_conv1x1_head(const void* in, int dtype, int ldin, int C, const float* w, const float* bias, float* out,
+                               int ldout, int ncls, int64_t npix, hipStream_t s);
 hipError_t launch_argmax(const float* logits, int64_t npix, int C, int64_t* pred, hipStream_t s);
 
 // gat.hip

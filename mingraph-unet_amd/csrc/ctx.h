@@ -130,7 +130,7 @@ inline void level_dims(int H, int W, int depth, std::vector<int>& hs, std::vecto
 }
 
 // one fused conv / convT / 1x1 launch described by a Layer (scale/shift chosen by the caller)
-int run_layer(mgu_ctx* c, const Layer& L, const float* in, int ldin, int B, int H, int W, float* out, int ldout, int coff,
+int run_layer(mgu_ctx* c, const Layer& L, const void* in, int ldin, int B, int H, int W, void* out, int ldout, int coff,
               int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s);
 
 // training path (mgunet_train.hip)

@@ -5,6 +5,34 @@
 namespace mgu {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 16-byte chunk <-> fp32 lanes for the two storage types (fp32: 4 elements, bf16: 8 elements)
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ void load(const float* p, float* f) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    f[0] = v[0], f[1] = v[1], f[2] = v[2], f[3] = v[3];
+  }
+  static __device__ __forceinline__ void store(float* p, const float* f) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{f[0], f[1], f[2], f[3]};
+  }
+};
+template <> struct Chunk<__bf16> {
+  static constexpr int VEC = 8;
+  static __device__ __forceinline__ void load(const __bf16* p, float* f) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+  }
+  static __device__ __forceinline__ void store(__bf16* p, const float* f) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)f[j];
+    *reinterpret_cast<bf16x8*>(p) = v;
+  }
+};
 
 static inline int nblocks(int64_t work, int threads, int cap = 256 * 16) {
   int64_t b = (work + threads - 1) / threads;
@@ -14,85 +42,105 @@ static inline int nblocks(int64_t work, int threads, int cap = 256 * 16) {
 }
 
 // ---- input: arbitrary-stride (n,c,y,x) fp32 -> NHWC with channels zero padded to Cp (Cp % 4 == 0) ----
-__global__ void pack_input_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t npix_total, int C,
-                                  int Cp, int H, int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw) {
-  const int q = Cp >> 2;
+template <typename T>
+__global__ void pack_input_kernel(const float* __restrict__ x, T* __restrict__ out, int64_t npix_total, int C, int Cp, int H,
+                                  int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw) {
+  constexpr int VEC = Chunk<T>::VEC;
+  const int q = Cp / VEC;
   const int64_t total = npix_total * q;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t pix = i / q;
-    const int c0 = (int)(i - pix * q) * 4;
+    const int c0 = (int)(i - pix * q) * VEC;
     const int64_t n = pix / ((int64_t)H * W);
     const int64_t rem = pix - n * (int64_t)H * W;
     const int y = (int)(rem / W);
     const int xx = (int)(rem - (int64_t)y * W);
     const float* p = x + n * sn + y * sh + xx * sw;
-    f32x4 v;
+    float v[VEC];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (c0 + j < C) ? p[(c0 + j) * sc] : 0.f;
-    *reinterpret_cast<f32x4*>(out + pix * Cp + c0) = v;
+    for (int j = 0; j < VEC; ++j) v[j] = (c0 + j < C) ? p[(c0 + j) * sc] : 0.f;
+    Chunk<T>::store(out + pix * Cp + c0, v);
   }
 }
 
-hipError_t launch_pack_input(const float* x, float* out, int B, int C, int Cp, int H, int W, int64_t sn, int64_t sc,
+hipError_t launch_pack_input(const float* x, void* out, int dtype, int B, int C, int Cp, int H, int W, int64_t sn, int64_t sc,
                              int64_t sh, int64_t sw, hipStream_t s) {
   const int64_t npix = (int64_t)B * H * W;
-  hipLaunchKernelGGL(pack_input_kernel, dim3(nblocks(npix * (Cp >> 2), 256)), dim3(256), 0, s, x, out, npix, C, Cp, H,
-                     W, sn, sc, sh, sw);
+  if (dtype == 0)
+    hipLaunchKernelGGL(pack_input_kernel<float>, dim3(nblocks(npix * (Cp >> 2), 256)), dim3(256), 0, s, x, (float*)out, npix, C,
+                       Cp, H, W, sn, sc, sh, sw);
+  else
+    hipLaunchKernelGGL(pack_input_kernel<__bf16>, dim3(nblocks(npix * (Cp >> 3), 256)), dim3(256), 0, s, x, (__bf16*)out, npix,
+                       C, Cp, H, W, sn, sc, sh, sw);
   return hipGetLastError();
 }
 
 // ---- MaxPool2d(2,2), floor mode (model/unet/unet_encoder.py:48,70); input may be a channel slice ----
-__global__ void maxpool2_kernel(const float* __restrict__ in, int ldin, float* __restrict__ out, int B, int H, int W,
-                                int C) {
-  const int Ho = H >> 1, Wo = W >> 1, q = C >> 2;
+template <typename T>
+__global__ void maxpool2_kernel(const T* __restrict__ in, int ldin, T* __restrict__ out, int B, int H, int W, int C) {
+  constexpr int VEC = Chunk<T>::VEC;
+  const int Ho = H >> 1, Wo = W >> 1, q = C / VEC;
   const int64_t total = (int64_t)B * Ho * Wo * q;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % q) * 4;
+    const int c0 = (int)(i % q) * VEC;
     int64_t pix = i / q;
     const int xo = (int)(pix % Wo);
     pix /= Wo;
     const int yo = (int)(pix % Ho);
     const int n = (int)(pix / Ho);
-    const float* p = in + (((int64_t)n * H + 2 * yo) * W + 2 * xo) * ldin + c0;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(p + ldin);
-    const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)W * ldin);
-    const f32x4 e = *reinterpret_cast<const f32x4*>(p + (int64_t)W * ldin + ldin);
-    f32x4 v;
+    const T* p = in + (((int64_t)n * H + 2 * yo) * W + 2 * xo) * ldin + c0;
+    float a[VEC], b[VEC], c[VEC], e[VEC], v[VEC];
+    Chunk<T>::load(p, a);
+    Chunk<T>::load(p + ldin, b);
+    Chunk<T>::load(p + (int64_t)W * ldin, c);
+    Chunk<T>::load(p + (int64_t)W * ldin + ldin, e);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(c[j], e[j]));
-    *reinterpret_cast<f32x4*>(out + (((int64_t)n * Ho + yo) * Wo + xo) * C + c0) = v;
+    for (int j = 0; j < VEC; ++j) v[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(c[j], e[j]));
+    Chunk<T>::store(out + (((int64_t)n * Ho + yo) * Wo + xo) * C + c0, v);
   }
 }
 
-hipError_t launch_maxpool2(const float* in, int ldin, float* out, int B, int H, int W, int C, hipStream_t s) {
-  const int64_t total = (int64_t)B * (H >> 1) * (W >> 1) * (C >> 2);
+hipError_t launch_maxpool2(const void* in, int ldin, void* out, int dtype, int B, int H, int W, int C, hipStream_t s) {
+  const int vec = dtype == 0 ? 4 : 8;
+  const int64_t total = (int64_t)B * (H >> 1) * (W >> 1) * (C / vec);
   if (total == 0) return hipSuccess;
-  hipLaunchKernelGGL(maxpool2_kernel, dim3(nblocks(total, 256)), dim3(256), 0, s, in, ldin, out, B, H, W, C);
+  if (dtype == 0)
+    hipLaunchKernelGGL(maxpool2_kernel<float>, dim3(nblocks(total, 256)), dim3(256), 0, s, (const float*)in, ldin, (float*)out, B,
+                       H, W, C);
+  else
+    hipLaunchKernelGGL(maxpool2_kernel<__bf16>, dim3(nblocks(total, 256)), dim3(256), 0, s, (const __bf16*)in, ldin, (__bf16*)out,
+                       B, H, W, C);
   return hipGetLastError();
 }
 
 // ---- patch mean: one workgroup per patch; (Np, C) = mean over patch x patch window (zero padded) ----
-__global__ __launch_bounds__(256) void patch_mean_kernel(const float* __restrict__ feat, float* __restrict__ out, int H,
-                                                         int W, int C, int patch, int nph, int npw) {
+template <typename T>
+__global__ __launch_bounds__(256) void patch_mean_kernel(const T* __restrict__ feat, float* __restrict__ out, int H, int W,
+                                                         int C, int patch, int nph, int npw) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [npl][C]
-  const int q = C >> 2;
+  constexpr int VEC = Chunk<T>::VEC;
+  const int q = C / VEC;
   const int npl = 256 / q;  // pixel lanes
   const int t = threadIdx.x;
   const int cq = t % q, pl = t / q;
   const int node = blockIdx.x;
   const int img = node / (nph * npw);
   const int pr = (node / npw) % nph, pc = node % npw;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
   if (pl < npl) {
     for (int i = pl; i < patch * patch; i += npl) {
       const int y = pr * patch + i / patch, x = pc * patch + i % patch;
       if (y < H && x < W) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(feat + (((int64_t)img * H + y) * W + x) * C + cq * 4);
-        acc += v;
+        float v[VEC];
+        Chunk<T>::load(feat + (((int64_t)img * H + y) * W + x) * C + cq * VEC, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += v[j];
       }
     }
-    *reinterpret_cast<f32x4*>(red + pl * C + cq * 4) = acc;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[pl * C + cq * VEC + j] = acc[j];
   }
   __syncthreads();
   if (t < C) {
@@ -102,47 +150,56 @@ __global__ __launch_bounds__(256) void patch_mean_kernel(const float* __restrict
   }
 }
 
-hipError_t launch_patch_mean(const float* feat, float* out, int B, int H, int W, int C, int patch, hipStream_t s) {
-  if ((C & 3) || C > 256 || C < 4) return hipErrorInvalidValue;
+hipError_t launch_patch_mean(const void* feat, int dtype, float* out, int B, int H, int W, int C, int patch, hipStream_t s) {
+  const int vec = dtype == 0 ? 4 : 8;
+  if ((C % vec) || C > 256 || C < vec) return hipErrorInvalidValue;
   const int nph = (H + patch - 1) / patch, npw = (W + patch - 1) / patch;
-  const int npl = 256 / (C >> 2);
-  hipLaunchKernelGGL(patch_mean_kernel, dim3(B * nph * npw), dim3(256), (size_t)npl * C * sizeof(float), s, feat, out,
-                     H, W, C, patch, nph, npw);
+  const int npl = 256 / (C / vec);
+  const size_t lds = (size_t)npl * C * sizeof(float);
+  if (dtype == 0)
+    hipLaunchKernelGGL(patch_mean_kernel<float>, dim3(B * nph * npw), dim3(256), lds, s, (const float*)feat, out, H, W, C, patch,
+                       nph, npw);
+  else
+    hipLaunchKernelGGL(patch_mean_kernel<__bf16>, dim3(B * nph * npw), dim3(256), lds, s, (const __bf16*)feat, out, H, W, C,
+                       patch, nph, npw);
   return hipGetLastError();
 }
 
 // ---- weights: OIHW (Cout,Cin,KS,KS) -> panel [Cout][Kp], k = (r*KS+s)*Cp + c (zero padded) ------------
-__global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int Cp,
-                                   int KS, int Kp) {
+template <typename T>
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cout, int Cin, int Cp, int KS, int Kp) {
   const int64_t total = (int64_t)Cout * Kp;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(i / Kp), k = (int)(i - (int64_t)n * Kp);
     const int tap = k / Cp, c = k - tap * Cp;
     float v = 0.f;
     if (tap < KS * KS && c < Cin) v = w[((int64_t)n * Cin + c) * KS * KS + tap];
-    wp[i] = v;
+    wp[i] = (T)v;
   }
 }
 
-hipError_t launch_pack_conv_w(const float* w, float* wp, int Cout, int Cin, int Cp, int KS, int Kp, hipStream_t s) {
-  hipLaunchKernelGGL(pack_conv_w_kernel, dim3(nblocks((int64_t)Cout * Kp, 256)), dim3(256), 0, s, w, wp, Cout, Cin, Cp,
-                     KS, Kp);
+hipError_t launch_pack_conv_w(const float* w, void* wp, int dtype, int Cout, int Cin, int Cp, int KS, int Kp, hipStream_t s) {
+  dim3 g(nblocks((int64_t)Cout * Kp, 256)), b(256);
+  if (dtype == 0) hipLaunchKernelGGL(pack_conv_w_kernel<float>, g, b, 0, s, w, (float*)wp, Cout, Cin, Cp, KS, Kp);
+  else hipLaunchKernelGGL(pack_conv_w_kernel<__bf16>, g, b, 0, s, w, (__bf16*)wp, Cout, Cin, Cp, KS, Kp);
   return hipGetLastError();
 }
 
 // ---- ConvTranspose2d weight (Cin,Cout,2,2) -> panel [(dy*2+dx)*Cout + co][Kp], k = ci ----------------
-__global__ void pack_convt_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int Kp) {
+template <typename T>
+__global__ void pack_convt_w_kernel(const float* __restrict__ w, T* __restrict__ wp, int Cin, int Cout, int Kp) {
   const int64_t total = (int64_t)4 * Cout * Kp;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(i / Kp), k = (int)(i - (int64_t)n * Kp);
     const int q = n / Cout, co = n - q * Cout;
-    wp[i] = (k < Cin) ? w[((int64_t)k * Cout + co) * 4 + q] : 0.f;
+    wp[i] = (T)((k < Cin) ? w[((int64_t)k * Cout + co) * 4 + q] : 0.f);
   }
 }
 
-hipError_t launch_pack_convt_w(const float* w, float* wp, int Cin, int Cout, int Kp, hipStream_t s) {
-  hipLaunchKernelGGL(pack_convt_w_kernel, dim3(nblocks((int64_t)4 * Cout * Kp, 256)), dim3(256), 0, s, w, wp, Cin, Cout,
-                     Kp);
+hipError_t launch_pack_convt_w(const float* w, void* wp, int dtype, int Cin, int Cout, int Kp, hipStream_t s) {
+  dim3 g(nblocks((int64_t)4 * Cout * Kp, 256)), b(256);
+  if (dtype == 0) hipLaunchKernelGGL(pack_convt_w_kernel<float>, g, b, 0, s, w, (float*)wp, Cin, Cout, Kp);
+  else hipLaunchKernelGGL(pack_convt_w_kernel<__bf16>, g, b, 0, s, w, (__bf16*)wp, Cin, Cout, Kp);
   return hipGetLastError();
 }
 
@@ -177,8 +234,8 @@ hipError_t launch_bias_tile(const float* bias, float* shift, int C, int reps, hi
 // ---- 1x1 convolution with a handful of output channels (the segmentation head, unet_decoder.py:117,143) ----
 // HBM-bound (0.9 FLOP/B): 8 lanes read one pixel's channels as coalesced float4, each lane accumulates its partial
 // dot products for up to 4 classes, an 8-lane shuffle tree folds them, lane 0 of the group stores.
-template <int NC>
-__global__ __launch_bounds__(256) void conv1x1_head_kernel(const float* __restrict__ in, int ldin, int C,
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void conv1x1_head_kernel(const T* __restrict__ in, int ldin, int C,
                                                            const float* __restrict__ w /*[NC][C]*/,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            int ldout, int64_t npix) {
@@ -188,12 +245,14 @@ __global__ __launch_bounds__(256) void conv1x1_head_kernel(const float* __restri
     float acc[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) acc[k] = 0.f;
-    for (int c = lane8 * 4; c < C; c += 32) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(in + p * ldin + c);
+    constexpr int VEC = Chunk<T>::VEC;
+    for (int c = lane8 * VEC; c < C; c += 8 * VEC) {
+      float v[VEC];
+      Chunk<T>::load(in + p * ldin + c, v);
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k * C + c);
-        acc[k] += v[0] * wv[0] + v[1] * wv[1] + v[2] * wv[2] + v[3] * wv[3];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[k] += v[j] * w[k * C + c + j];
       }
     }
 #pragma unroll
@@ -209,11 +268,20 @@ __global__ __launch_bounds__(256) void conv1x1_head_kernel(const float* __restri
   }
 }
 
-hipError_t launch_conv1x1_head(const float* in, int ldin, int C, const float* w, const float* bias, float* out, int ldout,
-                               int ncls, int64_t npix, hipStream_t s) {
-  if ((C & 3) || (ldin & 3) || ncls < 1 || ncls > 4) return hipErrorInvalidValue;
+hipError_t launch_conv1x1_head(const void* in, int dtype, int ldin, int C, const float* w, const float* bias, float* out,
+                               int ldout, int ncls, int64_t npix, hipStream_t s) {
+  const int vec = dtype == 0 ? 4 : 8;
+  if ((C % vec) || (ldin % vec) || ncls < 1 || ncls > 4) return hipErrorInvalidValue;
   const int blocks = nblocks(npix * 8, 256, 256 * 32);
-#define MGU_HEAD(NC) hipLaunchKernelGGL(conv1x1_head_kernel<NC>, dim3(blocks), dim3(256), 0, s, in, ldin, C, w, bias, out, ldout, npix)
+#define MGU_HEAD(NC)                                                                                                         \
+  do {                                                                                                                       \
+    if (dtype == 0)                                                                                                          \
+      hipLaunchKernelGGL((conv1x1_head_kernel<float, NC>), dim3(blocks), dim3(256), 0, s, (const float*)in, ldin, C, w, bias, out, \
+                         ldout, npix);                                                                                       \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((conv1x1_head_kernel<__bf16, NC>), dim3(blocks), dim3(256), 0, s, (const __bf16*)in, ldin, C, w, bias,   \
+                         out, ldout, npix);                                                                                  \
+  } while (0)
   if (ncls == 1) MGU_HEAD(1);
   else if (ncls == 2) MGU_HEAD(2);
   else if (ncls == 3) MGU_HEAD(3);

@@ -32,19 +32,44 @@ static int g_halo_max_ppb = 16;  // MGU_HALO_PPB=n caps the patches a halo workg
 void set_use_halo(bool on) { g_use_halo = on; }
 void set_halo_max_ppb(int n) { g_halo_max_ppb = n < 1 ? 1 : n; }
 
-constexpr int CK = 32;           // K elements per pipeline step
-constexpr int LDS_LD = CK + 4;   // LDS row pitch in floats (144 B, keeps 16-B alignment)
+// ---- element traits: the kernels are written once for fp32 (exact v_mfma_f32_32x32x2_f32) and bf16 storage with
+// fp32 accumulation (v_mfma_f32_32x32x16_bf16).  All staging moves raw 16-byte chunks (4 floats or 8 bf16); an LDS
+// row holds NP such chunks of a pixel / output channel plus one chunk of padding (pitch 144 B for NP = 8, 80 B for
+// NP = 4: both map any 16 rows of a ds_read_b128 lane group to 16 distinct 4-bank slots).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <typename T> struct Elem;
+template <> struct Elem<float> { static constexpr int VEC = 4; };
+template <> struct Elem<__bf16> { static constexpr int VEC = 8; };
 
-template <int KS, int OUTMODE, int WAVES_M, int WAVES_N, int WMT, int WNT>
-__global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
+// acc += A(32 x kchunk) * B(kchunk x 32) for the 16-byte operand chunks of one lane: fp32 = 4 MFMAs of K = 2 (lane
+// (r, h) holds k = 4h .. 4h+3, element t feeds MFMA t), bf16 = one MFMA of K = 16 (lane holds k = 8h .. 8h+7)
+template <typename T>
+__device__ __forceinline__ f32x16 mma_chunk(const f32x4 a, const f32x4 b, f32x16 c) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], c, 0, 0, 0);
+    return c;
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+}
+
+template <typename T, int KS, int OUTMODE, int WAVES_M, int WAVES_N, int WMT, int WNT>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
   static_assert(WAVES_M * WAVES_N == 4, "4 wavefronts per workgroup");
+  constexpr int VEC = Elem<T>::VEC;      // elements per 16-byte chunk
+  constexpr int CK = 8 * VEC;            // K elements per pipeline step (one 128-byte row)
+  constexpr int LDS_LD = CK + VEC;       // LDS row pitch in elements (144 B)
   constexpr int BM = WAVES_M * WMT * 32;
   constexpr int BN = WAVES_N * WNT * 32;
   constexpr int AR = BM / 32;  // A rows staged per thread
   constexpr int BR = BN / 32;  // B rows staged per thread
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;
-  float* Bs = smem + BM * LDS_LD;
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  T* As = smem;
+  T* Bs = smem + BM * LDS_LD;
+  const T* const in_t = reinterpret_cast<const T*>(d.in);
+  const T* const w_t = reinterpret_cast<const T*>(d.w);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -53,20 +78,20 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
   const int wn = wave % WAVES_N;
   const int bm0 = blockIdx.x * BM;
   const int bn0 = blockIdx.y * BN;
-  const int kq = tid & 7;    // which float4 of the 32-wide K slice this thread stages
+  const int kq = tid & 7;    // which 16-byte chunk of the K slice this thread stages
   const int r0 = tid >> 3;   // first tile row this thread stages (then +32, +64, ...)
 
   // ---- per-row gather state: pixel base pointer + 9-bit tap validity mask ---------------------
-  const float* abase[AR];
+  const T* abase[AR];
   unsigned amask[AR];
   const int HW = d.H * d.W;
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const int m = bm0 + r0 + 32 * i;
-    abase[i] = d.in;
+    abase[i] = in_t;
     amask[i] = 0u;
     if (m < d.M) {
-      abase[i] = d.in + (size_t)m * d.ldin;
+      abase[i] = in_t + (size_t)m * d.ldin;
       if (KS == 2) {
         // stride-2 2x2 gather (ConvTranspose2d dgrad): row m = (img, y, x) over H x W reads the four
         // pixels (2y+dy, 2x+dx) of the Hout x Wout source grid; every tap is in range (Hout >= 2H).
@@ -74,7 +99,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
         const int rem = m - img * HW;
         const int oy = rem / d.W;
         const int ox = rem - oy * d.W;
-        abase[i] = d.in + (((size_t)img * d.Hout + 2 * oy) * d.Wout + 2 * ox) * d.ldin;
+        abase[i] = in_t + (((size_t)img * d.Hout + 2 * oy) * d.Wout + 2 * ox) * d.ldin;
         amask[i] = 0xFu;
       } else if (KS == 3) {
         const int rem = m % HW;
@@ -92,14 +117,14 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
       }
     }
   }
-  const float* wrow[BR];
+  const T* wrow[BR];
 #pragma unroll
-  for (int i = 0; i < BR; ++i) wrow[i] = d.w + (size_t)(bn0 + r0 + 32 * i) * d.Kp + kq * 4;
+  for (int i = 0; i < BR; ++i) wrow[i] = w_t + (size_t)(bn0 + r0 + 32 * i) * d.Kp + kq * VEC;
 
   f32x4 areg[AR];
   f32x4 breg[BR];
   auto load_tiles = [&](int k0) {
-    const int k = k0 + kq * 4;
+    const int k = k0 + kq * VEC;
     int tap = 0;
     long delta = k;
     if (KS == 3) {
@@ -119,7 +144,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const bool ok = kvalid && ((amask[i] >> tap) & 1u);
-      const float* src = ok ? abase[i] + delta : d.in;
+      const T* src = ok ? abase[i] + delta : in_t;
       const f32x4 v = *reinterpret_cast<const f32x4*>(src);
       areg[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -137,10 +162,10 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
 
   const int lr = lane & 31;
   const int lh = lane >> 5;
-  const float* Ap = As + (wm * WMT * 32 + lr) * LDS_LD + lh * 4;
-  const float* Bp = Bs + (wn * WNT * 32 + lr) * LDS_LD + lh * 4;
-  float* Asw = As + r0 * LDS_LD + kq * 4;
-  float* Bsw = Bs + r0 * LDS_LD + kq * 4;
+  const T* Ap = As + (wm * WMT * 32 + lr) * LDS_LD + lh * VEC;
+  const T* Bp = Bs + (wn * WNT * 32 + lr) * LDS_LD + lh * VEC;
+  T* Asw = As + r0 * LDS_LD + kq * VEC;
+  T* Bsw = Bs + r0 * LDS_LD + kq * VEC;
 
   const int nk = d.Kp / CK;
   load_tiles(0);
@@ -152,22 +177,19 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
     __syncthreads();
     if (ks + 1 < nk) load_tiles((ks + 1) * CK);
 #pragma unroll
-    for (int kk = 0; kk < CK / 8; ++kk) {
-      if (ks * CK + kk * 8 >= d.K) break;  // zero K tail (block-uniform): nothing to accumulate
+    for (int kk = 0; kk < 4; ++kk) {
+      if (ks * CK + kk * 2 * VEC >= d.K) break;  // zero K tail (block-uniform): nothing to accumulate
       f32x4 a[WMT], b[WNT];
 #pragma unroll
-      for (int mi = 0; mi < WMT; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(Ap + mi * 32 * LDS_LD + kk * 8);
+      for (int mi = 0; mi < WMT; ++mi) a[mi] = *reinterpret_cast<const f32x4*>(Ap + mi * 32 * LDS_LD + kk * 2 * VEC);
 #pragma unroll
-      for (int ni = 0; ni < WNT; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(Bp + ni * 32 * LDS_LD + kk * 8);
-      // lane (lr, lh) holds k = kk*8 + lh*4 + t for t = 0..3: MFMA t contracts k(lh=0) and k(lh=1);
-      // A and B use the same (lh, t) -> k map, so the permuted k order is consistent.
+      for (int ni = 0; ni < WNT; ++ni) b[ni] = *reinterpret_cast<const f32x4*>(Bp + ni * 32 * LDS_LD + kk * 2 * VEC);
+      // lane (lr, lh) holds the 16-byte chunk k = kk*2*VEC + lh*VEC .. +VEC-1 of its row; A and B use the same
+      // (lh, element) -> k map, so the permuted k order inside a 2*VEC group is consistent.
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int mi = 0; mi < WMT; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < WMT; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < WNT; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], b[ni][t], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < WNT; ++ni) acc[mi][ni] = mma_chunk<T>(a[mi], b[ni], acc[mi][ni]);
     }
     __syncthreads();
   }
@@ -177,7 +199,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
   // accumulator register made the epilogue ~5000 VALU instructions per wave (the K = 64 full-resolution layer
   // spent more time there than in its MFMAs).  Each row's output pixel index is computed ONCE per workgroup
   // into LDS (the tile buffers are free after the last barrier) and read back per register.
-  long long* rowpix = reinterpret_cast<long long*>(smem);
+  long long* rowpix = reinterpret_cast<long long*>(smem_raw);
   if (OUTMODE == 1) {
     for (int rrow = tid; rrow < BM; rrow += 256) {
       const int m = bm0 + rrow;
@@ -196,7 +218,8 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
   // Address arithmetic is kept off the per-element path: a uniform 64-bit tile base + a 32-bit element index
   // (rows of a tile span < 2^31 elements), and the m < M test only exists on the last (partial) row tile.
   const bool full_m = bm0 + BM <= d.M;   // block-uniform
-  float* const tile_out = d.out + (size_t)bm0 * d.ldout + d.coff;
+  T* const out_t = reinterpret_cast<T*>(d.out);
+  T* const tile_out = out_t + (size_t)bm0 * d.ldout + d.coff;
 #pragma unroll
   for (int ni = 0; ni < WNT; ++ni) {
     const int n = bn0 + (wn * WNT + ni) * 32 + lr;
@@ -221,10 +244,10 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
           float v = acc[mi][ni][r] * sc + sh;
           if (d.relu) v = fmaxf(v, 0.f);
           if (OUTMODE == 0) {
-            if (split) d.out2[(size_t)(bm0 + rrow) * d.ld2 + (n - d.split_n)] = v;
-            else tile_out[(unsigned)(rrow * d.ldout + n)] = v;
+            if (split) d.out2[(size_t)(bm0 + rrow) * d.ld2 + (n - d.split_n)] = v;   // always fp32 (GAT scalars)
+            else tile_out[(unsigned)(rrow * d.ldout + n)] = (T)v;
           } else {
-            d.out[(size_t)(rowpix[rrow] + qoff) * d.ldout + d.coff + co] = v;
+            out_t[(size_t)(rowpix[rrow] + qoff) * d.ldout + d.coff + co] = (T)v;
           }
         }
       }
@@ -243,9 +266,13 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmDesc d) {
 // double-buffered LDS panel, so there is a single s_barrier per tap.  The halo of the next chunk is
 // prefetched into registers while the current chunk computes.
 // =================================================================================================
-template <int TH, int WAVES_M, int WAVES_N, int WMT, int WNT, int TPS>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y,
-                                                               const int total_patches, const int patches_per_block) {
+template <typename T, int NP, int TH, int WAVES_M, int WAVES_N, int WMT, int WNT, int TPS>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y,
+                                                           const int total_patches, const int patches_per_block) {
+  constexpr int VEC = Elem<T>::VEC;      // elements per 16-byte chunk
+  constexpr int CK = NP * VEC;           // channels per chunk (NP 16-byte pieces per pixel)
+  constexpr int LDS_LD = CK + VEC;       // LDS row pitch in elements
+  constexpr int RPP = 256 / NP;          // rows staged per pass of the 256 threads
   // A workgroup walks `patches_per_block` consecutive TH x 16 patches (x fastest, then y, then image).  The
   // unit of the pipeline is an ITEM = (patch, 32-channel chunk) = 9/TPS steps of TPS taps each (one s_barrier per
   // step: TPS = 3 gives the narrow N <= 32 tile 96 MFMAs per wave between barriers instead of 32); the halo of
@@ -257,19 +284,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDes
   constexpr int BM = TH * TW;
   constexpr int BN = WAVES_N * WNT * 32;
   static_assert(BM == WAVES_M * WMT * 32 && WAVES_M * WAVES_N == 4, "tile/wave mismatch");
-  constexpr int HR = (HP + 31) / 32;  // halo pixels staged per thread
-  constexpr int BR = BN / 32;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Hs = smem;                  // [HP][36]
-  float* Bs = smem + HP * LDS_LD;    // [2][TPS][BN][36]
+  constexpr int HR = (HP + RPP - 1) / RPP;  // halo pixels staged per thread
+  constexpr int BR = (BN + RPP - 1) / RPP;
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  T* Hs = reinterpret_cast<T*>(smem_raw);   // [HP][LDS_LD]
+  T* Bs = Hs + HP * LDS_LD;                 // [2][TPS][BN][LDS_LD]
+  const T* const in_t = reinterpret_cast<const T*>(d.in);
+  const T* const w_t = reinterpret_cast<const T*>(d.w);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WAVES_N;
   const int wn = wave % WAVES_N;
-  const int kq = tid & 7;
-  const int r0 = tid >> 3;
+  const int kq = tid % NP;
+  const int r0 = tid / NP;
   const int bn0 = blockIdx.y * BN;
   const int p_begin = blockIdx.x * patches_per_block;
   const int npatch = min(patches_per_block, total_patches - p_begin);
@@ -280,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDes
   // and are zeroed by hmask when the registers are written to LDS.
   int hoff[HR];
   unsigned hmask = 0u, hmask_next = 0u;
-  const float* load_base = d.in;
+  const T* load_base = in_t;
   auto setup_patch = [&](int p, int& img, int& y0, int& x0) {
     const int tx = p % tiles_x;
     const int ty = (p / tiles_x) % tiles_y;
@@ -291,11 +320,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDes
   auto setup_load = [&](int p) {
     int img, y0, x0;
     setup_patch(p, img, y0, x0);
-    load_base = d.in + (size_t)img * d.H * d.W * d.ldin + kq * 4;
+    load_base = in_t + (size_t)img * d.H * d.W * d.ldin + kq * VEC;
     unsigned mk = 0u;
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
-      const int hp = r0 + 32 * i;
+      const int hp = r0 + RPP * i;
       const int hy = hp / HWID, hx = hp - hy * HWID;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
       const bool ok = hp < HP && y >= 0 && y < d.H && x >= 0 && x < d.W;
@@ -304,9 +333,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDes
     }
     hmask_next = mk;
   };
-  const float* wrow[BR];
+  const T* wrow[BR];
 #pragma unroll
-  for (int i = 0; i < BR; ++i) wrow[i] = d.w + (size_t)(bn0 + r0 + 32 * i) * d.Kp + kq * 4;
+  for (int i = 0; i < BR; ++i) wrow[i] = w_t + (size_t)(bn0 + r0 + RPP * i) * d.Kp + kq * VEC;   // panel rows padded to 128
 
   f32x4 hreg[HR];
   f32x4 breg[TPS][BR];
@@ -318,8 +347,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDes
   auto store_halo = [&]() {
 #pragma unroll
     for (int i = 0; i < HR; ++i)
-      if (r0 + 32 * i < HP)
-        *reinterpret_cast<f32x4*>(Hs + (r0 + 32 * i) * LDS_LD + kq * 4) = ((hmask >> i) & 1u) ? hreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (r0 + RPP * i < HP)
+        *reinterpret_cast<f32x4*>(Hs + (r0 + RPP * i) * LDS_LD + kq * VEC) = ((hmask >> i) & 1u) ? hreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto load_b = [&](int c, int stp) {   // the TPS weight tiles of step `stp` of chunk c
 #pragma unroll
@@ -334,7 +363,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDes
     for (int tt = 0; tt < TPS; ++tt)
 #pragma unroll
       for (int i = 0; i < BR; ++i)
-        *reinterpret_cast<f32x4*>(Bs + ((buf * TPS + tt) * BN + r0 + 32 * i) * LDS_LD + kq * 4) = breg[tt][i];
+        if (BN % RPP == 0 || r0 + RPP * i < BN)
+          *reinterpret_cast<f32x4*>(Bs + ((buf * TPS + tt) * BN + r0 + RPP * i) * LDS_LD + kq * VEC) = breg[tt][i];
   };
 
   f32x16 acc[WMT][WNT];
@@ -351,9 +381,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDes
 #pragma unroll
   for (int mi = 0; mi < WMT; ++mi) {
     const int pp = (wm * WMT + mi) * 32 + lr;
-    aoff[mi] = ((pp >> 4) * HWID + (pp & 15)) * LDS_LD + lh * 4;
+    aoff[mi] = ((pp >> 4) * HWID + (pp & 15)) * LDS_LD + lh * VEC;
   }
-  const int boff = (wn * WNT * 32 + lr) * LDS_LD + lh * 4;
+  const int boff = (wn * WNT * 32 + lr) * LDS_LD + lh * VEC;
 
   const int nchunks = d.Cp / CK;
   const int nitems = npatch * nchunks;
@@ -386,14 +416,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDes
     // operand fetches are software-pipelined one (tap, kk) group ahead of the MFMAs that consume them, so the
     // ~100-cycle ds_read latency hides under the previous group's MFMAs instead of being exposed 4x per tap
     {
-      constexpr int NG = TPS * (CK / 8);
+      constexpr int NKK = NP / 2;               // 32-byte k groups per chunk
+      constexpr int NG = TPS * NKK;
       f32x4 a[2][WMT], b[2][WNT];
       auto fetch = [&](int gidx, int slot) {
-        const int tt = gidx / (CK / 8), kk = gidx % (CK / 8);
+        const int tt = gidx / NKK, kk = gidx % NKK;
         const int tp = tap * TPS + tt;            // 3x3 tap index
         const int r = tp / 3, s = tp - 3 * r;
-        const float* Ap = Hs + (r * HWID + s) * LDS_LD + kk * 8;
-        const float* Bp = Bs + ((st & 1) * TPS + tt) * BN * LDS_LD + boff + kk * 8;
+        const T* Ap = Hs + (r * HWID + s) * LDS_LD + kk * 2 * VEC;
+        const T* Bp = Bs + ((st & 1) * TPS + tt) * BN * LDS_LD + boff + kk * 2 * VEC;
 #pragma unroll
         for (int mi = 0; mi < WMT; ++mi) a[slot][mi] = *reinterpret_cast<const f32x4*>(Ap + aoff[mi]);
 #pragma unroll
@@ -404,12 +435,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDes
       for (int gidx = 0; gidx < NG; ++gidx) {
         if (gidx + 1 < NG) fetch(gidx + 1, (gidx + 1) & 1);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int mi = 0; mi < WMT; ++mi)
 #pragma unroll
-          for (int mi = 0; mi < WMT; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < WNT; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[gidx & 1][mi][t], b[gidx & 1][ni][t], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < WNT; ++ni) acc[mi][ni] = mma_chunk<T>(a[gidx & 1][mi], b[gidx & 1][ni], acc[mi][ni]);
       }
     }
     if (++tap == SPI) {
@@ -426,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDes
         setup_patch(p_begin + pi, img, y0, x0);
         // uniform 64-bit image base + 32-bit element index; per element only one add (row/col constants fold
         // into scalar multiples of W*ldout and ldout), bounds tests only on patches that cross the image edge
-        float* const img_out = d.out + (size_t)img * d.H * d.W * d.ldout + d.coff;
+        T* const img_out = reinterpret_cast<T*>(d.out) + (size_t)img * d.H * d.W * d.ldout + d.coff;
         const bool interior = (y0 + TH <= d.H) && (x0 + TW <= d.W);   // block-uniform
         const unsigned sA = (unsigned)(d.W * d.ldout), sB = (unsigned)d.ldout;
 #pragma unroll
@@ -447,9 +475,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDes
               if (d.relu) v = fmaxf(v, 0.f);
               const unsigned idx = lane_idx + (unsigned)pyc * sA + (unsigned)pxc * sB;
               if (interior) {
-                if (nvalid) img_out[idx] = v;
+                if (nvalid) img_out[idx] = (T)v;
               } else if (nvalid && y0 + pyc < d.H && x0 + pxc + 4 * lh < d.W) {
-                img_out[idx] = v;
+                img_out[idx] = (T)v;
               }
               acc[mi][ni][rr] = 0.f;
             }
@@ -464,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f32_kernel(const IgemmDes
   }
 }
 
-template <int TH, int WAVES_M, int WAVES_N, int WMT, int WNT, int TPS>
+template <typename T, int NP, int TH, int WAVES_M, int WAVES_N, int WMT, int WNT, int TPS>
 static hipError_t launch_halo(const IgemmDesc& d, hipStream_t s) {
   constexpr int BN = WAVES_N * WNT * 32;
   constexpr int HP = (TH + 2) * 18;
@@ -476,56 +504,82 @@ static hipError_t launch_halo(const IgemmDesc& d, hipStream_t s) {
   if (ppb < 1) ppb = 1;
   if (ppb > g_halo_max_ppb) ppb = g_halo_max_ppb;
   dim3 grid((total + ppb - 1) / ppb, ntn);
-  const size_t lds = (size_t)(HP + 2 * TPS * BN) * LDS_LD * sizeof(float);
+  const size_t lds = (size_t)(HP + 2 * TPS * BN) * (NP * 16 + 16);
   static bool attr_set = false;
   if (!attr_set && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_f32_kernel<TH, WAVES_M, WAVES_N, WMT, WNT, TPS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, NP, TH, WAVES_M, WAVES_N, WMT, WNT, TPS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_halo_f32_kernel<TH, WAVES_M, WAVES_N, WMT, WNT, TPS>), grid, dim3(256), lds, s, d, tiles_x, tiles_y,
-                     total, ppb);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, NP, TH, WAVES_M, WAVES_N, WMT, WNT, TPS>), grid, dim3(256), lds, s, d, tiles_x,
+                     tiles_y, total, ppb);
   return hipGetLastError();
 }
 
-static bool halo_applicable(const IgemmDesc& d) {
-  return d.KS == 3 && d.out_mode == 0 && (d.Cp % CK) == 0 && d.K == 9 * d.Cp && d.ldin == d.Cp &&
-         (long)d.H * d.W * d.ldin < (1l << 31) && (long)d.H * d.W * d.ldout < (1l << 31) && g_use_halo;
+template <typename T>
+static int halo_np(const IgemmDesc& d) {   // 16-byte pieces per pixel chunk the halo kernel can use, 0 = not applicable
+  constexpr int VEC = Elem<T>::VEC;
+  if (!(d.KS == 3 && d.out_mode == 0 && d.K == 9 * d.Cp && d.ldin == d.Cp && (long)d.H * d.W * d.ldin < (1l << 31) &&
+        (long)d.H * d.W * d.ldout < (1l << 31) && g_use_halo))
+    return 0;
+  if (d.Cp % (8 * VEC) == 0) return 8;
+  if (sizeof(T) == 2 && d.Cp % (4 * VEC) == 0) return 4;   // bf16 layers with 32 input channels
+  return 0;
 }
 
-template <int KS, int OUTMODE, int WAVES_M, int WAVES_N, int WMT, int WNT>
+template <typename T, int KS, int OUTMODE, int WAVES_M, int WAVES_N, int WMT, int WNT>
 static hipError_t launch_cfg(const IgemmDesc& d, hipStream_t s) {
   constexpr int BM = WAVES_M * WMT * 32;
   constexpr int BN = WAVES_N * WNT * 32;
   dim3 grid((d.M + BM - 1) / BM, (d.N + BN - 1) / BN);
-  const size_t lds = (size_t)(BM + BN) * LDS_LD * sizeof(float);
-  hipLaunchKernelGGL((igemm_f32_kernel<KS, OUTMODE, WAVES_M, WAVES_N, WMT, WNT>), grid, dim3(256), lds, s, d);
+  const size_t lds = (size_t)(BM + BN) * 144;
+  hipLaunchKernelGGL((igemm_kernel<T, KS, OUTMODE, WAVES_M, WAVES_N, WMT, WNT>), grid, dim3(256), lds, s, d);
   return hipGetLastError();
 }
 
-template <int KS, int OUTMODE>
+template <typename T, int KS, int OUTMODE>
 static hipError_t launch_tiles(const IgemmDesc& d, hipStream_t s) {
-  if (d.N > 64) return launch_cfg<KS, OUTMODE, 2, 2, 2, 2>(d, s);   // 128 x 128 tile, wave 64x64
-  if (d.N > 32) return launch_cfg<KS, OUTMODE, 4, 1, 2, 2>(d, s);   // 256 x 64 tile,  wave 64x64
-  return launch_cfg<KS, OUTMODE, 4, 1, 2, 1>(d, s);                 // 256 x 32 tile,  wave 64x32
+  if (d.N > 64) return launch_cfg<T, KS, OUTMODE, 2, 2, 2, 2>(d, s);   // 128 x 128 tile, wave 64x64
+  if (d.N > 32) return launch_cfg<T, KS, OUTMODE, 4, 1, 2, 2>(d, s);   // 256 x 64 tile,  wave 64x64
+  return launch_cfg<T, KS, OUTMODE, 4, 1, 2, 1>(d, s);                 // 256 x 32 tile,  wave 64x32
+}
+
+template <typename T, int NP>
+static hipError_t launch_halo_tiles(const IgemmDesc& d, hipStream_t s) {
+  if (d.N > 64) return launch_halo<T, NP, 8, 2, 2, 2, 2, 1>(d, s);     // 8x16 px  x 128 ch, wave 64x64
+  if (d.N > 32) return launch_halo<T, NP, 16, 4, 1, 2, 2, 1>(d, s);    // 16x16 px x 64 ch,  wave 64x64
+  if (g_halo_tps3) return launch_halo<T, NP, 16, 4, 1, 2, 1, 3>(d, s);  // 16x16 px x 32 ch, wave 64x32, 3 taps per barrier
+  return launch_halo<T, NP, 16, 4, 1, 2, 1, 1>(d, s);
 }
 
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s) {
   if (d.M <= 0 || d.N <= 0) return hipSuccess;
-  if ((d.Cp & 3) || (d.ldin & 3) || (d.Kp % CK) || d.K > d.Kp) return hipErrorInvalidValue;
+  if ((d.Cp & 3) || (d.ldin & 3) || (d.Kp % 32) || d.K > d.Kp) return hipErrorInvalidValue;
   if (d.out_mode == 1) {
     if (d.KS != 1) return hipErrorInvalidValue;
-    return launch_tiles<1, 1>(d, s);
+    return launch_tiles<float, 1, 1>(d, s);
   }
-  if (halo_applicable(d)) {
-    if (d.N > 64) return launch_halo<8, 2, 2, 2, 2, 1>(d, s);    // 8x16 px  x 128 ch, wave 64x64
-    if (d.N > 32) return launch_halo<16, 4, 1, 2, 2, 1>(d, s);   // 16x16 px x 64 ch,  wave 64x64
-    if (g_halo_tps3) return launch_halo<16, 4, 1, 2, 1, 3>(d, s);  // 16x16 px x 32 ch, wave 64x32, 3 taps per barrier
-    return launch_halo<16, 4, 1, 2, 1, 1>(d, s);
+  if (halo_np<float>(d) == 8) return launch_halo_tiles<float, 8>(d, s);
+  if (d.KS == 3) return launch_tiles<float, 3, 0>(d, s);
+  if (d.KS == 1) return launch_tiles<float, 1, 0>(d, s);
+  if (d.KS == 2) return launch_tiles<float, 2, 0>(d, s);
+  return hipErrorInvalidValue;
+}
+
+// bf16 storage, fp32 accumulate (inference): `in`, `w`, `out` of the descriptor point to bf16 data, ld/Cp/K/Kp are in
+// elements (Cp % 8 == 0, Kp % 64 == 0); scale/shift stay fp32.
+hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s) {
+  if (d.M <= 0 || d.N <= 0) return hipSuccess;
+  if ((d.Cp & 7) || (d.ldin & 7) || (d.Kp % 64) || d.K > d.Kp || d.split_n) return hipErrorInvalidValue;
+  if (d.out_mode == 1) {
+    if (d.KS != 1) return hipErrorInvalidValue;
+    return launch_tiles<__bf16, 1, 1>(d, s);
   }
-  if (d.KS == 3) return launch_tiles<3, 0>(d, s);
-  if (d.KS == 1) return launch_tiles<1, 0>(d, s);
-  if (d.KS == 2) return launch_tiles<2, 0>(d, s);
+  const int np = halo_np<__bf16>(d);
+  if (np == 8) return launch_halo_tiles<__bf16, 8>(d, s);
+  if (np == 4) return launch_halo_tiles<__bf16, 4>(d, s);
+  if (d.KS == 3) return launch_tiles<__bf16, 3, 0>(d, s);
+  if (d.KS == 1) return launch_tiles<__bf16, 1, 0>(d, s);
   return hipErrorInvalidValue;
 }
 

@@ -22,9 +22,10 @@ WsPlan plan_ws(const mgu_ctx* c, int B, int H, int W) {
   level_dims(H, W, c->depth, hs, wsz);
   WsPlan p;
   size_t off = 0;
-  auto take = [&](size_t floats) {
+  const size_t es = c->dtype == MGU_DTYPE_BF16 ? 2 : 4;
+  auto take = [&](size_t elems) {
     size_t o = off;
-    off += (floats * sizeof(float) + 255) / 256 * 256;
+    off += (elems * es + 255) / 256 * 256;
     return o;
   };
   p.xin = take((size_t)B * H * W * c->Cp0);
@@ -89,10 +90,12 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
   if (in_ch < 1 || ncls < 1 || feat < 4 || (feat & 3) || depth < 1 || depth > 8)
     return fail(c, MGU_ERR_INVALID, "unsupported UNet(%d,%d,%d,%d): init_features must be a positive multiple of 4, depth 1..8",
                 in_ch, ncls, feat, depth);
-  if (dtype != MGU_DTYPE_F32) return fail(c, MGU_ERR_INVALID, "dtype %d not built yet (fp32 only)", dtype);
+  if (dtype != MGU_DTYPE_F32 && dtype != MGU_DTYPE_BF16) return fail(c, MGU_ERR_INVALID, "unknown dtype %d", dtype);
+  if (dtype == MGU_DTYPE_BF16 && ((feat & 7) || ncls > 4))
+    return fail(c, MGU_ERR_INVALID, "bf16 storage needs init_features %% 8 == 0 (16-byte lanes of 8 bf16) and <= 4 classes");
   HIPCHK(c, hipSetDevice(c->device));
   c->in_ch = in_ch, c->ncls = ncls, c->feat = feat, c->depth = depth, c->dtype = dtype;
-  c->Cp0 = rup(in_ch, 4);
+  c->Cp0 = rup(in_ch, dtype == MGU_DTYPE_BF16 ? 8 : 4);
   c->layers.clear();
   auto add_block = [&](const std::string& prefix, int cin, int cp, int cout) {  // ConvBlock, unet_encoder.py:4-25
     for (int j = 0; j < 2; ++j) {
@@ -139,7 +142,7 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
   size_t total = 0;
   for (auto& L : c->layers) {
     L.K = L.KS * L.KS * L.Cp;
-    L.Kp = rup(L.K, 32);
+    L.Kp = rup(L.K, dtype == MGU_DTYPE_BF16 ? 64 : 32);   // one 128-byte LDS row of k per pipeline step
     L.N = L.convt ? 4 * L.Cout : L.Cout;
     L.Np = rup(L.N, 128);
     total += (size_t)L.Np * L.Kp + 2 * (size_t)L.Np + (L.bn.empty() ? 0 : 4 * (size_t)L.Np);
@@ -243,13 +246,13 @@ int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void*
       if ((rc = get(cw + ".weight", (int64_t)L.Cin * L.Cout * 4, &w))) return rc;
       if ((rc = get(cw + ".bias", L.Cout, &b))) return rc;
       L.w_src = w, L.b_src = b;
-      HIPCHK(c, launch_pack_convt_w(w, L.wp, L.Cin, L.Cout, L.Kp, s));
+      HIPCHK(c, launch_pack_convt_w(w, L.wp, c->dtype, L.Cin, L.Cout, L.Kp, s));
       HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 4, s));  // scale unused (nullptr at launch)
     } else {
       if ((rc = get(cw + ".weight", (int64_t)L.Cout * L.Cin * L.KS * L.KS, &w))) return rc;
       if ((rc = get(cw + ".bias", L.Cout, &b))) return rc;
       L.w_src = w, L.b_src = b;
-      HIPCHK(c, launch_pack_conv_w(w, L.wp, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
+      HIPCHK(c, launch_pack_conv_w(w, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
       if (!L.bn.empty()) {
         const float *g, *be, *rm, *rv;
         const std::string bn = L.prefix + L.bn;
@@ -286,15 +289,15 @@ int mgu_unet_reserve(mgu_ctx* c, int B, int H, int W, int training) {
 
 }  // extern "C"
 
-int mgud::run_layer(mgu_ctx* c, const Layer& L, const float* in, int ldin, int B, int H, int W, float* out, int ldout,
+int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int B, int H, int W, void* out_v, int ldout,
                     int coff, int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s) {
   IgemmDesc d;
   memset(&d, 0, sizeof d);
-  d.in = in;
+  d.in = (const float*)in_v;   // element type follows c->dtype; the descriptor carries raw pointers
   d.w = L.wp;
   d.scale = scale;
   d.shift = shift;
-  d.out = out;
+  d.out = (float*)out_v;
   d.M = B * H * W;
   d.H = H;
   d.W = W;
@@ -312,11 +315,12 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const float* in, int ldin, int B
   d.Hout = Hout;
   d.Wout = Wout;
   ProfScope ps(c, s);
-  HIPCHK(c, launch_igemm_f32(d, s));
+  if (c->dtype == MGU_DTYPE_BF16) HIPCHK(c, launch_igemm_bf16(d, s));
+  else HIPCHK(c, launch_igemm_f32(d, s));
   return MGU_OK;
 }
 
-static int run_conv(mgu_ctx* c, const Layer& L, const float* in, int ldin, int B, int H, int W, float* out, int ldout,
+static int run_conv(mgu_ctx* c, const Layer& L, const void* in, int ldin, int B, int H, int W, void* out, int ldout,
                     int coff, int relu, int Hout, int Wout, hipStream_t s) {  // eval: folded BN scale/shift
   return run_layer(c, L, in, ldin, B, H, W, out, ldout, coff, relu, L.bn.empty() ? nullptr : L.scale, L.shift, Hout, Wout, s);
 }
@@ -337,15 +341,18 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
     if (!cat_dev[i] || !feat_dev[i]) return fail(c, MGU_ERR_INVALID, "NULL cat/feat buffer %d", i);
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)hip_stream;
+  if (training && c->dtype != MGU_DTYPE_F32)
+    return fail(c, MGU_ERR_STATE, "training runs in fp32 only (bf16 storage is an inference mode)");
   if (training)  // batch-statistics BatchNorm, running-stat update, activations kept for mgu_unet_backward
     return unet_forward_train(c, (const float*)x_dev, xs_n, xs_c, xs_h, xs_w, B, H, W, (float*)logits_dev, cat_dev, feat_dev, s);
   const WsPlan plan = plan_ws(c, B, H, W);
   int rc = ensure(c, &c->ws, &c->ws_bytes, plan.total);
   if (rc) return rc;
   char* ws = (char*)c->ws;
-  float* xin = (float*)(ws + plan.xin);
-  float* tmp = (float*)(ws + plan.tmp);
-  float* bott = (float*)(ws + plan.bott);
+  const size_t es = c->dtype == MGU_DTYPE_BF16 ? 2 : 4;
+  void* xin = ws + plan.xin;
+  void* tmp = ws + plan.tmp;
+  void* bott = ws + plan.bott;
   std::vector<int> hs, wsz;
   level_dims(H, W, depth, hs, wsz);
 
@@ -359,19 +366,19 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
   // odd sizes: F.pad (unet_decoder.py:46-47) leaves a zero row/column in the up-sampled half
   for (int i = 0; i < depth; ++i)
     if (2 * hs[i + 1] != hs[i] || 2 * wsz[i + 1] != wsz[i])
-      HIPCHK(c, hipMemsetAsync(cat_dev[i], 0, (size_t)B * hs[i] * wsz[i] * 2 * ((size_t)c->feat << i) * sizeof(float), s));
+      HIPCHK(c, hipMemsetAsync(cat_dev[i], 0, (size_t)B * hs[i] * wsz[i] * 2 * ((size_t)c->feat << i) * es, s));
 
-  HIPCHK(c, launch_pack_input((const float*)x_dev, xin, B, c->in_ch, c->Cp0, H, W, xs_n, xs_c, xs_h, xs_w, s));
+  HIPCHK(c, launch_pack_input((const float*)x_dev, xin, c->dtype, B, c->in_ch, c->Cp0, H, W, xs_n, xs_c, xs_h, xs_w, s));
 
   int li = 0;
-  const float* cur = xin;
+  const void* cur = xin;
   int cur_ld = c->Cp0;
   for (int i = 0; i < depth; ++i) {  // encoder, unet_encoder.py:67-70
     const int C = c->feat << i;
     if ((rc = run_conv(c, c->layers[li++], cur, cur_ld, B, hs[i], wsz[i], tmp, C, 0, 1, 0, 0, s))) return rc;
-    if ((rc = run_conv(c, c->layers[li++], tmp, C, B, hs[i], wsz[i], (float*)cat_dev[i], 2 * C, 0, 1, 0, 0, s))) return rc;
-    float* pooled = (float*)(ws + plan.pooled[i]);
-    HIPCHK(c, launch_maxpool2((const float*)cat_dev[i], 2 * C, pooled, B, hs[i], wsz[i], C, s));
+    if ((rc = run_conv(c, c->layers[li++], tmp, C, B, hs[i], wsz[i], cat_dev[i], 2 * C, 0, 1, 0, 0, s))) return rc;
+    void* pooled = ws + plan.pooled[i];
+    HIPCHK(c, launch_maxpool2(cat_dev[i], 2 * C, pooled, c->dtype, B, hs[i], wsz[i], C, s));
     cur = pooled;
     cur_ld = C;
   }
@@ -386,12 +393,11 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
     const int i = depth - 1 - b;
     const int C = c->feat << i;
     // ConvTranspose2d(k2,s2) -> pixel-shuffle store into channels [C, 2C) of the concat buffer (:36,:53)
-    if ((rc = run_conv(c, c->layers[li++], cur, cur_ld, B, hs[i + 1], wsz[i + 1], (float*)cat_dev[i], 2 * C, C, 0, hs[i],
-                       wsz[i], s)))
+    if ((rc = run_conv(c, c->layers[li++], cur, cur_ld, B, hs[i + 1], wsz[i + 1], cat_dev[i], 2 * C, C, 0, hs[i], wsz[i], s)))
       return rc;
-    if ((rc = run_conv(c, c->layers[li++], (const float*)cat_dev[i], 2 * C, B, hs[i], wsz[i], tmp, C, 0, 1, 0, 0, s))) return rc;
-    if ((rc = run_conv(c, c->layers[li++], tmp, C, B, hs[i], wsz[i], (float*)feat_dev[i], C, 0, 1, 0, 0, s))) return rc;
-    cur = (const float*)feat_dev[i];
+    if ((rc = run_conv(c, c->layers[li++], cat_dev[i], 2 * C, B, hs[i], wsz[i], tmp, C, 0, 1, 0, 0, s))) return rc;
+    if ((rc = run_conv(c, c->layers[li++], tmp, C, B, hs[i], wsz[i], feat_dev[i], C, 0, 1, 0, 0, s))) return rc;
+    cur = feat_dev[i];
     cur_ld = C;
   }
   // final 1x1 conv (:143): a few output channels -> HBM-bound head kernel reading the reference's (ncls, C) weight
@@ -399,8 +405,9 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
     const Layer& F = c->layers[li++];
     if (c->ncls <= 4 && F.w_src && F.b_src) {
       ProfScope ps(c, s);
-      HIPCHK(c, launch_conv1x1_head(cur, cur_ld, F.Cin, F.w_src, F.b_src, (float*)logits_dev, c->ncls, c->ncls, (int64_t)B * H * W, s));
-    } else if ((rc = run_conv(c, F, cur, cur_ld, B, H, W, (float*)logits_dev, c->ncls, 0, 0, 0, 0, s))) {
+      HIPCHK(c, launch_conv1x1_head(cur, c->dtype, cur_ld, F.Cin, F.w_src, F.b_src, (float*)logits_dev, c->ncls, c->ncls,
+                                    (int64_t)B * H * W, s));   // logits are always fp32
+    } else if ((rc = run_conv(c, F, cur, cur_ld, B, H, W, logits_dev, c->ncls, 0, 0, 0, 0, s))) {
       return rc;
     }
   }
@@ -437,7 +444,7 @@ int mgu_conv2d_nhwc(mgu_ctx* c, const void* in_dev, int B, int H, int W, int Cin
   float *sc, *sh;
   int rc = block_scratch(c, L.Np, L.Kp, &L.wp, &sc, &sh, s);
   if (rc) return rc;
-  HIPCHK(c, launch_pack_conv_w((const float*)w_dev, L.wp, Cout, Cin, Cin, ksize, L.Kp, s));
+  HIPCHK(c, launch_pack_conv_w((const float*)w_dev, L.wp, 0, Cout, Cin, Cin, ksize, L.Kp, s));
   IgemmDesc d;
   memset(&d, 0, sizeof d);
   d.in = (const float*)in_dev, d.w = L.wp, d.out = (float*)out_dev;
@@ -468,7 +475,7 @@ int mgu_conv_transpose2x2_nhwc(mgu_ctx* c, const void* in_dev, int B, int H, int
   float *wp, *sc, *sh;
   int rc = block_scratch(c, Np, Kp, &wp, &sc, &sh, s);
   if (rc) return rc;
-  HIPCHK(c, launch_pack_convt_w((const float*)w_dev, wp, Cin, Cout, Kp, s));
+  HIPCHK(c, launch_pack_convt_w((const float*)w_dev, wp, 0, Cin, Cout, Kp, s));
   IgemmDesc d;
   memset(&d, 0, sizeof d);
   d.in = (const float*)in_dev, d.w = wp, d.out = (float*)out_dev;
@@ -489,7 +496,7 @@ int mgu_maxpool2x2_nhwc(mgu_ctx* c, const void* in_dev, int ld_in, int B, int H,
   if (!in_dev || !out_dev || B < 1 || H < 2 || W < 2 || Cc < 4 || (Cc & 3) || ld_in < Cc || (ld_in & 3))
     return fail(c, MGU_ERR_INVALID, "bad maxpool args (C and ld_in must be multiples of 4, H,W >= 2)");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, launch_maxpool2((const float*)in_dev, ld_in, (float*)out_dev, B, H, W, Cc, (hipStream_t)hip_stream));
+  HIPCHK(c, launch_maxpool2(in_dev, ld_in, out_dev, 0, B, H, W, Cc, (hipStream_t)hip_stream));
   return MGU_OK;
 }
 
@@ -501,13 +508,16 @@ int mgu_argmax_classes(mgu_ctx* c, const void* logits_dev, int64_t npix, int num
   return MGU_OK;
 }
 
-int mgu_patch_mean(mgu_ctx* c, const void* feat_dev, int B, int H, int W, int C, int patch, void* out_dev,
+int mgu_patch_mean(mgu_ctx* c, const void* feat_dev, int feat_dtype, int B, int H, int W, int C, int patch, void* out_dev,
                    void* hip_stream) {
   if (!c || !feat_dev || !out_dev || B < 1 || H < 1 || W < 1 || patch < 1)
     return fail(c, MGU_ERR_INVALID, "bad patch_mean args");
-  if ((C & 3) || C < 4 || C > 256) return fail(c, MGU_ERR_INVALID, "patch_mean needs C %% 4 == 0 and 4 <= C <= 256 (got %d)", C);
+  if (feat_dtype != MGU_DTYPE_F32 && feat_dtype != MGU_DTYPE_BF16) return fail(c, MGU_ERR_INVALID, "unknown dtype %d", feat_dtype);
+  const int vec = feat_dtype == MGU_DTYPE_BF16 ? 8 : 4;
+  if ((C % vec) || C < vec || C > 256)
+    return fail(c, MGU_ERR_INVALID, "patch_mean needs C %% %d == 0 and C <= 256 (got %d)", vec, C);
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, launch_patch_mean((const float*)feat_dev, (float*)out_dev, B, H, W, C, patch, (hipStream_t)hip_stream));
+  HIPCHK(c, launch_patch_mean(feat_dev, feat_dtype, (float*)out_dev, B, H, W, C, patch, (hipStream_t)hip_stream));
   return MGU_OK;
 }
 
@@ -548,7 +558,7 @@ int mgu_gat_layer_forward(mgu_ctx* c, const void* X_dev, int N, int Fin, const i
   HIPCHK(c, hipMemsetAsync(gmax, 0, (size_t)num_graphs * heads * 4, s));
   // nn.Linear weight (F',Fin) stacked over heads is already the [N][K] panel (K padded to 32); rows HF.. hold
   // W^T a_src / W^T a_tgt so the same GEMM emits the attention scalars s, t (graph_attention.py:53,57-64)
-  HIPCHK(c, launch_pack_conv_w((const float*)W_dev, wp, HF, Fin, Fin, 1, Kp, s));
+  HIPCHK(c, launch_pack_conv_w((const float*)W_dev, wp, 0, HF, Fin, Fin, 1, Kp, s));
   HIPCHK(c, launch_gat_wa_rows((const float*)W_dev, (const float*)a_dev, wp, heads, Fout_head, Fin, Kp, s));
   IgemmDesc d;
   memset(&d, 0, sizeof d);

@@ -170,7 +170,7 @@ int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t x
     if (2 * hs[i + 1] != hs[i] || 2 * ws[i + 1] != ws[i])
       HIPCHK(c, hipMemsetAsync(cat_dev[i], 0, (size_t)B * hs[i] * ws[i] * 2 * ((size_t)c->feat << i) * sizeof(float), s));
   float* xin = at(c, p.xin);
-  HIPCHK(c, launch_pack_input(x, xin, B, c->in_ch, c->Cp0, H, W, xs_n, xs_c, xs_h, xs_w, s));
+  HIPCHK(c, launch_pack_input(x, xin, 0, B, c->in_ch, c->Cp0, H, W, xs_n, xs_c, xs_h, xs_w, s));
 
   c->t_cat.assign(d, nullptr);
   c->t_feat.assign(d, nullptr);
@@ -183,7 +183,7 @@ int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t x
     if ((rc = conv_bn_relu_train(c, c->layers[li], cur, ld, B, hs[i], ws[i], at(c, p.z[li]), at(c, p.y1[li]), C, sums, red, s))) return rc;
     if ((rc = conv_bn_relu_train(c, c->layers[li + 1], at(c, p.y1[li]), C, B, hs[i], ws[i], at(c, p.z[li + 1]), cat, 2 * C, sums, red, s))) return rc;
     float* pooled = at(c, p.pooled[i]);
-    HIPCHK(c, launch_maxpool2(cat, 2 * C, pooled, B, hs[i], ws[i], C, s));
+    HIPCHK(c, launch_maxpool2(cat, 2 * C, pooled, 0, B, hs[i], ws[i], C, s));
     c->t_cat[i] = cat, c->t_pooled[i] = pooled;
     cur = pooled, ld = C;
   }
@@ -208,7 +208,7 @@ int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t x
   }
   Layer& F = c->layers.back();
   if (c->ncls <= 4) {
-    HIPCHK(c, launch_conv1x1_head(cur, ld, F.Cin, F.w_src, F.b_src, logits, c->ncls, c->ncls, (int64_t)B * H * W, s));
+    HIPCHK(c, launch_conv1x1_head(cur, 0, ld, F.Cin, F.w_src, F.b_src, logits, c->ncls, c->ncls, (int64_t)B * H * W, s));
   } else if ((rc = run_layer(c, F, cur, ld, B, H, W, logits, c->ncls, 0, 0, nullptr, F.shift, 0, 0, s))) {
     return rc;
   }

@@ -81,13 +81,16 @@ class PatchGraphConstructor:
         if not feat_nchw.is_cuda:
             raise RuntimeError("patch_mean_features runs only on a HIP device")
         B, Cc, H, W = feat_nchw.shape
+        if feat_nchw.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f"expected float32 or bfloat16 features, got {feat_nchw.dtype}")
+        code = 1 if feat_nchw.dtype == torch.bfloat16 else 0
         nhwc = feat_nchw.permute(0, 2, 3, 1).contiguous()  # no copy when storage is already NHWC
         nph, npw = (H + self.patch_size - 1) // self.patch_size, (W + self.patch_size - 1) // self.patch_size
         out = torch.empty((B * nph * npw, Cc), device=feat_nchw.device, dtype=torch.float32)
         from .gat import _context
         ctx = _context(feat_nchw.device)
         with torch.cuda.device(feat_nchw.device):
-            rc = _lib.lib().mgu_patch_mean(ctx.handle, nhwc.data_ptr(), B, H, W, Cc, self.patch_size, out.data_ptr(),
+            rc = _lib.lib().mgu_patch_mean(ctx.handle, nhwc.data_ptr(), code, B, H, W, Cc, self.patch_size, out.data_ptr(),
                                            _lib.current_stream_ptr(feat_nchw.device))
         _lib.check(rc, ctx.handle)
         return out

@@ -77,12 +77,14 @@ class UNetDecoder(nn.Module):
 class UNet(nn.Module):
     """Drop-in for model/unet/unet_model.py:6-36.  forward(x) -> (logits, skips, decoder_feats)."""
 
-    def __init__(self, in_channels=3, num_classes=2, init_features=32, depth=4):
+    def __init__(self, in_channels=3, num_classes=2, init_features=32, depth=4, compute_dtype=torch.float32):
         super().__init__()
         if init_features % 4 != 0:
             raise ValueError("init_features must be a multiple of 4 (NHWC 16-byte lanes)")
         self.in_channels, self.num_classes = in_channels, num_classes
         self.init_features, self.depth = init_features, depth
+        self.compute_dtype = torch.float32
+        self.set_compute_dtype(compute_dtype)
         self.encoder = UNetEncoder(in_channels=in_channels, init_features=init_features, depth=depth)
         self.decoder = UNetDecoder(num_classes=num_classes, init_features=init_features, depth=depth)
         self._ctx = {}          # device index -> _lib.Context
@@ -90,6 +92,17 @@ class UNet(nn.Module):
         self._slots = None      # [(state_dict key, owning dict, name)]: survives .to() / load_state_dict
 
     # ---- plumbing -------------------------------------------------------------------------
+    def set_compute_dtype(self, dtype) -> "UNet":
+        """torch.float32: exact-fp32 MFMA (default, the reference's precision).  torch.bfloat16: bf16 storage of
+        activations and packed weights with fp32 accumulation (BASELINE config 3, inference only); parameters stay
+        fp32 masters, inputs and logits stay fp32, skips / decoder features come back as bfloat16 tensors."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+        if dtype == torch.bfloat16 and (getattr(self, "init_features", 8) % 8 or getattr(self, "num_classes", 1) > 4):
+            raise ValueError("bfloat16 storage needs init_features % 8 == 0 and at most 4 classes")
+        self.compute_dtype = dtype
+        return self
+
     def __getstate__(self):  # contexts hold device handles: never pickled / deep-copied
         d = self.__dict__.copy()
         d["_ctx"], d["_loaded_sig"], d["_slots"] = {}, {}, None
@@ -98,12 +111,15 @@ class UNet(nn.Module):
 
     def _context(self, device: torch.device) -> "_lib.Context":
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        ctx = self._ctx.get(idx)
+        code = 1 if self.compute_dtype == torch.bfloat16 else 0
+        key = (idx, code)
+        ctx = self._ctx.get(key)
         if ctx is None:
             ctx = _lib.Context(idx)
+            ctx.key = key
             _lib.check(_lib.lib().mgu_unet_configure(ctx.handle, self.in_channels, self.num_classes,
-                                                     self.init_features, self.depth, 0), ctx.handle)
-            self._ctx[idx] = ctx
+                                                     self.init_features, self.depth, code), ctx.handle)
+            self._ctx[key] = ctx
         return ctx
 
     def _named_tensors(self):
@@ -122,7 +138,7 @@ class UNet(nn.Module):
     def _sync_weights(self, ctx, device) -> None:
         tensors = self._named_tensors()
         sig = tuple((v.data_ptr(), v._version) for _, v in tensors)
-        if self._loaded_sig.get(ctx.device_index) == sig:
+        if self._loaded_sig.get(ctx.key) == sig:
             return
         descs, keep = [], []
         for k, v in tensors:
@@ -137,7 +153,7 @@ class UNet(nn.Module):
         arr = (_lib.TensorDesc * len(descs))(*descs)
         _lib.check(_lib.lib().mgu_unet_load_weights(ctx.handle, arr, len(descs), _lib.current_stream_ptr(device)),
                    ctx.handle)
-        self._loaded_sig[ctx.device_index] = sig
+        self._loaded_sig[ctx.key] = sig
 
     def mark_parameters_changed(self) -> None:
         """Parameters/buffers were modified behind torch's back (Adam step or BN running stats written by
@@ -163,6 +179,8 @@ class UNet(nn.Module):
                                "'cuda' -- there is deliberately no CPU fallback")
         if x.dtype != torch.float32:
             raise TypeError(f"expected float32 input, got {x.dtype}")
+        if self.training and self.compute_dtype != torch.float32:
+            raise RuntimeError("bfloat16 storage is an inference mode: call .eval() or set_compute_dtype(torch.float32)")
         B, Cin, H, W = x.shape
         if Cin != self.in_channels:
             raise RuntimeError(f"expected {self.in_channels} input channels, got {Cin}")
@@ -176,9 +194,10 @@ class UNet(nn.Module):
             ws.append(ws[-1] // 2)
         with torch.cuda.device(dev):
             # NHWC storage, NCHW logical view (channels_last semantics without its size-1 ambiguities)
+            adt = self.compute_dtype  # activations the forward stores; logits are always fp32
             logits = torch.empty((B, H, W, self.num_classes), device=dev, dtype=torch.float32)
-            cats = [torch.empty((B, hs[i], ws[i], 2 * (f << i)), device=dev, dtype=torch.float32) for i in range(d)]
-            feats = [torch.empty((B, hs[i], ws[i], f << i), device=dev, dtype=torch.float32) for i in range(d)]
+            cats = [torch.empty((B, hs[i], ws[i], 2 * (f << i)), device=dev, dtype=adt) for i in range(d)]
+            feats = [torch.empty((B, hs[i], ws[i], f << i), device=dev, dtype=adt) for i in range(d)]
             cat_ptrs = (C.c_void_p * d)(*[t.data_ptr() for t in cats])
             feat_ptrs = (C.c_void_p * d)(*[t.data_ptr() for t in feats])
             sn, sc, sh, sw = x.stride()
