@@ -1,4 +1,5 @@
-// Implicit-GEMM convolution / transposed-convolution / linear kernel for gfx950 (CDNA4), fp32.
+// Implicit-GEMM convolution / transposed-convolution / linear kernels for gfx950 (CDNA4): exact fp32, and bf16
+// storage with fp32 accumulation (one source, templated on the element type).
 //
 // Replaces the aten::mkldnn_convolution calls behind ConvBlock (model/unet/unet_encoder.py:4-25),
 // ConvTranspose2d (model/unet/unet_decoder.py:25,36), final_conv (unet_decoder.py:117,143) and the
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
   if (npatch <= 0) return;
 
   // halo staging map of the patch being LOADED: thread -> (halo pixel r0 + 32 i, float4 kq).  Out-of-image
-  // pixels keep offset 0 (a mapped address: the loads stay unconditional, see the note in igemm_f32_kernel)
+  // pixels keep offset 0 (a mapped address: the loads stay unconditional, see the note in igemm_kernel)
   // and are zeroed by hmask when the registers are written to LDS.
   int hoff[HR];
   unsigned hmask = 0u, hmask_next = 0u;
@@ -396,7 +397,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
   load_b(0, 1);              // nsteps >= 3
   int c = 0, tap = 0, pi = 0;   // chunk / step-in-item / patch of the step being computed
   int c2 = 0, t2 = 2;           // chunk / step-in-item of step st + 2 (weights depend on (chunk, step) only)
-  if (SPI == 3 && nchunks == 1) { /* t2 = 2 is still inside item 0 */ }
   for (int st = 0; st < nsteps; ++st) {
     __syncthreads();  // Bs[st&1] (and a fresh halo when tap == 0) visible; Bs[(st+1)&1] no longer read
     if (st + 1 < nsteps) store_b((st + 1) & 1);

@@ -1,5 +1,5 @@
 // C-ABI of libmgunet.so (see include/mgunet.h): context, weight repacking, U-Net forward schedule,
-// GAT layer schedule.  Host orchestration only -- every arithmetic op is a kernel in igemm_f32.hip,
+// GAT layer schedule.  Host orchestration only -- every arithmetic op is a kernel in igemm.hip,
 // elementwise.hip or gat.hip.  No CPU fallback exists: without a HIP device every call fails.
 #include "ctx.h"
 

@@ -2,7 +2,7 @@
 // (dgrad / wgrad / BN / ReLU / MaxPool / ConvTranspose / 1x1), softmax cross-entropy, Adam.
 // Replaces the autograd graph the reference builds at scripts/train_segmentation.py:121-134
 // (optimizer.zero_grad -> model(images) -> CrossEntropyLoss -> loss.backward -> optimizer.step).
-// Host orchestration only; kernels live in igemm_f32.hip, wgrad_f32.hip, train_kernels.hip.
+// Host orchestration only; kernels live in igemm.hip, wgrad_f32.hip, train_kernels.hip.
 #include <algorithm>
 
 #include "ctx.h"
