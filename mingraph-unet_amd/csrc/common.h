@@ -57,10 +57,15 @@ struct WgradDesc {
   int M, H, W;      // rows enumerate (img, y, x) over H x W
   int Hs, Ws;       // KS == 2 source grid
   int N, K, Kp;     // Dw panel [>=N][Kp]
-  float* dw;        // accumulated with float atomics: zero it first
+  float* dw;        // [groups][>=N][Kp] partial panels; the launcher sets `groups`.  groups == 1: accumulated with
+                    // float atomics into ONE panel the caller zeroed; groups > 1: plain stores, every element of
+                    // every partial panel written (no zeroing needed), the caller sums the panels
+  size_t dw_capacity;  // floats available at dw
+  int groups;          // set by the launcher
   int rows_per_split;  // set by the launcher
 };
-hipError_t launch_wgrad_f32(const WgradDesc& d, hipStream_t s);
+hipError_t launch_wgrad_f32(WgradDesc& d, hipStream_t s);
+void set_wgrad_halo(bool on);
 
 // train_kernels.hip
 size_t chan_reduce_work_bytes(int Cmax);
@@ -84,7 +89,8 @@ hipError_t launch_ce(const float* logits, const int64_t* labels, int64_t M, int 
                      double* loss_sum, float* loss_out, hipStream_t s);
 hipError_t launch_pack_dgrad_w(const float* w, float* wp, int Cout, int Cin, int Cop, int KS, int Kp, hipStream_t s);
 hipError_t launch_pack_convt_dgrad_w(const float* w, float* wp, int Cin, int Cout, int Kp, hipStream_t s);
-hipError_t launch_unpack_conv_grad(const float* dwp, float* g, int Cout, int Cin, int Cp, int KS, int Kp, hipStream_t s);
+hipError_t launch_unpack_conv_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cout, int Cin, int Cp, int KS,
+                                   int Kp, hipStream_t s);
 hipError_t launch_unpack_convt_grad(const float* dwp, float* g, int Cin, int Cout, int Kp, hipStream_t s);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                        float wd, int step, float grad_scale, hipStream_t s);

@@ -61,6 +61,8 @@ int mgu_create(int device_id, mgu_ctx** out) {
   c->device = device_id;
   const char* nh = getenv("MGU_NO_HALO");
   set_use_halo(!(nh && nh[0] == '1'));
+  const char* nw = getenv("MGU_NO_WGRAD_HALO");
+  set_wgrad_halo(!(nw && nw[0] == '1'));
   const char* t1 = getenv("MGU_HALO_TPS1");
   set_halo_tps3(!(t1 && t1[0] == '1'));
   const char* pp = getenv("MGU_HALO_PPB");

@@ -13,7 +13,7 @@ using namespace mgud;
 namespace {
 
 struct TPlan {
-  size_t xin = 0, bott = 0, ta = 0, tb = 0, tc = 0, dwp = 0, dgp = 0, sums = 0, red = 0, total = 0;
+  size_t xin = 0, bott = 0, ta = 0, tb = 0, tc = 0, dwp = 0, dwp_floats = 0, dgp = 0, sums = 0, red = 0, total = 0;
   std::vector<size_t> z, y1, pooled, dcat;
 };
 
@@ -56,7 +56,8 @@ TPlan plan_train(const mgu_ctx* c, int B, int H, int W) {
     const size_t cop = rup(L.Cout, 4);
     pmax = std::max(pmax, (size_t)rup(L.Cp, 128) * rup(L.KS * L.KS * (int)cop * (L.convt ? 4 : 1), 32));  // dgrad panel
   }
-  p.dwp = fl(pmax);
+  p.dwp_floats = std::max(pmax, (size_t)12 << 20);   // >= 48 MB: room for the atomics-free wgrad's partial panels
+  p.dwp = fl(p.dwp_floats);
   p.dgp = fl(pmax);
   p.sums = take(sizeof(double) * 2 * ((size_t)c->feat << d) + 64);
   p.red = take(chan_reduce_work_bytes(c->feat << d));
@@ -85,6 +86,7 @@ struct Bwd {
   mgu_ctx* c;
   hipStream_t s;
   float *ta, *tb, *dwp, *dgp, *flat;
+  size_t dwp_floats;
   double *sums, *red;
 };
 
@@ -99,12 +101,15 @@ int conv_wgrad(Bwd& w, const Layer& L, const float* dz) {
   d.M = L.t_B * L.t_H * L.t_W, d.H = L.t_H, d.W = L.t_W;
   d.N = L.Cout, d.K = L.K, d.Kp = L.Kp;
   d.dw = w.dwp;
+  d.dw_capacity = w.dwp_floats;
+  // the atomic path needs ONE zeroed panel; the halo path overwrites its partial panels, so zeroing the first
+  // panel is all either needs (and costs one small memset)
   HIPCHK(c, hipMemsetAsync(w.dwp, 0, (size_t)rup(L.Cout, 4) * L.Kp * sizeof(float), w.s));
   {
     ProfScope ps(c, w.s);
     HIPCHK(c, launch_wgrad_f32(d, w.s));
   }
-  HIPCHK(c, launch_unpack_conv_grad(w.dwp, w.flat + L.off_w, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, w.s));
+  HIPCHK(c, launch_unpack_conv_grad(w.dwp, d.groups, (size_t)d.N * d.Kp, w.flat + L.off_w, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, w.s));
   return MGU_OK;
 }
 
@@ -249,6 +254,7 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
   Bwd w;
   w.c = c, w.s = s;
   w.ta = at(c, p.ta), w.tb = at(c, p.tb), w.dwp = at(c, p.dwp), w.dgp = at(c, p.dgp);
+  w.dwp_floats = p.dwp_floats;
   w.flat = (float*)flat_grad_dev;
   w.sums = (double*)((char*)c->tws + p.sums);
   w.red = (double*)((char*)c->tws + p.red);
@@ -266,10 +272,10 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
     WgradDesc g;
     memset(&g, 0, sizeof g);
     g.z = dlog, g.ldz = ldd, g.in = F.t_in, g.ldin = F.t_ldin, g.Cp = C0, g.KS = 1;
-    g.M = (int)M0, g.H = H, g.W = W, g.N = ldd, g.K = C0, g.Kp = F.Kp, g.dw = w.dwp;
+    g.M = (int)M0, g.H = H, g.W = W, g.N = ldd, g.K = C0, g.Kp = F.Kp, g.dw = w.dwp, g.dw_capacity = w.dwp_floats;
     HIPCHK(c, hipMemsetAsync(w.dwp, 0, (size_t)ldd * F.Kp * sizeof(float), s));
     HIPCHK(c, launch_wgrad_f32(g, s));
-    HIPCHK(c, launch_unpack_conv_grad(w.dwp, w.flat + F.off_w, c->ncls, C0, C0, 1, F.Kp, s));
+    HIPCHK(c, launch_unpack_conv_grad(w.dwp, g.groups, (size_t)g.N * g.Kp, w.flat + F.off_w, c->ncls, C0, C0, 1, F.Kp, s));
     const int Kpd = rup(ldd, 32);
     HIPCHK(c, launch_pack_dgrad_w(F.w_src, w.dgp, c->ncls, C0, ldd, 1, Kpd, s));
     IgemmDesc q;
@@ -298,7 +304,7 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
       memset(&g, 0, sizeof g);
       g.z = U.t_in, g.ldz = U.t_ldin, g.in = dcat, g.ldin = 2 * C, g.inoff = C, g.Cp = C, g.KS = 2;
       g.M = U.t_B * U.t_H * U.t_W, g.H = U.t_H, g.W = U.t_W, g.Hs = hs[i], g.Ws = ws[i];
-      g.N = U.Cin, g.K = Kt, g.Kp = Kpt, g.dw = w.dwp;
+      g.N = U.Cin, g.K = Kt, g.Kp = Kpt, g.dw = w.dwp, g.dw_capacity = w.dwp_floats;
       HIPCHK(c, hipMemsetAsync(w.dwp, 0, (size_t)U.Cin * Kpt * sizeof(float), s));
       HIPCHK(c, launch_wgrad_f32(g, s));
       HIPCHK(c, launch_unpack_convt_grad(w.dwp, w.flat + U.off_w, U.Cin, C, Kpt, s));

@@ -361,19 +361,26 @@ hipError_t launch_pack_convt_dgrad_w(const float* w, float* wp, int Cin, int Cou
 
 // ---- gradient panels -> the reference's parameter layouts ---------------------------------------------
 // conv: panel [Cout][Kp], k = tap*Cp + c  ->  OIHW (Cout, Cin, KS, KS)
-__global__ void unpack_conv_grad_kernel(const float* __restrict__ dwp, float* __restrict__ g, int Cout, int Cin, int Cp, int KS,
-                                        int Kp) {
-  const int64_t total = (int64_t)Cout * Cin * KS * KS;
+// (sums `groups` partial panels in a fixed order: the atomics-free wgrad path writes one panel per patch group)
+__global__ void unpack_conv_grad_kernel(const float* __restrict__ dwp, int groups, size_t panel_stride, float* __restrict__ g,
+                                        int Cout, int Cin, int Cp, int KS, int Kp) {
+  // thread -> panel element (co, k) so reads of a partial panel are coalesced along k; writes scatter by 9 floats
+  const int64_t total = (int64_t)Cout * KS * KS * Cp;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int tap = (int)(i % (KS * KS));
-    const int64_t r = i / (KS * KS);
-    const int ci = (int)(r % Cin), co = (int)(r / Cin);
-    g[i] = dwp[(int64_t)co * Kp + tap * Cp + ci];
+    const int k = (int)(i % (KS * KS * Cp));
+    const int co = (int)(i / (KS * KS * Cp));
+    const int tap = k / Cp, ci = k - tap * Cp;
+    if (ci >= Cin) continue;
+    const float* p = dwp + (int64_t)co * Kp + k;
+    float sum = 0.f;
+    for (int q = 0; q < groups; ++q) sum += p[(size_t)q * panel_stride];
+    g[((int64_t)co * Cin + ci) * KS * KS + tap] = sum;
   }
 }
-hipError_t launch_unpack_conv_grad(const float* dwp, float* g, int Cout, int Cin, int Cp, int KS, int Kp, hipStream_t s) {
-  hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(nblk((int64_t)Cout * Cin * KS * KS, 256)), dim3(256), 0, s, dwp, g, Cout, Cin,
-                     Cp, KS, Kp);
+hipError_t launch_unpack_conv_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cout, int Cin, int Cp, int KS,
+                                   int Kp, hipStream_t s) {
+  hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(nblk((int64_t)Cout * KS * KS * Cp, 256)), dim3(256), 0, s, dwp, groups,
+                     panel_stride, g, Cout, Cin, Cp, KS, Kp);
   return hipGetLastError();
 }
 // convT: panel [Cin][Kp], k = q*Cout + co  ->  (Cin, Cout, 2, 2)
