@@ -58,7 +58,7 @@ struct WgradDesc {
   int Hs, Ws;       // KS == 2 source grid
   int N, K, Kp;     // Dw panel [>=N][Kp]
   float* dw;        // [groups][>=N][Kp] partial panels; the launcher sets `groups`.  groups == 1: accumulated with
-                    // float atomics into ONE panel the caller zeroed; groups > 1: plain stores, every element of
+                    // float atomics into ONE panel (zeroed by the launcher); groups > 1: plain stores, every element of
                     // every partial panel written (no zeroing needed), the caller sums the panels
   size_t dw_capacity;  // floats available at dw
   int groups;          // set by the launcher

@@ -40,6 +40,9 @@ struct mgu_ctx {
   int device = 0;
   std::string err;
   bool configured = false, loaded = false;
+  bool fold_dirty = false;  // BN running stats / affine changed since the eval scale/shift were folded
+  void* redws = nullptr;    // per-channel reduction slots (self-cleaning: zero between launches)
+  size_t redws_bytes = 0;
   int in_ch = 0, ncls = 0, feat = 0, depth = 0, dtype = 0, Cp0 = 0;
   std::vector<Layer> layers;  // enc[i].conv1, enc[i].conv2 ..., bott.conv1, bott.conv2, dec[b].up, dec[b].conv1, dec[b].conv2 ..., final
   int64_t nparams = 0;

@@ -79,6 +79,7 @@ void mgu_destroy(mgu_ctx* c) {
   if (c->ws) (void)hipFree(c->ws);
   if (c->gws) (void)hipFree(c->gws);
   if (c->tws) (void)hipFree(c->tws);
+  if (c->redws) (void)hipFree(c->redws);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   for (auto e : c->ev_total)
     if (e) (void)hipEventDestroy(e);
@@ -263,7 +264,7 @@ int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void*
         if ((rc = get(bn + ".running_mean", L.Cout, &rm))) return rc;
         if ((rc = get(bn + ".running_var", L.Cout, &rv))) return rc;
         L.gamma = g, L.beta = be, L.run_mean = const_cast<float*>(rm), L.run_var = const_cast<float*>(rv);
-        HIPCHK(c, launch_bn_fold(b, g, be, rm, rv, 1e-5f, L.scale, L.shift, L.Cout, s));
+        c->fold_dirty = true;   // eval scale/shift are folded lazily by the next eval forward (training never reads them)
       } else {
         HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 1, s));
       }
@@ -350,6 +351,11 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
   const WsPlan plan = plan_ws(c, B, H, W);
   int rc = ensure(c, &c->ws, &c->ws_bytes, plan.total);
   if (rc) return rc;
+  if (c->fold_dirty) {  // eval BatchNorm: y = scale * conv + shift with the CURRENT running statistics
+    for (auto& L : c->layers)
+      if (!L.bn.empty()) HIPCHK(c, launch_bn_fold(L.b_src, L.gamma, L.beta, L.run_mean, L.run_var, 1e-5f, L.scale, L.shift, L.Cout, s));
+    c->fold_dirty = false;
+  }
   char* ws = (char*)c->ws;
   const size_t es = c->dtype == MGU_DTYPE_BF16 ? 2 : 4;
   void* xin = ws + plan.xin;

@@ -13,7 +13,7 @@ using namespace mgud;
 namespace {
 
 struct TPlan {
-  size_t xin = 0, bott = 0, ta = 0, tb = 0, tc = 0, dwp = 0, dwp_floats = 0, dgp = 0, sums = 0, red = 0, total = 0;
+  size_t xin = 0, bott = 0, ta = 0, tb = 0, tc = 0, dwp = 0, dwp_floats = 0, dgp = 0, sums = 0, total = 0;
   std::vector<size_t> z, y1, pooled, dcat;
 };
 
@@ -60,9 +60,19 @@ TPlan plan_train(const mgu_ctx* c, int B, int H, int W) {
   p.dwp = fl(p.dwp_floats);
   p.dgp = fl(pmax);
   p.sums = take(sizeof(double) * 2 * ((size_t)c->feat << d) + 64);
-  p.red = take(chan_reduce_work_bytes(c->feat << d));
   p.total = off;
   return p;
+}
+
+// The reduction slots are zero between launches: slot_reduce_kernel clears what it read, so only a fresh allocation
+// needs a memset (instead of one before each of the ~60 per-channel reductions of a step).
+int ensure_red(mgu_ctx* c) {
+  const size_t need = chan_reduce_work_bytes(std::max(c->feat << c->depth, 64));
+  if (c->redws_bytes >= need) return MGU_OK;
+  int rc = ensure(c, &c->redws, &c->redws_bytes, need);
+  if (rc) return rc;
+  HIPCHK(c, hipMemset(c->redws, 0, need));
+  return MGU_OK;
 }
 
 inline float* at(mgu_ctx* c, size_t off) { return (float*)((char*)c->tws + off); }
@@ -102,9 +112,6 @@ int conv_wgrad(Bwd& w, const Layer& L, const float* dz) {
   d.N = L.Cout, d.K = L.K, d.Kp = L.Kp;
   d.dw = w.dwp;
   d.dw_capacity = w.dwp_floats;
-  // the atomic path needs ONE zeroed panel; the halo path overwrites its partial panels, so zeroing the first
-  // panel is all either needs (and costs one small memset)
-  HIPCHK(c, hipMemsetAsync(w.dwp, 0, (size_t)rup(L.Cout, 4) * L.Kp * sizeof(float), w.s));
   {
     ProfScope ps(c, w.s);
     HIPCHK(c, launch_wgrad_f32(d, w.s));
@@ -167,10 +174,12 @@ int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t x
   c->have_train_fwd = false;
   int rc = ensure(c, &c->tws, &c->tws_bytes, p.total);
   if (rc) return rc;
+  if ((rc = ensure_red(c))) return rc;
+  c->fold_dirty = true;   // this forward rewrites running_mean/var in place
   std::vector<int> hs, ws;
   level_dims(H, W, d, hs, ws);
   double* sums = (double*)((char*)c->tws + p.sums);
-  double* red = (double*)((char*)c->tws + p.red);
+  double* red = (double*)c->redws;
   for (int i = 0; i < d; ++i)
     if (2 * hs[i + 1] != hs[i] || 2 * ws[i + 1] != ws[i])
       HIPCHK(c, hipMemsetAsync(cat_dev[i], 0, (size_t)B * hs[i] * ws[i] * 2 * ((size_t)c->feat << i) * sizeof(float), s));
@@ -257,7 +266,7 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
   w.dwp_floats = p.dwp_floats;
   w.flat = (float*)flat_grad_dev;
   w.sums = (double*)((char*)c->tws + p.sums);
-  w.red = (double*)((char*)c->tws + p.red);
+  w.red = (double*)c->redws;
   float* tc = at(c, p.tc);
   int rc;
 
@@ -273,7 +282,6 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
     memset(&g, 0, sizeof g);
     g.z = dlog, g.ldz = ldd, g.in = F.t_in, g.ldin = F.t_ldin, g.Cp = C0, g.KS = 1;
     g.M = (int)M0, g.H = H, g.W = W, g.N = ldd, g.K = C0, g.Kp = F.Kp, g.dw = w.dwp, g.dw_capacity = w.dwp_floats;
-    HIPCHK(c, hipMemsetAsync(w.dwp, 0, (size_t)ldd * F.Kp * sizeof(float), s));
     HIPCHK(c, launch_wgrad_f32(g, s));
     HIPCHK(c, launch_unpack_conv_grad(w.dwp, g.groups, (size_t)g.N * g.Kp, w.flat + F.off_w, c->ncls, C0, C0, 1, F.Kp, s));
     const int Kpd = rup(ldd, 32);
@@ -305,7 +313,6 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
       g.z = U.t_in, g.ldz = U.t_ldin, g.in = dcat, g.ldin = 2 * C, g.inoff = C, g.Cp = C, g.KS = 2;
       g.M = U.t_B * U.t_H * U.t_W, g.H = U.t_H, g.W = U.t_W, g.Hs = hs[i], g.Ws = ws[i];
       g.N = U.Cin, g.K = Kt, g.Kp = Kpt, g.dw = w.dwp, g.dw_capacity = w.dwp_floats;
-      HIPCHK(c, hipMemsetAsync(w.dwp, 0, (size_t)U.Cin * Kpt * sizeof(float), s));
       HIPCHK(c, launch_wgrad_f32(g, s));
       HIPCHK(c, launch_unpack_convt_grad(w.dwp, w.flat + U.off_w, U.Cin, C, Kpt, s));
     }

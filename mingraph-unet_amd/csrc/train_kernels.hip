@@ -103,12 +103,16 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
 }
 
 // outd[j] = sum over slots (j < n, slot pitch = pitch); optional fp32 copies: outf0[j] for j < n0, outf1[j-n0] beyond
-__global__ void slot_reduce_kernel(const double* __restrict__ slots, int n, int pitch, double* __restrict__ outd,
+// The slots it read are cleared again, so the NEXT reduction needs no memset (the workspace is zeroed once, at allocation).
+__global__ void slot_reduce_kernel(double* __restrict__ slots, int n, int pitch, double* __restrict__ outd,
                                    float* __restrict__ outf0, int n0, float* __restrict__ outf1) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   double s = 0.0;
-  for (int k = 0; k < RED_SLOTS; ++k) s += slots[(size_t)k * pitch + j];
+  for (int k = 0; k < RED_SLOTS; ++k) {
+    s += slots[(size_t)k * pitch + j];
+    slots[(size_t)k * pitch + j] = 0.0;
+  }
   if (outd) outd[j] = s;
   if (j < n0) {
     if (outf0) outf0[j] = (float)s;
@@ -125,9 +129,7 @@ static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const fl
                                      float* dz, int64_t M, int C, double* work, double* outd, float* outf0, int n0,
                                      float* outf1, hipStream_t s) {
   if ((C & 3) || C < 4 || C > 1024 || (ldz & 3) || M < 1) return hipErrorInvalidValue;
-  hipError_t e = hipMemsetAsync(work, 0, chan_reduce_work_bytes(C), s);
-  if (e != hipSuccess) return e;
-  int64_t blocks = (M + 63) / 64;
+  int64_t blocks = (M + 63) / 64;   // `work` is zero on entry and on exit (slot_reduce_kernel cleans up)
   if (blocks > 4096) blocks = 4096;
   const int rows = (int)((M + blocks - 1) / blocks);
   blocks = (M + rows - 1) / rows;
@@ -361,26 +363,49 @@ hipError_t launch_pack_convt_dgrad_w(const float* w, float* wp, int Cin, int Cou
 
 // ---- gradient panels -> the reference's parameter layouts ---------------------------------------------
 // conv: panel [Cout][Kp], k = tap*Cp + c  ->  OIHW (Cout, Cin, KS, KS)
-// (sums `groups` partial panels in a fixed order: the atomics-free wgrad path writes one panel per patch group)
-__global__ void unpack_conv_grad_kernel(const float* __restrict__ dwp, int groups, size_t panel_stride, float* __restrict__ g,
-                                        int Cout, int Cin, int Cp, int KS, int Kp) {
-  // thread -> panel element (co, k) so reads of a partial panel are coalesced along k; writes scatter by 9 floats
-  const int64_t total = (int64_t)Cout * KS * KS * Cp;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i % (KS * KS * Cp));
-    const int co = (int)(i / (KS * KS * Cp));
-    const int tap = k / Cp, ci = k - tap * Cp;
-    if (ci >= Cin) continue;
+// Sums `groups` partial panels in a fixed order (the atomics-free wgrad path writes one panel per patch group).
+// A workgroup owns 32 consecutive panel elements (128-byte coalesced reads of every partial panel) and splits the
+// group loop over 8 slices, so a small panel with 512 partials still fills the chip.
+__global__ __launch_bounds__(256) void unpack_conv_grad_kernel(const float* __restrict__ dwp, int groups, size_t panel_stride,
+                                                               float* __restrict__ g, int Cout, int Cin, int Cp, int KS,
+                                                               int Kp) {
+  __shared__ float part[8][32];
+  const int kk = KS * KS * Cp;
+  const int64_t total = (int64_t)Cout * kk;
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (int64_t i0 = (int64_t)blockIdx.x * 32; i0 < total; i0 += (int64_t)gridDim.x * 32) {
+    const int64_t i = i0 + e;
+    const bool ok = i < total;
+    const int k = ok ? (int)(i % kk) : 0;
+    const int co = ok ? (int)(i / kk) : 0;
     const float* p = dwp + (int64_t)co * Kp + k;
-    float sum = 0.f;
-    for (int q = 0; q < groups; ++q) sum += p[(size_t)q * panel_stride];
-    g[((int64_t)co * Cin + ci) * KS * KS + tap] = sum;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int q = sl;
+    for (; q + 24 < groups; q += 32) {   // 4 independent loads in flight
+      s0 += p[(size_t)q * panel_stride];
+      s1 += p[(size_t)(q + 8) * panel_stride];
+      s2 += p[(size_t)(q + 16) * panel_stride];
+      s3 += p[(size_t)(q + 24) * panel_stride];
+    }
+    for (; q < groups; q += 8) s0 += p[(size_t)q * panel_stride];
+    part[sl][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && ok) {
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += part[j][e];
+      const int tap = k / Cp, ci = k - tap * Cp;
+      if (ci < Cin) g[((int64_t)co * Cin + ci) * KS * KS + tap] = sum;
+    }
+    __syncthreads();
   }
 }
 hipError_t launch_unpack_conv_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cout, int Cin, int Cp, int KS,
                                    int Kp, hipStream_t s) {
-  hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(nblk((int64_t)Cout * KS * KS * Cp, 256)), dim3(256), 0, s, dwp, groups,
-                     panel_stride, g, Cout, Cin, Cp, KS, Kp);
+  int64_t blocks = ((int64_t)Cout * KS * KS * Cp + 31) / 32;
+  if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dwp, groups, panel_stride, g, Cout, Cin,
+                     Cp, KS, Kp);
   return hipGetLastError();
 }
 // convT: panel [Cin][Kp], k = q*Cout + co  ->  (Cin, Cout, 2, 2)

@@ -360,6 +360,9 @@ hipError_t launch_wgrad_f32(WgradDesc& d, hipStream_t s) {
     if (d.N % 64 == 0) return launch_wg_halo<2>(d, s);
     return launch_wg_halo<1>(d, s);
   }
+  if (d.dw_capacity < (size_t)d.N * d.Kp) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(d.dw, 0, (size_t)d.N * d.Kp * sizeof(float), s);   // the tile kernels accumulate with atomics
+  if (e != hipSuccess) return e;
   if (d.KS == 3) return launch_wg_tiles<3>(d, s);
   if (d.KS == 2) return launch_wg_tiles<2>(d, s);
   if (d.KS == 1) return launch_wg_tiles<1>(d, s);
