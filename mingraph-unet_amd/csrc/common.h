@@ -18,6 +18,7 @@ namespace mgu {
 struct IgemmDesc {
   const float* in;
   const float* w;
+  const float* wu;     // optional: Winograd-transformed 3x3 weights (launch_pack_wino_w); enables wino_f32.hip
   const float* scale;  // may be nullptr (== 1)
   const float* shift;  // may be nullptr (== 0)
   float* out;
@@ -43,6 +44,13 @@ struct IgemmDesc {
 
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
 hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s);  // in / w / out point to bf16, sizes in elements
+// wino_f32.hip: Winograd F(2x2,3x3) for fp32 3x3 layers with Cp % 32 == 0
+size_t wino_u_floats(int Cout, int Cp);
+hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int Cp, int dgrad, hipStream_t s);
+bool wino_applicable(const IgemmDesc& d);
+hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s);
+void set_use_wino(bool on);
+bool use_wino();
 void set_use_halo(bool on);
 void set_halo_max_ppb(int n);
 void set_halo_tps3(bool on);

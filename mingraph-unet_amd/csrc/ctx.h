@@ -20,6 +20,8 @@ struct Layer {
   bool convt = false;
   int K = 0, Kp = 0, N = 0, Np = 0;
   float *wp = nullptr, *scale = nullptr, *shift = nullptr;
+  bool wino = false;     // fp32 3x3 layer with Cp % 32 == 0: Winograd-transformed weights kept in wu
+  float* wu = nullptr;
   // caller-owned parameter tensors recorded by load_weights (used by the training path)
   const float *w_src = nullptr, *b_src = nullptr, *gamma = nullptr, *beta = nullptr;
   float *run_mean = nullptr, *run_var = nullptr;
@@ -43,6 +45,8 @@ struct mgu_ctx {
   bool fold_dirty = false;  // BN running stats / affine changed since the eval scale/shift were folded
   void* redws = nullptr;    // per-channel reduction slots (self-cleaning: zero between launches)
   size_t redws_bytes = 0;
+  void* wuws = nullptr;     // Winograd weight scratch of the mgu_conv2d_nhwc building block
+  size_t wuws_bytes = 0;
   int in_ch = 0, ncls = 0, feat = 0, depth = 0, dtype = 0, Cp0 = 0;
   std::vector<Layer> layers;  // enc[i].conv1, enc[i].conv2 ..., bott.conv1, bott.conv2, dec[b].up, dec[b].conv1, dec[b].conv2 ..., final
   int64_t nparams = 0;

@@ -559,6 +559,7 @@ hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s) {
     if (d.KS != 1) return hipErrorInvalidValue;
     return launch_tiles<float, 1, 1>(d, s);
   }
+  if (wino_applicable(d)) return launch_wino_f32(d, s);
   if (halo_np<float>(d) == 8) return launch_halo_tiles<float, 8>(d, s);
   if (d.KS == 3) return launch_tiles<float, 3, 0>(d, s);
   if (d.KS == 1) return launch_tiles<float, 1, 0>(d, s);

@@ -63,6 +63,8 @@ int mgu_create(int device_id, mgu_ctx** out) {
   set_use_halo(!(nh && nh[0] == '1'));
   const char* nw = getenv("MGU_NO_WGRAD_HALO");
   set_wgrad_halo(!(nw && nw[0] == '1'));
+  const char* nwi = getenv("MGU_NO_WINOGRAD");
+  set_use_wino(!(nwi && nwi[0] == '1'));
   const char* t1 = getenv("MGU_HALO_TPS1");
   set_halo_tps3(!(t1 && t1[0] == '1'));
   const char* pp = getenv("MGU_HALO_PPB");
@@ -80,6 +82,7 @@ void mgu_destroy(mgu_ctx* c) {
   if (c->gws) (void)hipFree(c->gws);
   if (c->tws) (void)hipFree(c->tws);
   if (c->redws) (void)hipFree(c->redws);
+  if (c->wuws) (void)hipFree(c->wuws);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   for (auto e : c->ev_total)
     if (e) (void)hipEventDestroy(e);
@@ -149,6 +152,8 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     L.N = L.convt ? 4 * L.Cout : L.Cout;
     L.Np = rup(L.N, 128);
     total += (size_t)L.Np * L.Kp + 2 * (size_t)L.Np + (L.bn.empty() ? 0 : 4 * (size_t)L.Np);
+    L.wino = dtype == MGU_DTYPE_F32 && !L.convt && L.KS == 3 && L.Cp % 32 == 0;   // Winograd F(2x2,3x3) layers (wino_f32.hip)
+    if (L.wino) total += wino_u_floats(L.Cout, L.Cp);
   }
   // flat parameter order = the reference's named_parameters(): per ConvBlock conv1.{w,b}, conv2.{w,b},
   // bn1.{w,b}, bn2.{w,b} (unet_encoder.py:7-13); decoder block: upsample.{w,b} then its conv_block; final.
@@ -190,6 +195,8 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     p += L.Np;
     L.shift = p;
     p += L.Np;
+    L.wu = nullptr;
+    if (L.wino) L.wu = p, p += wino_u_floats(L.Cout, L.Cp);
     if (!L.bn.empty()) {
       L.mean = p, p += L.Np;
       L.invstd = p, p += L.Np;
@@ -256,6 +263,7 @@ int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void*
       if ((rc = get(cw + ".bias", L.Cout, &b))) return rc;
       L.w_src = w, L.b_src = b;
       HIPCHK(c, launch_pack_conv_w(w, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
+      if (L.wu) HIPCHK(c, launch_pack_wino_w(w, L.wu, L.Cout, L.Cin, L.Cp, 0, s));
       if (!L.bn.empty()) {
         const float *g, *be, *rm, *rv;
         const std::string bn = L.prefix + L.bn;
@@ -298,6 +306,7 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
   memset(&d, 0, sizeof d);
   d.in = (const float*)in_v;   // element type follows c->dtype; the descriptor carries raw pointers
   d.w = L.wp;
+  d.wu = L.wu;
   d.scale = scale;
   d.shift = shift;
   d.out = (float*)out_v;
@@ -453,9 +462,14 @@ int mgu_conv2d_nhwc(mgu_ctx* c, const void* in_dev, int B, int H, int W, int Cin
   int rc = block_scratch(c, L.Np, L.Kp, &L.wp, &sc, &sh, s);
   if (rc) return rc;
   HIPCHK(c, launch_pack_conv_w((const float*)w_dev, L.wp, 0, Cout, Cin, Cin, ksize, L.Kp, s));
+  if (ksize == 3 && Cin % 32 == 0 && use_wino()) {   // same routing as the model's layers: Winograd F(2x2,3x3)
+    if ((rc = ensure(c, &c->wuws, &c->wuws_bytes, wino_u_floats(Cout, Cin) * sizeof(float)))) return rc;
+    L.wu = (float*)c->wuws;
+    HIPCHK(c, launch_pack_wino_w((const float*)w_dev, L.wu, Cout, Cin, Cin, 0, s));
+  }
   IgemmDesc d;
   memset(&d, 0, sizeof d);
-  d.in = (const float*)in_dev, d.w = L.wp, d.out = (float*)out_dev;
+  d.in = (const float*)in_dev, d.w = L.wp, d.wu = L.wu, d.out = (float*)out_dev;
   d.M = B * H * W, d.H = H, d.W = W, d.Cp = Cin, d.ldin = Cin, d.KS = ksize, d.K = L.K, d.Kp = L.Kp;
   d.N = Cout, d.ldout = ld_out, d.coff = c_off, d.relu = relu;
   if (scale_dev && shift_dev) {  // y = scale*(conv) + shift, bias folded by the caller into shift
