@@ -89,7 +89,8 @@ hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int C
 // NT = 1: 32 output channels,               wave (i, g) owns m tile g.
 template <int NT>
 __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y,
-                                                          const int total_patches, const int patches_per_block) {
+                                                          const int total_patches, const int patches_per_block,
+                                                          const int ngroups, const int nitems, const int per_xcd) {
   constexpr int MT = NT;                         // m tiles per wavefront
   constexpr int RH = 10, RW = 34, HPIX = RH * RW;   // raw halo of the 8 x 32 pixel patch
   constexpr int PLD = 36;                        // floats per raw pixel in LDS: 32 channels + 4 pad (144 bytes)
@@ -104,7 +105,13 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   const int wi = wave & 3, wg = wave >> 2;
   const int lr = lane & 31, lh = lane >> 5;
   const int tx = lr & 15, ty = lr >> 4;
-  const int p_begin = blockIdx.x * patches_per_block;
+  // XCD-aware work order: workgroup L runs on XCD L % 8 (round-robin dispatch); give each XCD a CONTIGUOUS range of
+  // (n block, patch group) items in n-major order, so the workgroups that share an L2 stream the same U slice (large
+  // layers: 2-4 MB per n block against a 4 MB L2) and neighbouring patches (shared halo rows).
+  const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (item >= nitems) return;
+  const int nblock = item / ngroups;
+  const int p_begin = (item - nblock * ngroups) * patches_per_block;
   const int npatch = min(patches_per_block, total_patches - p_begin);
   if (npatch <= 0) return;
 
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   }
   const int ncg = d.Cp >> 3;                       // 8-channel k groups
   const int nC = d.Cp >> 5;                        // 32-channel raw chunks
-  const int ntg = blockIdx.y * NT + (NT == 2 ? wg : 0);
+  const int ntg = nblock * NT + (NT == 2 ? wg : 0);
   const float* const up = d.wu + ((size_t)ntg * ncg * 16 + wi * 4) * 256 + lane * 4;
 
   // ---- raw halo staging: thread -> (pixel hp0 + 64 i, 16-byte piece kq) ----
@@ -204,6 +211,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
         int nx = cg + 1;
         if (nx == ncg) nx = 0;
         load_b(nx, (kg + 1) & 1);   // fragments of the next k group (wraps to the next patch's first)
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: hipcc otherwise sinks them to just before their use
         cg = nx;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
@@ -289,7 +297,9 @@ static hipError_t launch_wino_nt(const IgemmDesc& d, hipStream_t s) {
   int ppb = (int)(((long)total * nblk) / (256 * 2));
   if (ppb < 1) ppb = 1;
   if (ppb > 16) ppb = 16;
-  dim3 grid((total + ppb - 1) / ppb, nblk);
+  const int ngroups = (total + ppb - 1) / ppb;
+  const int per_xcd = (ngroups * nblk + 7) / 8;
+  dim3 grid(8 * per_xcd, 1);
   const size_t lds = (size_t)(10 * 34 * 36 + 4 * 2 * NT * 16 * 64) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -297,7 +307,8 @@ static hipError_t launch_wino_nt(const IgemmDesc& d, hipStream_t s) {
                               (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(wino3x3_f32_kernel<NT>, grid, dim3(512), lds, s, d, tiles_x, tiles_y, total, ppb);
+  hipLaunchKernelGGL(wino3x3_f32_kernel<NT>, grid, dim3(512), lds, s, d, tiles_x, tiles_y, total, ppb, ngroups,
+                     ngroups * nblk, per_xcd);
   return hipGetLastError();
 }
 
