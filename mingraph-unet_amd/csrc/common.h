@@ -50,6 +50,7 @@ hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int C
 bool wino_applicable(const IgemmDesc& d);
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s);
 void set_use_wino(bool on);
+void set_wino_mode(int v);
 bool use_wino();
 void set_use_halo(bool on);
 void set_halo_max_ppb(int n);

@@ -65,6 +65,8 @@ int mgu_create(int device_id, mgu_ctx** out) {
   set_wgrad_halo(!(nw && nw[0] == '1'));
   const char* nwi = getenv("MGU_NO_WINOGRAD");
   set_use_wino(!(nwi && nwi[0] == '1'));
+  const char* wmo = getenv("MGU_WINO_MODE");
+  set_wino_mode(wmo ? atoi(wmo) : -1);
   const char* t1 = getenv("MGU_HALO_TPS1");
   set_halo_tps3(!(t1 && t1[0] == '1'));
   const char* pp = getenv("MGU_HALO_PPB");

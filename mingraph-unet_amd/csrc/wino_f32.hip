@@ -12,19 +12,20 @@
 // MI355X mapping
 //   * a workgroup of 8 wavefronts owns an 8 x 32 pixel output patch (4 x 16 Winograd tiles = two 32-row MFMA
 //     m tiles) and 32*NT output channels, and walks several patches (persistent);
-//   * per 32 input channels the RAW 10 x 34 halo is staged once into LDS -- the transformed input V is never
+//   * per 16 input channels the RAW 10 x 34 halo is staged once into LDS (double buffered) -- the transformed input V is never
 //     written anywhere.  Wavefront (i, g) owns row i of the 4x4 transform: row i of B^T d is a +-1 combination of
 //     two raw rows, so the wave reads 2 rows x 4 columns (8 ds_read_b128) per lane and k chunk, forms its 4
 //     components V[i][0..3] with 8 vector adds, and issues 16 MFMAs on them.  That is 2 LDS reads per V value --
 //     fewer than writing V to LDS and reading it back -- with no barrier between transform and MFMA;
-//   * raw columns are stored split by parity ([row][x & 1][x >> 1][36 floats]): tile tx touches entries tx, tx+1 of
-//     each parity plane, so the 16 lanes of a ds_read_b128 group are 144 bytes apart -> conflict free;
+//   * raw columns are stored split by parity ([row][x & 1][x >> 1][20 floats]): tile tx touches entries tx, tx+1 of
+//     each parity plane, so the 16 lanes of a ds_read_b128 group are 80 bytes apart -> conflict free;
 //   * U = G g G^T is precomputed (pack_wino_w_kernel) in MFMA-fragment order: the four components of a wave are one
 //     contiguous 4 KB block per 8 input channels, loaded straight from L2 into VGPRs (coalesced 16-byte lanes).
 //     Only one wave of the workgroup uses a given component, so staging U through LDS would buy nothing;
 //   * inverse transform: each wave folds its own row (M[i][.] A) in registers, the four row waves meet through a
 //     small LDS exchange, and lanes store one channel each (32 lanes = one 128-byte line of a pixel).
 #include "common.h"
+#include <type_traits>
 
 namespace mgu {
 
@@ -85,20 +86,33 @@ hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int C
   return hipGetLastError();
 }
 
-// NT = 2: 64 output channels per workgroup, wave (i, g) owns n tile g and both m tiles;
-// NT = 1: 32 output channels,               wave (i, g) owns m tile g.
-template <int NT>
-__global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y,
-                                                          const int total_patches, const int patches_per_block,
-                                                          const int ngroups, const int nitems, const int per_xcd) {
-  constexpr int MT = NT;                         // m tiles per wavefront
+// Work split (MODE):
+//   0: 8 wavefronts, 64 output channels; wave (i, g) owns transform row i, n tile g and both m tiles of the patch
+//   1: 8 wavefronts, 32 output channels; wave (i, g) owns row i and m tile g
+//   (a 4-wavefront split with two independent workgroups per CU was measured too: no faster, and it spills)
+//
+// Pipeline: the raw halo streams in 16-channel chunks through TWO LDS buffers.  At the top of chunk c (one barrier)
+// every thread parks chunk c+1 (loaded one chunk ago into VGPRs) in the idle buffer and issues the loads of chunk
+// c+2; the weight fragments of k group g+1 are issued before the MFMAs of group g.  Nothing is waited for in the step
+// it was issued in.
+template <int MODE>
+__global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y, const int total_patches,
+                        const int patches_per_block, const int ngroups, const int nitems, const int per_xcd) {
+  constexpr int NWAVES = 8;
+  constexpr int NG = NWAVES / 4;                 // wave groups
+  constexpr int MT = MODE == 1 ? 1 : 2;          // m tiles per wavefront
+  constexpr int NTB = MODE == 0 ? 2 : 1;         // n tiles (32 output channels) per workgroup
+  constexpr int ZMT = MT;                        // m tiles per exchange pass
   constexpr int RH = 10, RW = 34, HPIX = RH * RW;   // raw halo of the 8 x 32 pixel patch
-  constexpr int PLD = 36;                        // floats per raw pixel in LDS: 32 channels + 4 pad (144 bytes)
-  constexpr int HR = (HPIX + 63) / 64;           // raw pixels staged per thread (8 threads x 16 bytes per pixel)
+  constexpr int PLD = 20;                        // floats per raw pixel in LDS: 16 channels + 4 pad (80 bytes: 16 lanes
+                                                 // of a ds_read_b128 group, one pixel apart, hit 16 distinct 4-bank slots)
+  constexpr int HSTRIDE = NWAVES * 16;           // raw pixels staged per pass (4 threads x 16 bytes per pixel)
+  constexpr int HR = (HPIX + HSTRIDE - 1) / HSTRIDE;
   constexpr int S1 = 17 * PLD, S2 = PLD, S3 = 17 * PLD + PLD;   // LDS offsets of tile columns 1..3 (parity planes)
+  constexpr int RAWF = HR * HSTRIDE / RW * 34 * PLD + 34 * PLD;   // floats per raw buffer, padded: the staging pass of the
+                                                 // threads past HPIX stores (never read) dummies instead of branching
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Hs = smem;                 // [RH][2][17][PLD]
-  float* Zx = smem + HPIX * PLD;    // [4 rows i][2 g][MT][16 regs][64 lanes]
+  float* Zx = smem + 2 * RAWF;      // [4 rows i][NG][ZMT][16 regs][64 lanes]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,7 +121,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   const int tx = lr & 15, ty = lr >> 4;
   // XCD-aware work order: workgroup L runs on XCD L % 8 (round-robin dispatch); give each XCD a CONTIGUOUS range of
   // (n block, patch group) items in n-major order, so the workgroups that share an L2 stream the same U slice (large
-  // layers: 2-4 MB per n block against a 4 MB L2) and neighbouring patches (shared halo rows).
+  // layers: 1-4 MB per n block against a 4 MB L2) and neighbouring patches (shared halo rows).
   const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (item >= nitems) return;
   const int nblock = item / ngroups;
@@ -122,18 +136,18 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   int offA[MT], offB[MT];
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
-    const int m_abs = NT == 2 ? mi : wg;
+    const int m_abs = MODE == 1 ? wg : mi;
     const int rowbase = 2 * (2 * m_abs + ty);
     offA[mi] = ((rowbase + ra) * 34 + tx) * PLD + lh * 4;
     offB[mi] = ((rowbase + rb) * 34 + tx) * PLD + lh * 4;
   }
   const int ncg = d.Cp >> 3;                       // 8-channel k groups
-  const int nC = d.Cp >> 5;                        // 32-channel raw chunks
-  const int ntg = nblock * NT + (NT == 2 ? wg : 0);
+  const int nC = d.Cp >> 4;                        // 16-channel raw chunks
+  const int ntg = nblock * NTB + (MODE == 0 ? wg : 0);
   const float* const up = d.wu + ((size_t)ntg * ncg * 16 + wi * 4) * 256 + lane * 4;
 
-  // ---- raw halo staging: thread -> (pixel hp0 + 64 i, 16-byte piece kq) ----
-  const int kq = tid & 7, hp0 = tid >> 3;
+  // ---- raw halo staging: thread -> (pixel hp0 + HSTRIDE i, 16-byte piece kq) ----
+  const int kq = tid & 3, hp0 = tid >> 2;
   int hoff[HR];
   unsigned hmask = 0u, hmask_next = 0u;
   const float* load_base = d.in;
@@ -151,7 +165,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
     unsigned mk = 0u;
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
-      const int hp = hp0 + 64 * i;
+      const int hp = hp0 + HSTRIDE * i;
       const int r = hp / RW, cc = hp - r * RW;
       const int y = y0 - 1 + r, x = x0 - 1 + cc;
       const bool ok = hp < HPIX && y >= 0 && y < d.H && x >= 0 && x < d.W;
@@ -164,17 +178,28 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   auto load_halo = [&](int c) {
     hmask = hmask_next;
 #pragma unroll
-    for (int i = 0; i < HR; ++i) hreg[i] = *reinterpret_cast<const f32x4*>(load_base + hoff[i] + c * 32);
+    for (int i = 0; i < HR; ++i) hreg[i] = *reinterpret_cast<const f32x4*>(load_base + hoff[i] + c * 16);
   };
-  auto store_halo = [&]() {
+  auto store_halo = [&](float* Hs) {
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
-      const int hp = hp0 + 64 * i;
+      const int hp = hp0 + HSTRIDE * i;
       const int r = hp / RW, cc = hp - r * RW;
-      if (hp < HPIX)
-        *reinterpret_cast<f32x4*>(Hs + ((r * 2 + (cc & 1)) * 17 + (cc >> 1)) * PLD + kq * 4) =
-            ((hmask >> i) & 1u) ? hreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(Hs + ((r * 2 + (cc & 1)) * 17 + (cc >> 1)) * PLD + kq * 4) =
+          ((hmask >> i) & 1u) ? hreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  // the load stream runs two chunks ahead of the compute: (lp, lc) = patch / chunk of the NEXT load.
+  // (the loads themselves are UNCONDITIONAL: a branch around a load makes hipcc drain vmcnt at the join, which would
+  //  wait for the chunk just issued.  Past the end of the stream the last patch is simply re-read and never used.)
+  int lp = 0, lc = 0;
+  auto prep_next = [&]() {   // address setup of the next load (branchy: kept out of the chunk body)
+    if (lc == 0 && lp < npatch) setup_load(p_begin + lp);
+  };
+  auto load_next = [&]() {   // issue the loads of the next chunk in stream order (straight-line code)
+    load_halo(lc);
+    lc = lc + 1 == nC ? 0 : lc + 1;
+    lp += lc == 0 ? 1 : 0;
   };
 
   f32x4 bf[2][4];
@@ -191,50 +216,96 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][mi][r] = 0.f;
 
-  setup_load(p_begin);
-  load_halo(0);
+  prep_next();
+  load_next();              // chunk 0 of the first patch
   load_b(0, 0);
-  int cg = 0;   // k group (of the patch) whose fragments sit in bf[0] at the top of a chunk
+  store_halo(smem);
+  prep_next();
+  load_next();              // chunk 1 of the stream, parked at the top of chunk 0
+  int cg = 0;               // k group whose fragments sit in bf[0] at the top of a chunk
+  int buf = 0;              // raw buffer of the chunk being computed
   for (int pi = 0; pi < npatch; ++pi) {
     for (int c = 0; c < nC; ++c) {
-      __syncthreads();   // every wave is done with the previous raw chunk
-      store_halo();
-      __syncthreads();   // raw chunk visible
-      if (c + 1 < nC) {
-        load_halo(c + 1);
-      } else if (pi + 1 < npatch) {
-        setup_load(p_begin + pi + 1);
-        load_halo(0);
+      prep_next();
+      __syncthreads();   // the chunk to compute is visible in buffer buf; every wave has left buffer buf ^ 1
+      const float* Hs = smem + buf * RAWF;
+      auto operands = [&](const int kg, const int mi, f32x4 (&v)[4]) {   // V[i][0..3] of this lane's tile, 4 channels
+        const float* pa = Hs + offA[mi] + kg * 8;
+        const float* pb = Hs + offB[mi] + kg * 8;
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(pa) + sgn * *reinterpret_cast<const f32x4*>(pb);
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(pa + S1) + sgn * *reinterpret_cast<const f32x4*>(pb + S1);
+        const f32x4 r2 = *reinterpret_cast<const f32x4*>(pa + S2) + sgn * *reinterpret_cast<const f32x4*>(pb + S2);
+        const f32x4 r3 = *reinterpret_cast<const f32x4*>(pa + S3) + sgn * *reinterpret_cast<const f32x4*>(pb + S3);
+        v[0] = r0 - r2;
+        v[1] = r1 + r2;
+        v[2] = r2 - r1;
+        v[3] = r1 - r3;
+      };
+      auto mfma16 = [&](const f32x4 (&v)[4], const int slot, const int mi) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            acc[j][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][t], bf[slot][j][t], acc[j][mi], 0, 0, 0);
+      };
+      // The staging of a chunk -- 3 LDS stores (chunk c+1), the next k group's 4 fragment loads, 3 halo loads (chunk
+      // c+2) -- has no dependence on this chunk's MFMAs.  Left as a phase of its own it costs ~1500 cycles per chunk in
+      // which NO wave of the workgroup feeds the matrix pipe (all eight are in the same phase, by the barrier); a wave
+      // has ~60 free issue cycles behind every MFMA, so the staging instructions are threaded between the first m
+      // tile's MFMAs instead (sched_group_barrier pattern below).  Issue order: fragment loads BEFORE halo loads (vmcnt
+      // retires in order; the halo is the long-latency stream and must not sit in front of the kg = 1 fragment wait).
+      f32x4 va[4], vb[4];
+      operands(0, 0, va);
+      store_halo(smem + (buf ^ 1) * RAWF);
+      int nx = cg + 1 == ncg ? 0 : cg + 1;
+      load_b(nx, 1);
+      load_next();
+      mfma16(va, 0, 0);
+      if (MT == 2) {
+        operands(0, 1, vb);
+        mfma16(vb, 0, 1);
       }
 #pragma unroll
-      for (int kg = 0; kg < 4; ++kg) {
-        int nx = cg + 1;
-        if (nx == ncg) nx = 0;
-        load_b(nx, (kg + 1) & 1);   // fragments of the next k group (wraps to the next patch's first)
-        __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: hipcc otherwise sinks them to just before their use
-        cg = nx;
+      for (int i = 0; i < HR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-          f32x4 v[4];
-          {
-            const float* pa = Hs + offA[mi] + kg * 8;
-            const float* pb = Hs + offB[mi] + kg * 8;
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(pa) + sgn * *reinterpret_cast<const f32x4*>(pb);
-            const f32x4 r1 = *reinterpret_cast<const f32x4*>(pa + S1) + sgn * *reinterpret_cast<const f32x4*>(pb + S1);
-            const f32x4 r2 = *reinterpret_cast<const f32x4*>(pa + S2) + sgn * *reinterpret_cast<const f32x4*>(pb + S2);
-            const f32x4 r3 = *reinterpret_cast<const f32x4*>(pa + S3) + sgn * *reinterpret_cast<const f32x4*>(pb + S3);
-            v[0] = r0 - r2;
-            v[1] = r1 + r2;
-            v[2] = r2 - r1;
-            v[3] = r1 - r3;
-          }
+      for (int i = 0; i < 4 + HR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      if (MT == 2) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              acc[j][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][t], bf[kg & 1][j][t], acc[j][mi], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      nx = nx + 1 == ncg ? 0 : nx + 1;
+      cg = nx;
+      operands(1, 0, va);
+      load_b(nx, 0);   // first k group of the next chunk (wraps to the next patch's first)
+      mfma16(va, 1, 0);
+      if (MT == 2) {
+        operands(1, 1, vb);
+        mfma16(vb, 1, 1);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+      }
+      if (MT == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      buf ^= 1;
     }
     // ---- inverse transform + epilogue of patch pi --------------------------------------------------------
     int img, y0, x0;
@@ -244,40 +315,64 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
     const bool nvalid = n < d.N;
     const float sc = (nvalid && d.scale) ? d.scale[n] : 1.f;
     const float sh = (nvalid && d.shift) ? d.shift[n] : 0.f;
+    const unsigned sW = (unsigned)(d.W * d.ldout);
+    // block-uniform fast path: a patch inside the image with whole n tiles stores without per-element branches (hipcc
+    // puts an s_waitcnt vmcnt(0) in front of every conditional store, which serialises the store round trips)
+    const bool interior = (y0 + 8 <= d.H) && (x0 + 32 <= d.W) && (d.N % (32 * NTB) == 0);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      // column part in registers: Z[i][q] = sum_j M[i][j] A[j][q]   (A^T = [1 1 1 0; 0 1 -1 -1])
+    for (int mp = 0; mp < MT / ZMT; ++mp) {   // exchange passes over the m tiles
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
+      for (int q = 0; q < 2; ++q) {
+        // column part in registers: Z[i][q] = sum_j M[i][j] A[j][q]   (A^T = [1 1 1 0; 0 1 -1 -1]); the exchange buffer
+        // is [src row i][g][m][register quad][lane][4]: 16-byte LDS writes, and the quad a wave finishes is one read
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float z = q == 0 ? (acc[0][mi][r] + acc[1][mi][r] + acc[2][mi][r]) : (acc[1][mi][r] - acc[2][mi][r] - acc[3][mi][r]);
-          Zx[(((wi * 2 + wg) * MT + mi) * 16 + r) * 64 + lane] = z;
-        }
-      __syncthreads();
-      // row part: wave i finishes accumulator registers 4i .. 4i+3 (tile row 2m + (i>>1), tiles 8(i&1) + 4h + 0..3)
+        for (int zi = 0; zi < ZMT; ++zi) {
+          const int mi = mp * ZMT + zi;
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) {
-        const int m_abs = NT == 2 ? mi : wg;
-        const int oy = y0 + 2 * (2 * m_abs + (wi >> 1));
+          for (int rq = 0; rq < 4; ++rq) {
+            f32x4 z;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int r = 4 * wi + rr;
-          const float z0 = Zx[(((0 * 2 + wg) * MT + mi) * 16 + r) * 64 + lane];
-          const float z1 = Zx[(((1 * 2 + wg) * MT + mi) * 16 + r) * 64 + lane];
-          const float z2 = Zx[(((2 * 2 + wg) * MT + mi) * 16 + r) * 64 + lane];
-          const float z3 = Zx[(((3 * 2 + wg) * MT + mi) * 16 + r) * 64 + lane];
-          float ya = (z0 + z1 + z2) * sc + sh;    // output row 2*tr
-          float yb = (z1 - z2 - z3) * sc + sh;    // output row 2*tr + 1
-          if (d.relu) ya = fmaxf(ya, 0.f), yb = fmaxf(yb, 0.f);
-          const int ox = x0 + 2 * (rr + 8 * (wi & 1) + 4 * lh) + q;
-          if (nvalid && ox < d.W) {
-            if (oy < d.H) img_out[(size_t)(oy * d.W + ox) * d.ldout + n] = ya;
-            if (oy + 1 < d.H) img_out[(size_t)((oy + 1) * d.W + ox) * d.ldout + n] = yb;
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * rq + e;
+              z[e] = q == 0 ? (acc[0][mi][r] + acc[1][mi][r] + acc[2][mi][r]) : (acc[1][mi][r] - acc[2][mi][r] - acc[3][mi][r]);
+            }
+            *reinterpret_cast<f32x4*>(Zx + ((((wi * NG + wg) * ZMT + zi) * 4 + rq) * 64 + lane) * 4) = z;
           }
         }
+        __syncthreads();
+        // row part: wave i finishes accumulator registers 4i .. 4i+3 (tile row 2m + (i>>1), tiles 8(i&1) + 4h + 0..3)
+        auto finish = [&](auto guarded) {
+#pragma unroll
+          for (int zi = 0; zi < ZMT; ++zi) {
+            const int mi = mp * ZMT + zi;
+            const int m_abs = MODE == 1 ? wg : mi;
+            const int oy = y0 + 2 * (2 * m_abs + (wi >> 1));
+            const int ox0 = x0 + 2 * (8 * (wi & 1) + 4 * lh) + q;
+            const unsigned idx0 = (unsigned)((oy * d.W + ox0) * d.ldout + n);
+            const f32x4 z0 = *reinterpret_cast<const f32x4*>(Zx + ((((0 * NG + wg) * ZMT + zi) * 4 + wi) * 64 + lane) * 4);
+            const f32x4 z1 = *reinterpret_cast<const f32x4*>(Zx + ((((1 * NG + wg) * ZMT + zi) * 4 + wi) * 64 + lane) * 4);
+            const f32x4 z2 = *reinterpret_cast<const f32x4*>(Zx + ((((2 * NG + wg) * ZMT + zi) * 4 + wi) * 64 + lane) * 4);
+            const f32x4 z3 = *reinterpret_cast<const f32x4*>(Zx + ((((3 * NG + wg) * ZMT + zi) * 4 + wi) * 64 + lane) * 4);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              float ya = (z0[rr] + z1[rr] + z2[rr]) * sc + sh;    // output row 2*tr
+              float yb = (z1[rr] - z2[rr] - z3[rr]) * sc + sh;    // output row 2*tr + 1
+              if (d.relu) ya = fmaxf(ya, 0.f), yb = fmaxf(yb, 0.f);
+              const unsigned idx = idx0 + (unsigned)(2 * rr * d.ldout);
+              if (!decltype(guarded)::value) {
+                img_out[idx] = ya;
+                img_out[idx + sW] = yb;
+              } else if (nvalid && ox0 + 2 * rr < d.W) {
+                if (oy < d.H) img_out[idx] = ya;
+                if (oy + 1 < d.H) img_out[idx + sW] = yb;
+              }
+            }
+          }
+        };
+        if (interior) finish(std::false_type{});
+        else finish(std::true_type{});
+        __syncthreads();   // Zx is rewritten by the next pass / patch
       }
-      __syncthreads();   // Zx is rewritten by the next pass / patch
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -288,38 +383,45 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   }
 }
 
-template <int NT>
-static hipError_t launch_wino_nt(const IgemmDesc& d, hipStream_t s) {
+static int g_wino_mode = -1;   // MGU_WINO_MODE=1: force work split 1 on every layer (A/B); default: 0 for N > 32
+void set_wino_mode(int v) { g_wino_mode = v; }
+
+template <int MODE>
+static hipError_t launch_wino_mode(const IgemmDesc& d, hipStream_t s) {
+  constexpr int NTB = MODE == 0 ? 2 : 1, NWAVES = 8, NG = NWAVES / 4;
+  constexpr int ZMT = MODE == 0 ? 2 : 1;
   const int tiles_x = (d.W + 31) / 32, tiles_y = (d.H + 7) / 8;
   const int B = d.M / (d.H * d.W);
-  const int total = tiles_x * tiles_y * B, nblk = (d.N + 32 * NT - 1) / (32 * NT);
-  // one 512-thread workgroup per CU is resident: keep ~2 workgroups per CU in the grid, each walking its patches
+  const int total = tiles_x * tiles_y * B, nblk = (d.N + 32 * NTB - 1) / (32 * NTB);
+  // one 512-thread workgroup per CU is resident: keep ~2 rounds of them in the grid, each walking its patches
   int ppb = (int)(((long)total * nblk) / (256 * 2));
   if (ppb < 1) ppb = 1;
   if (ppb > 16) ppb = 16;
   const int ngroups = (total + ppb - 1) / ppb;
   const int per_xcd = (ngroups * nblk + 7) / 8;
   dim3 grid(8 * per_xcd, 1);
-  const size_t lds = (size_t)(10 * 34 * 36 + 4 * 2 * NT * 16 * 64) * sizeof(float);
+  constexpr int HSTRIDE = NWAVES * 16, HR = (340 + HSTRIDE - 1) / HSTRIDE;
+  constexpr int RAWF = HR * HSTRIDE / 34 * 34 * 20 + 34 * 20;   // must match the kernel
+  const size_t lds = (size_t)(2 * RAWF + 4 * NG * ZMT * 16 * 64) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino3x3_f32_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino3x3_f32_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(wino3x3_f32_kernel<NT>, grid, dim3(512), lds, s, d, tiles_x, tiles_y, total, ppb, ngroups,
+  hipLaunchKernelGGL((wino3x3_f32_kernel<MODE>), grid, dim3(64 * NWAVES), lds, s, d, tiles_x, tiles_y, total, ppb, ngroups,
                      ngroups * nblk, per_xcd);
   return hipGetLastError();
 }
 
 bool wino_applicable(const IgemmDesc& d) {
-  return g_use_wino && d.wu && d.KS == 3 && d.out_mode == 0 && d.split_n == 0 && (d.Cp % 32) == 0 && d.K == 9 * d.Cp &&
+  return g_use_wino && d.wu && d.KS == 3 && d.out_mode == 0 && d.split_n == 0 && (d.Cp % 16) == 0 && d.K == 9 * d.Cp &&
          (d.ldin & 3) == 0 && (long)d.H * d.W * d.ldin < (1l << 31) && (long)d.H * d.W * d.ldout < (1l << 31);
 }
 
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
-  if (d.N > 32) return launch_wino_nt<2>(d, s);
-  return launch_wino_nt<1>(d, s);
+  if (d.N > 32 && g_wino_mode != 1) return launch_wino_mode<0>(d, s);
+  return launch_wino_mode<1>(d, s);
 }
 
 }  // namespace mgu
