@@ -227,7 +227,9 @@ def main():
                 launches += n.value
             L.mgu_profile_enable(ctx.handle, 0)
         flops = unet.flops(B, H, W)
+        exe_flops = float(L.mgu_unet_mfma_flops(ctx.handle, B, H, W))   # after the Winograd F(2x2,3x3) reduction
         ach = flops * nprof / (conv_ms * 1e-3) / 1e12
+        exe = exe_flops * nprof / (conv_ms * 1e-3) / 1e12
         # HBM bytes per launch of the same kernels from the committed PMC passes (rocprofv3 cannot run inside
         # this process); only quoted when the workload is the one they were collected on
         traffic, traffic_src = None, None
@@ -241,7 +243,14 @@ def main():
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_source": traffic_src, "algorithmic_flop_per_launch": round(flops / max(launches // nprof, 1)),
-                "kernel": "conv3x3_halo_f32_kernel + igemm_f32_kernel (the 23 conv3x3/convT/1x1 launches of a step)",
+                "note": ("achieved = ALGORITHMIC (direct-convolution, 2*MAC) FLOPs / kernel time; the fp32 3x3 layers run as "
+                         "Winograd F(2x2,3x3), which executes 2.25x fewer multiplies, so frac can exceed 1 -- "
+                         "executed_* are the FLOPs the matrix cores really issue against the same peak"),
+                "executed": round(exe, 2), "executed_frac": round(exe / peak, 4),
+                "executed_flop_per_launch": round(exe_flops / max(launches // nprof, 1)),
+                "kernel": ("wino3x3_f32_kernel (16 conv3x3) + igemm_kernel (first conv, 4 ConvTranspose) + conv1x1_head_kernel: "
+                           "the 23 conv launches of a step" if a.dtype == "f32" else
+                           "conv3x3_halo_kernel<bf16> + igemm_kernel<bf16>: the 23 conv launches of a step"),
                 "launches_per_step": launches // nprof, "kernel_ms_per_step": round(conv_ms / nprof, 4),
                 "unet_ms_per_step_with_events": round(tot_ms / nprof, 4), "gflop_per_step": round(flops / 1e9, 2)}
 

@@ -154,6 +154,10 @@ int mgu_gat_layer_forward(mgu_ctx* ctx, const void* X_dev, int N, int Fin,
 /* ---- introspection for bench.py / profiles ------------------------------------------------------ */
 /* FLOPs (2*MAC, convolutions only) of one U-Net forward over B images: SURVEY 8d table. */
 double mgu_unet_flops(mgu_ctx* ctx, int B, int H, int W);
+/* FLOPs the matrix cores actually EXECUTE for the same forward: the fp32 3x3 layers with Cin % 16 == 0 run as
+ * Winograd F(2x2,3x3) -- 16 multiplies per 2x2 output tile and (cin, cout) pair instead of 36 (csrc/wino_f32.hip);
+ * equal to mgu_unet_flops when that path is off (bf16 storage, MGU_NO_WINOGRAD=1). */
+double mgu_unet_mfma_flops(mgu_ctx* ctx, int B, int H, int W);
 /* Time the conv/GEMM kernels of the LAST mgu_unet_forward with HIP events on the launch stream:
  * enable before the forward, read after.  Adds event records only (no syncs) while enabled. */
 int mgu_profile_enable(mgu_ctx* ctx, int on);

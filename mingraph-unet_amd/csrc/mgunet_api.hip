@@ -632,6 +632,28 @@ double mgu_unet_flops(mgu_ctx* c, int B, int H, int W) {
   return fl * B;
 }
 
+double mgu_unet_mfma_flops(mgu_ctx* c, int B, int H, int W) {
+  if (!c || !c->configured) return -1.0;
+  std::vector<int> hs, wsz;
+  level_dims(H, W, c->depth, hs, wsz);
+  auto conv = [&](const Layer& L, int h, int w) {
+    if (L.wu && use_wino()) return 2.0 * ((h + 1) / 2) * ((w + 1) / 2) * 16.0 * L.Cp * L.Cout;   // per 2x2 tile: 16 products
+    return 2.0 * h * w * 9.0 * L.Cin * L.Cout;
+  };
+  double fl = 0;
+  int li = 0;
+  for (int i = 0; i <= c->depth; ++i)
+    for (int j = 0; j < 2; ++j, ++li) fl += conv(c->layers[li], hs[i], wsz[i]);
+  for (int b = 0; b < c->depth; ++b) {
+    const int i = c->depth - 1 - b;
+    const Layer& U = c->layers[li++];
+    fl += 2.0 * hs[i + 1] * wsz[i + 1] * (double)U.Cin * U.Cout * 4.0;
+    for (int j = 0; j < 2; ++j, ++li) fl += conv(c->layers[li], hs[i], wsz[i]);
+  }
+  fl += 2.0 * H * W * (double)c->layers[li].Cin * c->ncls;
+  return fl * B;
+}
+
 int mgu_profile_enable(mgu_ctx* c, int on) {
   if (!c) return MGU_ERR_INVALID;
   c->prof = on != 0;

@@ -6,6 +6,7 @@
 #include <algorithm>
 
 #include "ctx.h"
+#include <cstdlib>
 
 using namespace mgu;
 using namespace mgud;
@@ -13,7 +14,7 @@ using namespace mgud;
 namespace {
 
 struct TPlan {
-  size_t xin = 0, bott = 0, ta = 0, tb = 0, tc = 0, dwp = 0, dwp_floats = 0, dgp = 0, sums = 0, total = 0;
+  size_t xin = 0, bott = 0, ta = 0, tb = 0, tc = 0, dwp = 0, dwp_floats = 0, dgp = 0, wug = 0, sums = 0, total = 0;
   std::vector<size_t> z, y1, pooled, dcat;
 };
 
@@ -59,6 +60,10 @@ TPlan plan_train(const mgu_ctx* c, int B, int H, int W) {
   p.dwp_floats = std::max(pmax, (size_t)12 << 20);   // >= 48 MB: room for the atomics-free wgrad's partial panels
   p.dwp = fl(p.dwp_floats);
   p.dgp = fl(pmax);
+  size_t umax = 0;   // Winograd-transformed dgrad weights (conv_dgrad)
+  for (const auto& L : c->layers)
+    if (L.wino && rup(L.Cout, 4) % 16 == 0) umax = std::max(umax, wino_u_floats(L.Cin, rup(L.Cout, 4)));
+  p.wug = fl(umax + 64);
   p.sums = take(sizeof(double) * 2 * ((size_t)c->feat << d) + 64);
   p.total = off;
   return p;
@@ -95,7 +100,7 @@ int conv_bn_relu_train(mgu_ctx* c, Layer& L, const float* in, int ldin, int B, i
 struct Bwd {
   mgu_ctx* c;
   hipStream_t s;
-  float *ta, *tb, *dwp, *dgp, *flat;
+  float *ta, *tb, *dwp, *dgp, *wug, *flat;
   size_t dwp_floats;
   double *sums, *red;
 };
@@ -132,6 +137,11 @@ int conv_dgrad(Bwd& w, const Layer& L, const float* dz, float* out, int ldout) {
   d.M = L.t_B * L.t_H * L.t_W, d.H = L.t_H, d.W = L.t_W;
   d.Cp = Cop, d.ldin = L.Cout == Cop ? L.Cout : Cop, d.KS = L.KS, d.K = Kd, d.Kp = Kpd;
   d.N = L.Cin, d.ldout = ldout;
+  static const bool no_wd = getenv("MGU_NO_WINO_DGRAD") != nullptr;   // A/B switch
+  if (!no_wd && L.wino && L.KS == 3 && Cop % 16 == 0 && use_wino()) {   // same Winograd kernel, weights flipped + transposed
+    HIPCHK(c, launch_pack_wino_w(L.w_src, w.wug, L.Cin, L.Cout, Cop, 1, w.s));
+    d.wu = w.wug;
+  }
   ProfScope ps(c, w.s);
   HIPCHK(c, launch_igemm_f32(d, w.s));
   return MGU_OK;
@@ -264,6 +274,7 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
   w.c = c, w.s = s;
   w.ta = at(c, p.ta), w.tb = at(c, p.tb), w.dwp = at(c, p.dwp), w.dgp = at(c, p.dgp);
   w.dwp_floats = p.dwp_floats;
+  w.wug = at(c, p.wug);
   w.flat = (float*)flat_grad_dev;
   w.sums = (double*)((char*)c->tws + p.sums);
   w.red = (double*)c->redws;

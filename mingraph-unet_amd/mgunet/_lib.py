@@ -60,6 +60,7 @@ _PROTOS = {
                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_float, C.c_void_p, C.c_void_p]),
     "mgu_unet_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mgu_unet_mfma_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgu_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mgu_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
 }

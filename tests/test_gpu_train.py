@@ -12,6 +12,34 @@ import mgunet_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def pool_margin(p, x, depth):
+    """Smallest gap between the two largest values of any 2x2 max-pool window with a positive maximum (fp64 oracle
+    forward, train-mode BN).  MaxPool backward routes the whole gradient to the arg-max: where the top two are within
+    rounding distance, ANY change of summation order (mkldnn vs MFMA tiles vs Winograd) may route it to the other pixel,
+    which moves one gradient element -- up to ~20 % of a channel's gradient on these tiny shapes.  Such inputs do not
+    test the kernels, so the cases below take the first seed whose forward is clear of near-ties."""
+    q = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in p.items()}
+    _, skips, _ = O.unet_forward(q, x.double(), depth, training=True, new_stats={})
+    gap = float("inf")
+    for sk in skips:
+        B, C, H, W = sk.shape
+        w = sk[:, :, : H // 2 * 2, : W // 2 * 2].reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, H // 2, W // 2, 4)
+        top = w.topk(2, dim=-1).values
+        live = top[..., 0] > 0
+        if bool(live.any()):
+            gap = min(gap, float((top[..., 0] - top[..., 1])[live].min()))
+    return gap
+
+
+def well_posed_case(cfg, shape, seed, tag="train"):
+    for sd in range(seed, seed + 50):
+        p = O.make_unet_params(*cfg, seed=sd)
+        x = torch.from_numpy(O.formula_normal(tag + "/x", shape, seed=sd))
+        if pool_margin(p, x, cfg[3]) > 5e-5:   # forward rounding differences are ~1e-5 at most
+            return sd, p, x
+    raise RuntimeError("no well-posed seed found")
+
+
 def build(cfg, seed, dev):
     m = mgunet.UNet(*cfg)
     m.load_state_dict(O.make_unet_params(*cfg, seed=seed))
@@ -44,12 +72,11 @@ def check_against(tr, model, ref_loss, ref_grads, ref_newp, ref_stats, names, lo
 @pytest.mark.parametrize("cfg,shape", [((3, 3, 8, 2), (2, 3, 37, 45)), ((1, 2, 8, 2), (1, 1, 32, 32)),
                                        ((3, 2, 16, 3), (2, 3, 48, 40))])
 def test_train_step_vs_oracle_small_and_ragged(cuda, cfg, shape):
-    p = O.make_unet_params(*cfg, seed=21)
-    x = torch.from_numpy(O.formula_normal("train/x", shape, seed=21))
+    seed, p, x = well_posed_case(cfg, shape, 21)
     y = torch.from_numpy(O.formula_labels("train/y", (shape[0], shape[2], shape[3]), cfg[1], seed=22))
     ref_loss, ref_g, ref_p, ref_stats, _, _ = O.train_step(p, x, y, cfg[3])
     names = list(ref_g.keys())
-    model = build(cfg, 21, cuda)
+    model = build(cfg, seed, cuda)
     assert [n for n, _ in model.named_parameters()] == names
     tr = mgunet.Trainer(model, lr=1e-3, weight_decay=1e-4)
     loss = tr.train_step(x.to(cuda), y.to(cuda))
