@@ -44,7 +44,7 @@ struct IgemmDesc {
 
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
 hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s);  // in / w / out point to bf16, sizes in elements
-// wino_f32.hip: Winograd F(2x2,3x3) for fp32 3x3 layers with Cp % 32 == 0
+// wino_f32.hip: Winograd F(2x2,3x3) for fp32 3x3 layers with Cp % 16 == 0
 size_t wino_u_floats(int Cout, int Cp);
 hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int Cp, int dgrad, hipStream_t s);
 bool wino_applicable(const IgemmDesc& d);

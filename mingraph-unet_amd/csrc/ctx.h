@@ -20,7 +20,7 @@ struct Layer {
   bool convt = false;
   int K = 0, Kp = 0, N = 0, Np = 0;
   float *wp = nullptr, *scale = nullptr, *shift = nullptr;
-  bool wino = false;     // fp32 3x3 layer with Cp % 32 == 0: Winograd-transformed weights kept in wu
+  bool wino = false;     // fp32 3x3 layer with Cp % 16 == 0: Winograd-transformed weights kept in wu
   float* wu = nullptr;
   // caller-owned parameter tensors recorded by load_weights (used by the training path)
   const float *w_src = nullptr, *b_src = nullptr, *gamma = nullptr, *beta = nullptr;

@@ -154,7 +154,7 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     L.N = L.convt ? 4 * L.Cout : L.Cout;
     L.Np = rup(L.N, 128);
     total += (size_t)L.Np * L.Kp + 2 * (size_t)L.Np + (L.bn.empty() ? 0 : 4 * (size_t)L.Np);
-    L.wino = dtype == MGU_DTYPE_F32 && !L.convt && L.KS == 3 && L.Cp % 32 == 0;   // Winograd F(2x2,3x3) layers (wino_f32.hip)
+    L.wino = dtype == MGU_DTYPE_F32 && !L.convt && L.KS == 3 && L.Cp % 16 == 0;   // Winograd F(2x2,3x3) layers (wino_f32.hip)
     if (L.wino) total += wino_u_floats(L.Cout, L.Cp);
   }
   // flat parameter order = the reference's named_parameters(): per ConvBlock conv1.{w,b}, conv2.{w,b},
@@ -464,7 +464,7 @@ int mgu_conv2d_nhwc(mgu_ctx* c, const void* in_dev, int B, int H, int W, int Cin
   int rc = block_scratch(c, L.Np, L.Kp, &L.wp, &sc, &sh, s);
   if (rc) return rc;
   HIPCHK(c, launch_pack_conv_w((const float*)w_dev, L.wp, 0, Cout, Cin, Cin, ksize, L.Kp, s));
-  if (ksize == 3 && Cin % 32 == 0 && use_wino()) {   // same routing as the model's layers: Winograd F(2x2,3x3)
+  if (ksize == 3 && Cin % 16 == 0 && use_wino()) {   // same routing as the model's layers: Winograd F(2x2,3x3)
     if ((rc = ensure(c, &c->wuws, &c->wuws_bytes, wino_u_floats(Cout, Cin) * sizeof(float)))) return rc;
     L.wu = (float*)c->wuws;
     HIPCHK(c, launch_pack_wino_w((const float*)w_dev, L.wu, Cout, Cin, Cin, 0, s));

@@ -81,6 +81,46 @@ def test_conv2d_exact_integer_data_asymmetric(cuda):
     assert torch.equal(conv_gpu(cuda, d, w2, torch.zeros(4), 3, 0).permute(0, 3, 1, 2), F.conv2d(d, w2, None, padding=1))
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (1, 5, 7, 16, 32),      # smaller than one 8x32 patch; N == 32 work split; one 16-channel chunk
+    (2, 12, 10, 64, 64),    # two ragged patch rows, 64-channel work split, four chunks
+    (1, 9, 70, 32, 96),     # three patch columns (last ragged), N tail inside a 64-channel n block
+    (3, 16, 32, 48, 40),    # exact patches, Cin = 3 chunks, N tail of the second n tile
+    (1, 31, 33, 128, 160),  # odd sizes both ways, three n blocks
+])
+def test_winograd_conv_vs_torch_and_direct(cuda, B, H, W, Cin, Cout, monkeypatch):
+    """The fp32 3x3 layers with Cin % 16 == 0 route to wino3x3_f32_kernel (Winograd F(2x2,3x3), csrc/wino_f32.hip):
+    compare against torch fp32 AND against the direct implicit-GEMM kernel (MGU_NO_WINOGRAD=1, read at mgu_create)
+    on the same operands, including the scale/shift/ReLU epilogue into a channel slice of a wider buffer."""
+    x = torch.from_numpy(O.formula_normal("kw/x", (B, Cin, H, W), seed=H))
+    w = torch.from_numpy(O.formula_uniform("kw/w", (Cout, Cin, 3, 3), -0.2, 0.2, seed=W))
+    b = torch.zeros(Cout)
+    sc = torch.from_numpy(O.formula_uniform("kw/sc", (Cout,), 0.5, 1.5, seed=1))
+    sh = torch.from_numpy(O.formula_uniform("kw/sh", (Cout,), -0.5, 0.5, seed=2))
+    ref = F.relu(F.conv2d(x, w, None, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ld, off = Cout + 24, 8
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+
+    def run():
+        from mgunet import gat as G
+        G._CTX.clear()   # new mgu_ctx: the environment switch is read by mgu_create
+        got = conv_gpu(cuda, x, w, b, 3, 1, ld_out=ld, c_off=off, scale=sc, shift=sh)
+        assert torch.all(got[..., :off] == -7.0) and torch.all(got[..., off + Cout:] == -7.0)
+        return got[..., off:off + Cout].permute(0, 3, 1, 2)
+
+    wino = run()
+    monkeypatch.setenv("MGU_NO_WINOGRAD", "1")
+    direct = run()
+    monkeypatch.delenv("MGU_NO_WINOGRAD")
+    from mgunet import gat as G
+    G._CTX.clear()
+    _context(cuda)   # mgu_create re-reads the environment: Winograd back on for the rest of the process
+    assert float((wino - ref).abs().max()) <= tol
+    assert float((direct - ref).abs().max()) <= tol
+    assert float((wino - direct).abs().max()) <= tol
+    assert not torch.equal(wino, direct)   # the two paths really are different kernels
+
+
 def test_conv2d_scale_shift_relu_and_channel_slice_store(cuda):
     x = torch.from_numpy(O.formula_normal("ks/x", (1, 16, 12, 10), seed=1))
     w = torch.from_numpy(O.formula_uniform("ks/w", (24, 16, 3, 3), -0.2, 0.2, seed=1))
