@@ -36,6 +36,9 @@ struct IgemmDesc {
   int out_mode;
   int ct_cout;     // out_mode 1: Cout (N == 4*Cout)
   int Hout, Wout;  // out_mode 1: output grid (>= 2H, 2W)
+  // optional fused MaxPool2d(2) of the output (Winograd kernel only): pool[(img, y/2, x/2)*ldpool + n], floor semantics
+  float* pool;
+  int ldpool;
   // optional split epilogue (out_mode 0): columns n >= split_n go to out2[m*ld2 + (n - split_n)] (0 = off)
   int split_n;
   float* out2;

@@ -303,7 +303,8 @@ int mgu_unet_reserve(mgu_ctx* c, int B, int H, int W, int training) {
 }  // extern "C"
 
 int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int B, int H, int W, void* out_v, int ldout,
-                    int coff, int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s) {
+                    int coff, int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s,
+                    void* pool, int ldpool, bool* pool_fused) {
   IgemmDesc d;
   memset(&d, 0, sizeof d);
   d.in = (const float*)in_v;   // element type follows c->dtype; the descriptor carries raw pointers
@@ -328,6 +329,11 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
   d.ct_cout = L.Cout;
   d.Hout = Hout;
   d.Wout = Wout;
+  if (pool_fused) *pool_fused = false;
+  if (pool && c->dtype == MGU_DTYPE_F32 && wino_applicable(d)) {   // the Winograd epilogue also writes the 2x2 max-pooled tensor
+    d.pool = (float*)pool, d.ldpool = ldpool;
+    if (pool_fused) *pool_fused = true;
+  }
   ProfScope ps(c, s);
   if (c->dtype == MGU_DTYPE_BF16) HIPCHK(c, launch_igemm_bf16(d, s));
   else HIPCHK(c, launch_igemm_f32(d, s));
@@ -335,8 +341,10 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
 }
 
 static int run_conv(mgu_ctx* c, const Layer& L, const void* in, int ldin, int B, int H, int W, void* out, int ldout,
-                    int coff, int relu, int Hout, int Wout, hipStream_t s) {  // eval: folded BN scale/shift
-  return run_layer(c, L, in, ldin, B, H, W, out, ldout, coff, relu, L.bn.empty() ? nullptr : L.scale, L.shift, Hout, Wout, s);
+                    int coff, int relu, int Hout, int Wout, hipStream_t s, void* pool = nullptr, int ldpool = 0,
+                    bool* pool_fused = nullptr) {  // eval: folded BN scale/shift
+  return run_layer(c, L, in, ldin, B, H, W, out, ldout, coff, relu, L.bn.empty() ? nullptr : L.scale, L.shift, Hout, Wout, s,
+                   pool, ldpool, pool_fused);
 }
 
 extern "C" {
@@ -395,9 +403,10 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
   for (int i = 0; i < depth; ++i) {  // encoder, unet_encoder.py:67-70
     const int C = c->feat << i;
     if ((rc = run_conv(c, c->layers[li++], cur, cur_ld, B, hs[i], wsz[i], tmp, C, 0, 1, 0, 0, s))) return rc;
-    if ((rc = run_conv(c, c->layers[li++], tmp, C, B, hs[i], wsz[i], cat_dev[i], 2 * C, 0, 1, 0, 0, s))) return rc;
     void* pooled = ws + plan.pooled[i];
-    HIPCHK(c, launch_maxpool2(cat_dev[i], 2 * C, pooled, c->dtype, B, hs[i], wsz[i], C, s));
+    bool fused = false;   // MaxPool2d(2) (unet_encoder.py:48) rides in the conv2 epilogue on the Winograd path
+    if ((rc = run_conv(c, c->layers[li++], tmp, C, B, hs[i], wsz[i], cat_dev[i], 2 * C, 0, 1, 0, 0, s, pooled, C, &fused))) return rc;
+    if (!fused) HIPCHK(c, launch_maxpool2(cat_dev[i], 2 * C, pooled, c->dtype, B, hs[i], wsz[i], C, s));
     cur = pooled;
     cur_ld = C;
   }

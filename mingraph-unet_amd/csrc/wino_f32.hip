@@ -32,6 +32,13 @@ namespace mgu {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Workgroup barrier for LDS hand-offs ONLY.  __syncthreads() is a workgroup-scope fence + barrier, and the fence makes
+// hipcc wait for vmcnt(0): every outstanding global load AND store (CDNA4 counts stores in vmcnt).  In this kernel that
+// meant each epilogue barrier waited for the round trip of the output stores just issued, and each chunk barrier for the
+// weight-fragment prefetch.  LDS operations of a wave complete in order, so lgkmcnt(0) before s_barrier is all a producer
+// needs; the "memory" clobber keeps the compiler from moving LDS accesses across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 static bool g_use_wino = true;   // MGU_NO_WINOGRAD=1: direct (halo implicit-GEMM) kernels only
 void set_use_wino(bool on) { g_use_wino = on; }
 bool use_wino() { return g_use_wino; }
@@ -99,10 +106,12 @@ template <int MODE>
 __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y, const int total_patches,
                         const int patches_per_block, const int ngroups, const int nitems, const int per_xcd) {
   constexpr int NWAVES = 8;
-  constexpr int NG = NWAVES / 4;                 // wave groups
   constexpr int MT = MODE == 1 ? 1 : 2;          // m tiles per wavefront
   constexpr int NTB = MODE == 0 ? 2 : 1;         // n tiles (32 output channels) per workgroup
-  constexpr int ZMT = MT;                        // m tiles per exchange pass
+  constexpr int NC = 32 * NTB;                   // output channels per workgroup
+  constexpr int ZP = NC + 8;                     // exchange-buffer pitch of a tile (floats)
+  constexpr int QPT = NC / 4;                    // channel quads per tile
+  constexpr int UPT = 64 * QPT / 512;            // (tile, channel quad) units a thread finishes per pass
   constexpr int RH = 10, RW = 34, HPIX = RH * RW;   // raw halo of the 8 x 32 pixel patch
   constexpr int PLD = 20;                        // floats per raw pixel in LDS: 16 channels + 4 pad (80 bytes: 16 lanes
                                                  // of a ds_read_b128 group, one pixel apart, hit 16 distinct 4-bank slots)
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   constexpr int RAWF = HR * HSTRIDE / RW * 34 * PLD + 34 * PLD;   // floats per raw buffer, padded: the staging pass of the
                                                  // threads past HPIX stores (never read) dummies instead of branching
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Zx = smem + 2 * RAWF;      // [4 rows i][NG][ZMT][16 regs][64 lanes]
+  float* Zx = smem + 2 * RAWF;      // [4 rows i][64 tiles][ZP]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -202,6 +211,19 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
     lp += lc == 0 ? 1 : 0;
   };
 
+  // finishing role of this thread in the epilogue: channel quad cq of the workgroup's NC channels (same for all its units)
+  const int cq = tid % QPT;
+  const int n0 = nblock * NC + cq * 4;
+  // 16-byte stores need whole, aligned channel quads
+  const bool fast_n = (d.N % NC == 0) && (d.ldout % 4 == 0) && (d.coff % 4 == 0) && (!d.pool || d.ldpool % 4 == 0);
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (n0 + e < d.N) {
+      if (d.scale) sc4[e] = d.scale[n0 + e];
+      if (d.shift) sh4[e] = d.shift[n0 + e];
+    }
+
   f32x4 bf[2][4];
   auto load_b = [&](int cg, int slot) {
 #pragma unroll
@@ -227,7 +249,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   for (int pi = 0; pi < npatch; ++pi) {
     for (int c = 0; c < nC; ++c) {
       prep_next();
-      __syncthreads();   // the chunk to compute is visible in buffer buf; every wave has left buffer buf ^ 1
+      lds_barrier();   // the chunk to compute is visible in buffer buf; every wave has left buffer buf ^ 1
       const float* Hs = smem + buf * RAWF;
       auto operands = [&](const int kg, const int mi, f32x4 (&v)[4]) {   // V[i][0..3] of this lane's tile, 4 channels
         const float* pa = Hs + offA[mi] + kg * 8;
@@ -308,71 +330,87 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
       buf ^= 1;
     }
     // ---- inverse transform + epilogue of patch pi --------------------------------------------------------
+    // The column part (M[i][.] A) is folded in registers; the four row waves then meet in LDS.  The exchange buffer is
+    // [row i][tile 0..63][channel] (channel fastest, pitch NC + 8: the two 32-lane halves of a store land in different
+    // bank halves), so the FINISHING threads can each take one tile and FOUR consecutive channels: 16-byte loads of the
+    // four rows' partial sums, and 16-byte global stores in which 16 (8) lanes cover one pixel's 256 (128) contiguous
+    // bytes -- a quarter of the store instructions of a lane-per-channel epilogue, all full lines.  (Store instruction
+    // issue, not bytes, was what made the epilogue cost as much as a whole 16-channel chunk.)
     int img, y0, x0;
     setup_patch(p_begin + pi, img, y0, x0);
     float* const img_out = d.out + (size_t)img * d.H * d.W * d.ldout + d.coff;
-    const int n = ntg * 32 + lr;
-    const bool nvalid = n < d.N;
-    const float sc = (nvalid && d.scale) ? d.scale[n] : 1.f;
-    const float sh = (nvalid && d.shift) ? d.shift[n] : 0.f;
     const unsigned sW = (unsigned)(d.W * d.ldout);
-    // block-uniform fast path: a patch inside the image with whole n tiles stores without per-element branches (hipcc
-    // puts an s_waitcnt vmcnt(0) in front of every conditional store, which serialises the store round trips)
-    const bool interior = (y0 + 8 <= d.H) && (x0 + 32 <= d.W) && (d.N % (32 * NTB) == 0);
+    const bool interior = (y0 + 8 <= d.H) && (x0 + 32 <= d.W) && fast_n;   // block-uniform
+    float* pool_out = nullptr;   // fused MaxPool2d(2): a Winograd tile IS a pooling window
+    if (d.pool) pool_out = d.pool + (size_t)img * (d.H >> 1) * (d.W >> 1) * d.ldpool;
+    f32x4 pmax[UPT];
 #pragma unroll
-    for (int mp = 0; mp < MT / ZMT; ++mp) {   // exchange passes over the m tiles
+    for (int q = 0; q < 2; ++q) {
+      // column part: Z[i][q] = sum_j M[i][j] A[j][q]   (A^T = [1 1 1 0; 0 1 -1 -1])
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        // column part in registers: Z[i][q] = sum_j M[i][j] A[j][q]   (A^T = [1 1 1 0; 0 1 -1 -1]); the exchange buffer
-        // is [src row i][g][m][register quad][lane][4]: 16-byte LDS writes, and the quad a wave finishes is one read
+      for (int mi = 0; mi < MT; ++mi) {
+        const int m_abs = MODE == 1 ? wg : mi;
 #pragma unroll
-        for (int zi = 0; zi < ZMT; ++zi) {
-          const int mi = mp * ZMT + zi;
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) {
-            f32x4 z;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int r = 4 * rq + e;
-              z[e] = q == 0 ? (acc[0][mi][r] + acc[1][mi][r] + acc[2][mi][r]) : (acc[1][mi][r] - acc[2][mi][r] - acc[3][mi][r]);
-            }
-            *reinterpret_cast<f32x4*>(Zx + ((((wi * NG + wg) * ZMT + zi) * 4 + rq) * 64 + lane) * 4) = z;
-          }
+        for (int r = 0; r < 16; ++r) {
+          const float z = q == 0 ? (acc[0][mi][r] + acc[1][mi][r] + acc[2][mi][r]) : (acc[1][mi][r] - acc[2][mi][r] - acc[3][mi][r]);
+          const int T = m_abs * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          Zx[(wi * 64 + T) * ZP + (MODE == 0 ? wg * 32 : 0) + lr] = z;
         }
-        __syncthreads();
-        // row part: wave i finishes accumulator registers 4i .. 4i+3 (tile row 2m + (i>>1), tiles 8(i&1) + 4h + 0..3)
-        auto finish = [&](auto guarded) {
+      }
+      lds_barrier();
+      // row part + epilogue: unit u = (tile, channel quad); y(2tr, .) = Z0 + Z1 + Z2, y(2tr+1, .) = Z1 - Z2 - Z3
 #pragma unroll
-          for (int zi = 0; zi < ZMT; ++zi) {
-            const int mi = mp * ZMT + zi;
-            const int m_abs = MODE == 1 ? wg : mi;
-            const int oy = y0 + 2 * (2 * m_abs + (wi >> 1));
-            const int ox0 = x0 + 2 * (8 * (wi & 1) + 4 * lh) + q;
-            const unsigned idx0 = (unsigned)((oy * d.W + ox0) * d.ldout + n);
-            const f32x4 z0 = *reinterpret_cast<const f32x4*>(Zx + ((((0 * NG + wg) * ZMT + zi) * 4 + wi) * 64 + lane) * 4);
-            const f32x4 z1 = *reinterpret_cast<const f32x4*>(Zx + ((((1 * NG + wg) * ZMT + zi) * 4 + wi) * 64 + lane) * 4);
-            const f32x4 z2 = *reinterpret_cast<const f32x4*>(Zx + ((((2 * NG + wg) * ZMT + zi) * 4 + wi) * 64 + lane) * 4);
-            const f32x4 z3 = *reinterpret_cast<const f32x4*>(Zx + ((((3 * NG + wg) * ZMT + zi) * 4 + wi) * 64 + lane) * 4);
+      for (int k = 0; k < UPT; ++k) {
+        const int u = tid + k * 512;
+        const int T = u / QPT;
+        const float* zp = Zx + T * ZP + cq * 4;
+        const f32x4 z0 = *reinterpret_cast<const f32x4*>(zp);
+        const f32x4 z1 = *reinterpret_cast<const f32x4*>(zp + 64 * ZP);
+        const f32x4 z2 = *reinterpret_cast<const f32x4*>(zp + 128 * ZP);
+        const f32x4 z3 = *reinterpret_cast<const f32x4*>(zp + 192 * ZP);
+        f32x4 ya = (z0 + z1 + z2) * sc4 + sh4;
+        f32x4 yb = (z1 - z2 - z3) * sc4 + sh4;
+        if (d.relu) {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              float ya = (z0[rr] + z1[rr] + z2[rr]) * sc + sh;    // output row 2*tr
-              float yb = (z1[rr] - z2[rr] - z3[rr]) * sc + sh;    // output row 2*tr + 1
-              if (d.relu) ya = fmaxf(ya, 0.f), yb = fmaxf(yb, 0.f);
-              const unsigned idx = idx0 + (unsigned)(2 * rr * d.ldout);
-              if (!decltype(guarded)::value) {
-                img_out[idx] = ya;
-                img_out[idx + sW] = yb;
-              } else if (nvalid && ox0 + 2 * rr < d.W) {
-                if (oy < d.H) img_out[idx] = ya;
-                if (oy + 1 < d.H) img_out[idx + sW] = yb;
+          for (int e = 0; e < 4; ++e) ya[e] = fmaxf(ya[e], 0.f), yb[e] = fmaxf(yb[e], 0.f);
+        }
+        const int oy = y0 + 2 * (T >> 4), ox = x0 + 2 * (T & 15) + q;
+        const unsigned idx = (unsigned)((oy * d.W + ox) * d.ldout + n0);
+        if (interior) {
+          *reinterpret_cast<f32x4*>(img_out + idx) = ya;
+          *reinterpret_cast<f32x4*>(img_out + idx + sW) = yb;
+        } else if (ox < d.W) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n0 + e < d.N) {
+              if (oy < d.H) img_out[idx + e] = ya[e];
+              if (oy + 1 < d.H) img_out[idx + sW + e] = yb[e];
+            }
+        }
+        if (d.pool) {
+          f32x4 m;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[e] = fmaxf(ya[e], yb[e]);
+          if (q == 0) {
+            pmax[k] = m;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], pmax[k][e]);
+            const int py = oy >> 1, px = ox >> 1;   // floor semantics of MaxPool2d: windows fully inside the image
+            if (oy + 1 < d.H && ox < d.W) {
+              float* pp = pool_out + (size_t)(py * (d.W >> 1) + px) * d.ldpool + n0;
+              if (fast_n) {
+                *reinterpret_cast<f32x4*>(pp) = m;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (n0 + e < d.N) pp[e] = m[e];
               }
             }
           }
-        };
-        if (interior) finish(std::false_type{});
-        else finish(std::true_type{});
-        __syncthreads();   // Zx is rewritten by the next pass / patch
+        }
       }
+      lds_barrier();   // Zx is rewritten by the next pass / patch
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -388,8 +426,7 @@ void set_wino_mode(int v) { g_wino_mode = v; }
 
 template <int MODE>
 static hipError_t launch_wino_mode(const IgemmDesc& d, hipStream_t s) {
-  constexpr int NTB = MODE == 0 ? 2 : 1, NWAVES = 8, NG = NWAVES / 4;
-  constexpr int ZMT = MODE == 0 ? 2 : 1;
+  constexpr int NTB = MODE == 0 ? 2 : 1, NWAVES = 8;
   const int tiles_x = (d.W + 31) / 32, tiles_y = (d.H + 7) / 8;
   const int B = d.M / (d.H * d.W);
   const int total = tiles_x * tiles_y * B, nblk = (d.N + 32 * NTB - 1) / (32 * NTB);
@@ -402,7 +439,7 @@ static hipError_t launch_wino_mode(const IgemmDesc& d, hipStream_t s) {
   dim3 grid(8 * per_xcd, 1);
   constexpr int HSTRIDE = NWAVES * 16, HR = (340 + HSTRIDE - 1) / HSTRIDE;
   constexpr int RAWF = HR * HSTRIDE / 34 * 34 * 20 + 34 * 20;   // must match the kernel
-  const size_t lds = (size_t)(2 * RAWF + 4 * NG * ZMT * 16 * 64) * sizeof(float);
+  const size_t lds = (size_t)(2 * RAWF + 4 * 64 * (32 * NTB + 8)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino3x3_f32_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
