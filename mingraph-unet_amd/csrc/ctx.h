@@ -20,8 +20,10 @@ struct Layer {
   bool convt = false;
   int K = 0, Kp = 0, N = 0, Np = 0;
   float *wp = nullptr, *scale = nullptr, *shift = nullptr;
+  bool first = false;    // fp32 first convolution (<= 4 input channels): VALU kernel, weights kept in wf
   bool wino = false;     // fp32 3x3 layer with Cp % 16 == 0: Winograd-transformed weights kept in wu
   float* wu = nullptr;
+  float* wf = nullptr;   // first conv (Cp == 4): [9][4][Cout] weights for conv3x3_first_kernel
   // caller-owned parameter tensors recorded by load_weights (used by the training path)
   const float *w_src = nullptr, *b_src = nullptr, *gamma = nullptr, *beta = nullptr;
   float *run_mean = nullptr, *run_var = nullptr;

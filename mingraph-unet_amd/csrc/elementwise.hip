@@ -290,6 +290,112 @@ hipError_t launch_conv1x1_head(const void* in, int dtype, int ldin, int C, const
   return hipGetLastError();
 }
 
+// ---- first convolution: Conv2d(in_channels <= 4 -> NCO, k3, p1) on the packed NHWC4 input -----------------------
+// K = 27..36 is far too short for an MFMA tile pipeline (the implicit-GEMM kernel spent its time in gather setup and
+// epilogue: 146 us at 8 x 512^2, against ~65 us for the 302 MB it has to move).  One thread owns one pixel and all NCO
+// output channels: the nine taps are nine coalesced 16-byte loads, the weights are wave-uniform, so they arrive through
+// the scalar cache and every multiply-add is a VALU op with an SGPR operand -- no LDS, no barrier; the 128-byte channel
+// vector of the pixel is stored as NCO/4 16-byte pieces.  HBM-bound.
+template <int NCO, int CIN>
+__global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restrict__ in /*NHWC4*/, const float* __restrict__ wf /*[9][4][NCO]*/,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            float* __restrict__ out, int64_t npix, int H, int W, int ldout, int coff,
+                                                            int relu) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < npix;   // (lanes past the end still take part in the wave's LDS transpose)
+  const int x = (int)(p % W);
+  const int y = (int)((p / W) % H);
+  float acc[NCO];
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) acc[co] = 0.f;
+  const float* base = in + p * 4;
+  // one tap per trip, NOT unrolled: unrolled, hipcc hoists all 9 * CIN * NCO scalar weight loads to the top and spills
+  // hundreds of SGPRs through v_writelane/v_readlane
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int r = tap / 3, sx = tap - 3 * r;
+    const bool ok = live && (unsigned)(y + r - 1) < (unsigned)H && (unsigned)(x + sx - 1) < (unsigned)W;
+    // unconditional load from a mapped address + select (a branch around a load serialises the batch)
+    const float4 v = *reinterpret_cast<const float4*>(ok ? base + ((r - 1) * W + (sx - 1)) * 4 : in);
+    const float vv[4] = {ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f};
+    const float* wt = wf + tap * 4 * NCO;   // wave-uniform: scalar loads
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+      for (int co = 0; co < NCO; ++co) acc[co] = fmaf(vv[c], wt[c * NCO + co], acc[co]);
+  }
+  // Epilogue.  A lane holds the NCO channels of ONE pixel: stored directly, a 16-byte store instruction would touch 64
+  // different lines.  Each wave transposes through its own LDS slab instead ([64 pixels][NCO + 4 floats], conflict-free
+  // 16-byte writes and reads) so that NCO/4 consecutive lanes cover one pixel and a store instruction writes
+  // 64 * 16 bytes of CONSECUTIVE pixels (the NHWC rows of a wave's 64 pixels are contiguous when ldout == NCO).
+  __shared__ __attribute__((aligned(16))) float tr[4][64 * (NCO + 4)];
+  float* slab = tr[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < NCO / 4; ++q) {
+    float4 t;
+    float* tp = &t.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = 4 * q + e;
+      float vq = acc[co] * (scale ? scale[co] : 1.f) + (shift ? shift[co] : 0.f);
+      tp[e] = relu ? fmaxf(vq, 0.f) : vq;
+    }
+    *reinterpret_cast<float4*>(slab + lane * (NCO + 4) + 4 * q) = t;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  constexpr int LPP = NCO / 4;            // lanes per pixel
+  constexpr int PPI = 64 / LPP;           // pixels per store instruction
+  const int64_t p0 = p - lane;            // first pixel of this wave (wave-uniform)
+  const int qd = lane % LPP, pl = lane / LPP;
+#pragma unroll
+  for (int k = 0; k < LPP; ++k) {
+    const int px = pl + k * PPI;          // pixel of the wave this lane stores in pass k
+    const float4 t = *reinterpret_cast<const float4*>(slab + px * (NCO + 4) + 4 * qd);
+    if (p0 + px < npix) *reinterpret_cast<float4*>(out + (p0 + px) * ldout + coff + 4 * qd) = t;
+  }
+}
+
+// wf[tap][c][co] = w[co][c][tap] (OIHW), zero for c >= Cin
+__global__ void pack_first_w_kernel(const float* __restrict__ w, float* __restrict__ wf, int Cout, int Cin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * 4 * Cout) return;
+  const int co = i % Cout, c = (i / Cout) % 4, tap = i / (4 * Cout);
+  wf[i] = c < Cin ? w[((int64_t)co * Cin + c) * 9 + tap] : 0.f;
+}
+
+hipError_t launch_pack_first_w(const float* w, float* wf, int Cout, int Cin, hipStream_t s) {
+  hipLaunchKernelGGL(pack_first_w_kernel, dim3((9 * 4 * Cout + 255) / 256), dim3(256), 0, s, w, wf, Cout, Cin);
+  return hipGetLastError();
+}
+
+bool first_conv_applicable(int Cin, int Cp, int Cout, int ldout, int coff) {
+  return Cp == 4 && Cin >= 1 && Cin <= 4 && (Cout == 16 || Cout == 32 || Cout == 64) && (ldout % 4) == 0 && (coff % 4) == 0;
+}
+
+hipError_t launch_first_conv(const float* in, const float* wf, const float* scale, const float* shift, float* out, int B, int H, int W,
+                             int Cin, int Cout, int ldout, int coff, int relu, hipStream_t s) {
+  const int64_t npix = (int64_t)B * H * W;
+  const dim3 grid((unsigned)((npix + 255) / 256)), block(256);
+#define MGU_FC(NCO, CIN) hipLaunchKernelGGL((conv3x3_first_kernel<NCO, CIN>), grid, block, 0, s, in, wf, scale, shift, out, npix, H, W, ldout, coff, relu)
+#define MGU_FC_CIN(NCO)            \
+  do {                             \
+    if (Cin == 1) MGU_FC(NCO, 1);  \
+    else if (Cin == 2) MGU_FC(NCO, 2); \
+    else if (Cin == 3) MGU_FC(NCO, 3); \
+    else MGU_FC(NCO, 4);           \
+  } while (0)
+  if (Cout == 16) MGU_FC_CIN(16);
+  else if (Cout == 32) MGU_FC_CIN(32);
+  else if (Cout == 64) MGU_FC_CIN(64);
+  else return hipErrorInvalidValue;
+#undef MGU_FC_CIN
+#undef MGU_FC
+  return hipGetLastError();
+}
+
 // ---- argmax over classes (first maximal index, like torch.argmax on distinct values) ---------------
 __global__ void argmax_kernel(const float* __restrict__ logits, int64_t npix, int C, int64_t* __restrict__ pred) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {

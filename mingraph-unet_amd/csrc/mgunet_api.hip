@@ -156,6 +156,8 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     total += (size_t)L.Np * L.Kp + 2 * (size_t)L.Np + (L.bn.empty() ? 0 : 4 * (size_t)L.Np);
     L.wino = dtype == MGU_DTYPE_F32 && !L.convt && L.KS == 3 && L.Cp % 16 == 0;   // Winograd F(2x2,3x3) layers (wino_f32.hip)
     if (L.wino) total += wino_u_floats(L.Cout, L.Cp);
+    L.first = dtype == MGU_DTYPE_F32 && !L.convt && L.KS == 3 && first_conv_applicable(L.Cin, L.Cp, L.Cout, 4, 0);
+    if (L.first) total += 9 * 4 * (size_t)L.Cout;
   }
   // flat parameter order = the reference's named_parameters(): per ConvBlock conv1.{w,b}, conv2.{w,b},
   // bn1.{w,b}, bn2.{w,b} (unet_encoder.py:7-13); decoder block: upsample.{w,b} then its conv_block; final.
@@ -199,6 +201,8 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     p += L.Np;
     L.wu = nullptr;
     if (L.wino) L.wu = p, p += wino_u_floats(L.Cout, L.Cp);
+    L.wf = nullptr;
+    if (L.first) L.wf = p, p += 9 * 4 * (size_t)L.Cout;
     if (!L.bn.empty()) {
       L.mean = p, p += L.Np;
       L.invstd = p, p += L.Np;
@@ -266,6 +270,7 @@ int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void*
       L.w_src = w, L.b_src = b;
       HIPCHK(c, launch_pack_conv_w(w, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
       if (L.wu) HIPCHK(c, launch_pack_wino_w(w, L.wu, L.Cout, L.Cin, L.Cp, 0, s));
+      if (L.wf) HIPCHK(c, launch_pack_first_w(w, L.wf, L.Cout, L.Cin, s));
       if (!L.bn.empty()) {
         const float *g, *be, *rm, *rv;
         const std::string bn = L.prefix + L.bn;
@@ -330,6 +335,12 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
   d.Hout = Hout;
   d.Wout = Wout;
   if (pool_fused) *pool_fused = false;
+  if (L.wf && c->dtype == MGU_DTYPE_F32 && ldin == 4 && first_conv_applicable(L.Cin, L.Cp, L.Cout, ldout, coff) &&
+      (int64_t)B * H * W * std::max(ldout, 4) < (1ll << 31)) {
+    ProfScope ps(c, s);
+    HIPCHK(c, launch_first_conv((const float*)in_v, L.wf, scale, shift, (float*)out_v, B, H, W, L.Cin, L.Cout, ldout, coff, relu, s));
+    return MGU_OK;
+  }
   if (pool && c->dtype == MGU_DTYPE_F32 && wino_applicable(d)) {   // the Winograd epilogue also writes the 2x2 max-pooled tensor
     d.pool = (float*)pool, d.ldpool = ldpool;
     if (pool_fused) *pool_fused = true;
