@@ -20,6 +20,7 @@
 //     channel pitch/offset so encoder outputs and the pixel-shuffled ConvTranspose outputs land
 //     directly in the two halves of the decoder's concat buffer (torch.cat never materialises).
 #include "common.h"
+#include <type_traits>
 
 namespace mgu {
 
@@ -200,60 +201,73 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
   // accumulator register made the epilogue ~5000 VALU instructions per wave (the K = 64 full-resolution layer
   // spent more time there than in its MFMAs).  Each row's output pixel index is computed ONCE per workgroup
   // into LDS (the tile buffers are free after the last barrier) and read back per register.
-  long long* rowpix = reinterpret_cast<long long*>(smem_raw);
+  // Every row's element offset (relative to the tile's first output pixel, 32 bit) is computed ONCE per workgroup into
+  // LDS (the tile buffers are free after the last barrier) and read back per register.
+  int* rowoff = reinterpret_cast<int*>(smem_raw);
+  long long pix0 = 0;   // OUTMODE 1: output pixel of the tile's first row (block-uniform)
   if (OUTMODE == 1) {
+    {
+      const int img = bm0 / HW;
+      const int rem = bm0 - img * HW;
+      const int y = rem / d.W;
+      pix0 = ((long long)img * d.Hout + 2 * y) * d.Wout + 2 * (rem - y * d.W);
+    }
     for (int rrow = tid; rrow < BM; rrow += 256) {
       const int m = bm0 + rrow;
-      long long pix = -1;
+      int off = 0;
       if (m < d.M) {
         const int img = m / HW;
         const int rem = m - img * HW;
         const int y = rem / d.W;
         const int x = rem - y * d.W;
-        pix = ((long long)img * d.Hout + 2 * y) * d.Wout + 2 * x;
+        off = (int)((((long long)img * d.Hout + 2 * y) * d.Wout + 2 * x - pix0) * d.ldout);   // a tile spans < 2^31 elements
       }
-      rowpix[rrow] = pix;
+      rowoff[rrow] = off;
     }
     __syncthreads();
   }
-  // Address arithmetic is kept off the per-element path: a uniform 64-bit tile base + a 32-bit element index
-  // (rows of a tile span < 2^31 elements), and the m < M test only exists on the last (partial) row tile.
+  // Address arithmetic is kept off the per-element path: a uniform 64-bit tile base + a 32-bit element index, and
+  // the stores of a full tile carry NO per-element condition (hipcc puts an s_waitcnt vmcnt(0) in front of every
+  // conditional store, which serialises the store round trips: that, not the MFMAs, bounded the K-short layers).
   const bool full_m = bm0 + BM <= d.M;   // block-uniform
+  const bool full_n = bn0 + BN <= d.N;   // block-uniform
   T* const out_t = reinterpret_cast<T*>(d.out);
-  T* const tile_out = out_t + (size_t)bm0 * d.ldout + d.coff;
+  T* const tile_out = OUTMODE == 1 ? out_t + (size_t)pix0 * d.ldout + d.coff : out_t + (size_t)bm0 * d.ldout + d.coff;
+  auto store_tile = [&](auto guarded_t) {
+    constexpr bool GUARDED = decltype(guarded_t)::value;
 #pragma unroll
-  for (int ni = 0; ni < WNT; ++ni) {
-    const int n = bn0 + (wn * WNT + ni) * 32 + lr;
-    const bool nvalid = n < d.N;
-    const float sc = (nvalid && d.scale) ? d.scale[n] : 1.f;
-    const float sh = (nvalid && d.shift) ? d.shift[n] : 0.f;
-    long long qoff = 0;   // OUTMODE 1: pixel offset of tap q = (dy, dx) and the channel inside the pixel
-    int co = n;
-    if (OUTMODE == 1) {
-      const int q = n / d.ct_cout;
-      co = n - q * d.ct_cout;
-      qoff = (long long)(q >> 1) * d.Wout + (q & 1);
-    }
-    const bool split = OUTMODE == 0 && d.split_n > 0 && n >= d.split_n;
+    for (int ni = 0; ni < WNT; ++ni) {
+      const int n = bn0 + (wn * WNT + ni) * 32 + lr;
+      const bool nvalid = n < d.N;
+      const float sc = (nvalid && d.scale) ? d.scale[n] : 1.f;
+      const float sh = (nvalid && d.shift) ? d.shift[n] : 0.f;
+      int ncol = n;   // element offset of column n inside a row's pixel (OUTMODE 1: tap q = (dy, dx) + channel)
+      if (OUTMODE == 1) {
+        const int q = n / d.ct_cout;
+        ncol = ((q >> 1) * d.Wout + (q & 1)) * d.ldout + (n - q * d.ct_cout);
+      }
+      const bool split = OUTMODE == 0 && d.split_n > 0 && n >= d.split_n;
 #pragma unroll
-    for (int mi = 0; mi < WMT; ++mi) {
+      for (int mi = 0; mi < WMT; ++mi) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int rrow = (wm * WMT + mi) * 32 + row;
-        if (nvalid && (full_m || bm0 + rrow < d.M)) {
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int rrow = (wm * WMT + mi) * 32 + row;
           float v = acc[mi][ni][r] * sc + sh;
           if (d.relu) v = fmaxf(v, 0.f);
-          if (OUTMODE == 0) {
+          const unsigned idx = OUTMODE == 1 ? (unsigned)(rowoff[rrow] + ncol) : (unsigned)(rrow * d.ldout + ncol);
+          if (!GUARDED) {
+            tile_out[idx] = (T)v;
+          } else if (nvalid && (full_m || bm0 + rrow < d.M)) {
             if (split) d.out2[(size_t)(bm0 + rrow) * d.ld2 + (n - d.split_n)] = v;   // always fp32 (GAT scalars)
-            else tile_out[(unsigned)(rrow * d.ldout + n)] = (T)v;
-          } else {
-            out_t[(size_t)(rowpix[rrow] + qoff) * d.ldout + d.coff + co] = (T)v;
+            else tile_out[idx] = (T)v;
           }
         }
       }
     }
-  }
+  };
+  if (full_m && full_n && !(OUTMODE == 0 && d.split_n > 0)) store_tile(std::false_type{});
+  else store_tile(std::true_type{});
 }
 
 // =================================================================================================
