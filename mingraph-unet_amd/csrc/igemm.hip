@@ -469,34 +469,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
         // uniform 64-bit image base + 32-bit element index; per element only one add (row/col constants fold
         // into scalar multiples of W*ldout and ldout), bounds tests only on patches that cross the image edge
         T* const img_out = reinterpret_cast<T*>(d.out) + (size_t)img * d.H * d.W * d.ldout + d.coff;
-        const bool interior = (y0 + TH <= d.H) && (x0 + TW <= d.W);   // block-uniform
+        // block-uniform fast path: a patch inside the image with whole n tiles stores with NO per-element condition
+        // (hipcc puts an s_waitcnt vmcnt(0) in front of every conditional store: serialised store round trips)
+        const bool interior = (y0 + TH <= d.H) && (x0 + TW <= d.W) && (bn0 + BN <= d.N);
         const unsigned sA = (unsigned)(d.W * d.ldout), sB = (unsigned)d.ldout;
+        auto store_patch = [&](auto guarded_t) {
+          constexpr bool GUARDED = decltype(guarded_t)::value;
 #pragma unroll
-        for (int ni = 0; ni < WNT; ++ni) {
-          const int n = bn0 + (wn * WNT + ni) * 32 + lr;
-          const bool nvalid = n < d.N;
-          const float sc = (nvalid && d.scale) ? d.scale[n] : 1.f;
-          const float sh = (nvalid && d.shift) ? d.shift[n] : 0.f;
-          const unsigned lane_idx = (unsigned)((y0 * d.W + x0 + 4 * lh) * d.ldout + n);
+          for (int ni = 0; ni < WNT; ++ni) {
+            const int n = bn0 + (wn * WNT + ni) * 32 + lr;
+            const bool nvalid = n < d.N;
+            const float sc = (nvalid && d.scale) ? d.scale[n] : 1.f;
+            const float sh = (nvalid && d.shift) ? d.shift[n] : 0.f;
+            const unsigned lane_idx = (unsigned)((y0 * d.W + x0 + 4 * lh) * d.ldout + n);
 #pragma unroll
-          for (int mi = 0; mi < WMT; ++mi) {
+            for (int mi = 0; mi < WMT; ++mi) {
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-              // pixel of this accumulator register inside the patch: pp = 32*(wm*WMT+mi) + 8*(rr>>2) + 4*lh + (rr&3)
-              const int pyc = 2 * (wm * WMT + mi) + (rr >> 3);            // patch row    (lane independent)
-              const int pxc = 8 * ((rr >> 2) & 1) + (rr & 3);             // patch column (without the 4*lh part)
-              float v = acc[mi][ni][rr] * sc + sh;
-              if (d.relu) v = fmaxf(v, 0.f);
-              const unsigned idx = lane_idx + (unsigned)pyc * sA + (unsigned)pxc * sB;
-              if (interior) {
-                if (nvalid) img_out[idx] = (T)v;
-              } else if (nvalid && y0 + pyc < d.H && x0 + pxc + 4 * lh < d.W) {
-                img_out[idx] = (T)v;
+              for (int rr = 0; rr < 16; ++rr) {
+                // pixel of this accumulator register inside the patch: pp = 32*(wm*WMT+mi) + 8*(rr>>2) + 4*lh + (rr&3)
+                const int pyc = 2 * (wm * WMT + mi) + (rr >> 3);            // patch row    (lane independent)
+                const int pxc = 8 * ((rr >> 2) & 1) + (rr & 3);             // patch column (without the 4*lh part)
+                float v = acc[mi][ni][rr] * sc + sh;
+                if (d.relu) v = fmaxf(v, 0.f);
+                const unsigned idx = lane_idx + (unsigned)pyc * sA + (unsigned)pxc * sB;
+                if (!GUARDED) {
+                  img_out[idx] = (T)v;
+                } else if (nvalid && y0 + pyc < d.H && x0 + pxc + 4 * lh < d.W) {
+                  img_out[idx] = (T)v;
+                }
+                acc[mi][ni][rr] = 0.f;
               }
-              acc[mi][ni][rr] = 0.f;
             }
           }
-        }
+        };
+        if (interior) store_patch(std::false_type{});
+        else store_patch(std::true_type{});
         c = 0;
         ++pi;
       } else {
