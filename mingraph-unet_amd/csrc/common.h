@@ -128,7 +128,17 @@ hipError_t launch_conv1x1_head(const void* in, int dtype, int ldin, int C, const
 hipError_t launch_argmax(const float* logits, int64_t npix, int C, int64_t* pred, hipStream_t s);
 
 // gat.hip
-hipError_t launch_gat_wa_rows(const float* W, const float* a, float* panel, int heads, int Fh, int Fin, int Kp, hipStream_t s);
+hipError_t launch_gat_wa_rows(const float* W, const float* a, float* panel, int row0, int heads, int Fh, int Fin, int Kp, hipStream_t s);
+// gat_fused.hip: aggregate-first path (Fin <= F')
+bool gat_fused_applicable(int Fin, int heads, int Fh, int64_t E);
+size_t gat_fused_scratch_floats(int Fin, int heads, int Fh);
+hipError_t launch_gat_prep(const float* W, const float* a, float* wa, float* Wf, int heads, int Fh, int Fin, const int32_t* gp, int G,
+                           int N, int32_t* node_graph, unsigned* gmax, hipStream_t s);
+hipError_t launch_gat_st(const float* x, const float* wa, int N, int Fin, int heads, float* st, hipStream_t s);
+hipError_t launch_pack_gat_wf(const float* W, float* Wf, int heads, int Fh, int Fin, hipStream_t s);
+hipError_t launch_gat_fused(const float* x, int Fin, const float* st, const int32_t* rowptr, const int32_t* col,
+                            const int32_t* node_graph, const unsigned* gmax, const float* Wf, int N, int heads, int Fh, int concat,
+                            float alpha, float* out, hipStream_t s);
 hipError_t launch_gat_node_graph(const int32_t* gp, int G, int nodes_per_graph, int N, int32_t* node_graph, hipStream_t s);
 hipError_t launch_gat_edge_max(const float* st, const int32_t* rowptr, const int32_t* col, const int32_t* node_graph, int N,
                                int heads, float alpha, unsigned* gmax_enc, hipStream_t s);

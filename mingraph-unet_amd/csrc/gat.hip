@@ -58,10 +58,10 @@ hipError_t launch_gat_node_graph(const int32_t* gp, int G, int nodes_per_graph, 
 constexpr int GAT_MAX_HF = 1024;
 
 __global__ __launch_bounds__(256) void gat_wa_rows_kernel(const float* __restrict__ W, const float* __restrict__ a,
-                                                          float* __restrict__ panel, int heads, int Fh, int Fin, int Kp) {
+                                                          float* __restrict__ panel, int row0, int heads, int Fh, int Fin, int Kp) {
   // one workgroup per output row r = (s|t, head); thread (fl, k): partial dot over f = fl, fl+nfl, ...; LDS fold
   __shared__ float red[256];
-  const int HF = heads * Fh, r = blockIdx.x;
+  const int r = blockIdx.x;
   const int which = r / heads, h = r - which * heads;
   const int kw = min(Fin, 256), nfl = 256 / kw;
   const int t = threadIdx.x, kl = t % kw, fl = t / kw;
@@ -75,14 +75,16 @@ __global__ __launch_bounds__(256) void gat_wa_rows_kernel(const float* __restric
     if (fl == 0 && k < Fin) {
       float tot = 0.f;
       for (int i = 0; i < nfl; ++i) tot += red[i * kw + kl];
-      panel[(size_t)(HF + r) * Kp + k] = tot;
+      panel[(size_t)(row0 + r) * Kp + k] = tot;
     }
     __syncthreads();
   }
 }
 
-hipError_t launch_gat_wa_rows(const float* W, const float* a, float* panel, int heads, int Fh, int Fin, int Kp, hipStream_t s) {
-  hipLaunchKernelGGL(gat_wa_rows_kernel, dim3(2 * heads), dim3(256), 0, s, W, a, panel, heads, Fh, Fin, Kp);
+// rows row0 .. row0 + 2*heads of `panel` (pitch Kp): row0 = heads*Fh appends them to the linear layer's weight panel,
+// row0 = 0 with Kp = Fin gives the compact (2H, Fin) matrix of the aggregate-first path (gat_fused.hip)
+hipError_t launch_gat_wa_rows(const float* W, const float* a, float* panel, int row0, int heads, int Fh, int Fin, int Kp, hipStream_t s) {
+  hipLaunchKernelGGL(gat_wa_rows_kernel, dim3(2 * heads), dim3(256), 0, s, W, a, panel, row0, heads, Fh, Fin, Kp);
   return hipGetLastError();
 }
 

@@ -580,6 +580,34 @@ int mgu_gat_layer_forward(mgu_ctx* c, const void* X_dev, int N, int Fin, const i
   if (num_graphs < 1) num_graphs = 1;
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)hip_stream;
+  static const bool no_fused = getenv("MGU_NO_GAT_FUSED") != nullptr;   // A/B switch
+  if (!no_fused && gat_fused_applicable(Fin, heads, Fout_head, E)) {
+    // aggregate-first path (gat_fused.hip): no (N, heads*F') node table, the gather moves Fin floats per edge
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+      size_t o = off;
+      off += (bytes + 255) / 256 * 256;
+      return o;
+    };
+    const size_t o_st = take((size_t)N * 2 * heads * 4), o_wa = take((size_t)2 * heads * Fin * 4);
+    const size_t o_wf = take((size_t)HF * Fin * 4), o_gm = take((size_t)num_graphs * heads * 4), o_ng = take((size_t)N * 4);
+    int rc = ensure(c, &c->gws, &c->gws_bytes, off);
+    if (rc) return rc;
+    char* g = (char*)c->gws;
+    float* st = (float*)(g + o_st);
+    float* wa = (float*)(g + o_wa);
+    float* wf = (float*)(g + o_wf);
+    unsigned* gmax = (unsigned*)(g + o_gm);
+    int32_t* node_graph = (num_graphs > 1 && graph_ptr_dev) ? (int32_t*)(g + o_ng) : nullptr;   // node -> graph id (NULL: one graph)
+    HIPCHK(c, launch_gat_prep((const float*)W_dev, (const float*)a_dev, wa, wf, heads, Fout_head, Fin, graph_ptr_dev, num_graphs, N,
+                              node_graph, gmax, s));
+    HIPCHK(c, launch_gat_st((const float*)X_dev, wa, N, Fin, heads, st, s));
+    HIPCHK(c, launch_gat_edge_max(st, rowptr_dev, col_dev, node_graph, N, heads, alpha, gmax, s));
+    ProfScope ps(c, s);
+    HIPCHK(c, launch_gat_fused((const float*)X_dev, Fin, st, rowptr_dev, col_dev, node_graph, gmax, wf, N, heads, Fout_head, concat,
+                               alpha, (float*)out_dev, s));
+    return MGU_OK;
+  }
   // scratch: Wh (N, HF) node table | st (N, 2H) attention scalars | packed panel (NPp, Kp) | gmax (G, heads)
   const int Kp = rup(Fin, 32), NP = HF + 2 * heads, P = HF, NPp = rup(NP, 128);
   size_t off = 0;
@@ -603,7 +631,7 @@ int mgu_gat_layer_forward(mgu_ctx* c, const void* X_dev, int N, int Fin, const i
   // nn.Linear weight (F',Fin) stacked over heads is already the [N][K] panel (K padded to 32); rows HF.. hold
   // W^T a_src / W^T a_tgt so the same GEMM emits the attention scalars s, t (graph_attention.py:53,57-64)
   HIPCHK(c, launch_pack_conv_w((const float*)W_dev, wp, 0, HF, Fin, Fin, 1, Kp, s));
-  HIPCHK(c, launch_gat_wa_rows((const float*)W_dev, (const float*)a_dev, wp, heads, Fout_head, Fin, Kp, s));
+  HIPCHK(c, launch_gat_wa_rows((const float*)W_dev, (const float*)a_dev, wp, HF, heads, Fout_head, Fin, Kp, s));
   IgemmDesc d;
   memset(&d, 0, sizeof d);
   d.in = (const float*)X_dev;
