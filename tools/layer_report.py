@@ -7,7 +7,7 @@ S = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 import os
 rows = list(csv.DictReader(open(max(glob.glob(root + "/runc/*kernel_trace.csv"), key=os.path.getmtime))))
 ig = [r for r in rows if any(t in r["Kernel_Name"] for t in ("igemm", "conv3x3_halo", "conv3x3_first", "wino3x3", "head_kernel"))]
-last = ig[-24:]
+last = ig[-23:]   # the 23 conv launches of the last U-Net forward
 def convf(h, cin, cout): return 2 * B * h * h * 9 * cin * cout
 layers = []
 h, cin, f = S, 3, 32
@@ -20,7 +20,6 @@ for b in range(4):
     layers.append(("dec%d.up" % b, 2 * B * h * h * prev * (prev // 2) * 4)); h *= 2
     layers += [("dec%d.c1" % b, convf(h, 2 * c, c)), ("dec%d.c2" % b, convf(h, c, c))]; prev = c
 layers.append(("final", 2 * B * S * S * 32 * 2))
-layers.append(("gat.lin", 2 * B * (S // 16) ** 2 * 32 * 256))
 tot = 0
 for (name, fl), r in zip(layers, last):
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3

@@ -11,6 +11,7 @@ def load(pat):
 
 def short(n):
     if "igemm" in n: return "igemm<" + n.split("<")[1].split(">")[0].replace(" ", "") + ">"
+    if "conv3x3_first" in n: return "first<" + n.split("<")[1].split(">")[0].replace(" ", "") + ">"
     if "wino3x3" in n: return "wino<" + n.split("<")[1].split(">")[0].replace(" ", "") + ">"
     if "conv3x3_halo" in n: return "halo<" + n.split("<")[1].split(">")[0].replace(" ", "") + ">"
     return n.split("(")[0].replace("mgu::", "").replace("void ", "")[:40]
@@ -46,7 +47,7 @@ for name, a in agg.items():
 # per-dispatch detail for igemm of the last step
 print()
 for tag in ("fetch", "write"):
-    rows = [(k, d) for (t, k), d in per.items() if t == tag and ("igemm" in k[1] or "halo" in k[1] or "wino" in k[1])]
+    rows = [(k, d) for (t, k), d in per.items() if t == tag and ("igemm" in k[1] or "halo" in k[1] or "wino" in k[1] or "first" in k[1])]
     rows = rows[-24:]
     print(tag, "last step, per igemm launch:")
     for (did, name), d in rows:
