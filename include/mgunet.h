@@ -124,6 +124,13 @@ int mgu_adam_step(mgu_ctx* ctx, void* flat_param_dev, const void* flat_grad_dev,
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   float grad_scale, void* hip_stream);
 
+/* One-shot request: the NEXT mgu_unet_forward on this ctx also writes the per-patch means of the shallowest decoder
+ * feature -- exactly what mgu_patch_mean(decoder_feats[0], ...) returns, (B*nph*npw, init_features) fp32 -- to out_dev.
+ * In eval mode with <= 4 classes the means and the final 1x1 conv share ONE pass over the feature map (it is read once
+ * instead of twice: both consumers are bandwidth bound).  The node features of the 'full forward' (SURVEY 8a row L3).
+ * out_dev == NULL cancels a pending request (e.g. after a forward that failed validation). */
+int mgu_unet_request_patch_mean(mgu_ctx* ctx, int patch, void* out_dev);
+
 /* ---- patch graph: replaces preprocessing/graph_construction/patch_graph_construction.py:49-102 -- */
 /* HOST routine (index maps are tiny and static per image size).  Emits the COO edge_index in the
  * reference's exact order (:77-92) into coo[0..E) (sources) and coo[E..2E) (targets), and the

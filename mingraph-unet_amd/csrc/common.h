@@ -117,7 +117,9 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, 
 hipError_t launch_pack_input(const float* x, void* out, int dtype, int B, int C, int Cp, int H, int W, int64_t sn, int64_t sc,
                              int64_t sh, int64_t sw, hipStream_t s);
 hipError_t launch_maxpool2(const void* in, int ldin, void* out, int dtype, int B, int H, int W, int C, hipStream_t s);
-hipError_t launch_patch_mean(const void* feat, int dtype, float* out, int B, int H, int W, int C, int patch, hipStream_t s);
+bool patch_mean_head_fusable(int dtype, int C, int ncls);
+hipError_t launch_patch_mean(const void* feat, int dtype, float* out, int B, int H, int W, int C, int patch, hipStream_t s,
+                             const float* head_w = nullptr, const float* head_b = nullptr, float* logits = nullptr, int ncls = 0);
 hipError_t launch_pack_conv_w(const float* w_oihw, void* wp, int dtype, int Cout, int Cin, int Cp, int KS, int Kp, hipStream_t s);
 hipError_t launch_pack_convt_w(const float* w_iohw, void* wp, int dtype, int Cin, int Cout, int Kp, hipStream_t s);
 hipError_t launch_bn_fold(const float* bias, const float* gamma, const float* beta, const float* mean, const float* var,

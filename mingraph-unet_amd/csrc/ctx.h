@@ -47,6 +47,8 @@ struct mgu_ctx {
   bool fold_dirty = false;  // BN running stats / affine changed since the eval scale/shift were folded
   void* redws = nullptr;    // per-channel reduction slots (self-cleaning: zero between launches)
   size_t redws_bytes = 0;
+  void* pm_out = nullptr;   // one-shot request (mgu_unet_request_patch_mean): patch means of decoder feature 0
+  int pm_patch = 0;
   void* wuws = nullptr;     // Winograd weight scratch of the mgu_conv2d_nhwc building block
   size_t wuws_bytes = 0;
   int in_ch = 0, ncls = 0, feat = 0, depth = 0, dtype = 0, Cp0 = 0;

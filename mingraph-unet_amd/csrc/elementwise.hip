@@ -114,9 +114,14 @@ hipError_t launch_maxpool2(const void* in, int ldin, void* out, int dtype, int B
 }
 
 // ---- patch mean: one workgroup per patch; (Np, C) = mean over patch x patch window (zero padded) ----
-template <typename T>
+// NC > 0: the same pass also applies the final 1x1 conv (unet_decoder.py:117,143) to every pixel it reads -- the
+// decoder feature is 268 MB at 8 x 512^2 and both consumers are pure bandwidth, so reading it once instead of twice
+// is the whole optimisation.  The C/VEC threads that hold a pixel's channels fold their partial dot products with a
+// shuffle tree (C/VEC is a power of two <= 32 on this path).
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void patch_mean_kernel(const T* __restrict__ feat, float* __restrict__ out, int H, int W,
-                                                         int C, int patch, int nph, int npw) {
+                                                         int C, int patch, int nph, int npw, const float* __restrict__ hw,
+                                                         const float* __restrict__ hb, float* __restrict__ logits) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [npl][C]
   constexpr int VEC = Chunk<T>::VEC;
   const int q = C / VEC;
@@ -129,14 +134,32 @@ __global__ __launch_bounds__(256) void patch_mean_kernel(const T* __restrict__ f
   float acc[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  float wq[NC > 0 ? NC : 1][VEC];
+  if (NC > 0) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) wq[k][j] = hw[k * C + cq * VEC + j];
+  }
   if (pl < npl) {
     for (int i = pl; i < patch * patch; i += npl) {
       const int y = pr * patch + i / patch, x = pc * patch + i % patch;
-      if (y < H && x < W) {
+      if (y < H && x < W) {   // uniform over the q threads of a pixel
         float v[VEC];
-        Chunk<T>::load(feat + (((int64_t)img * H + y) * W + x) * C + cq * VEC, v);
+        const int64_t pix = ((int64_t)img * H + y) * W + x;
+        Chunk<T>::load(feat + pix * C + cq * VEC, v);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+        if (NC > 0) {
+#pragma unroll
+          for (int k = 0; k < NC; ++k) {
+            float dsum = 0.f;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) dsum += v[j] * wq[k][j];
+            for (int o = 1; o < q; o <<= 1) dsum += __shfl_xor(dsum, o);
+            if (cq == 0) logits[pix * NC + k] = dsum + hb[k];
+          }
+        }
       }
     }
 #pragma unroll
@@ -150,18 +173,37 @@ __global__ __launch_bounds__(256) void patch_mean_kernel(const T* __restrict__ f
   }
 }
 
-hipError_t launch_patch_mean(const void* feat, int dtype, float* out, int B, int H, int W, int C, int patch, hipStream_t s) {
+// ncls > 0: also write logits[pixel][ncls] = head_w (ncls, C) . feat[pixel] + head_b (the fused 1x1 head); needs
+// ncls <= 4 and C / vec a power of two <= 32 (head_fusable below)
+bool patch_mean_head_fusable(int dtype, int C, int ncls) {
+  const int vec = dtype == 0 ? 4 : 8;
+  if (C % vec || ncls < 1 || ncls > 4) return false;
+  const int q = C / vec;
+  return q >= 1 && q <= 32 && (q & (q - 1)) == 0;
+}
+
+hipError_t launch_patch_mean(const void* feat, int dtype, float* out, int B, int H, int W, int C, int patch, hipStream_t s,
+                             const float* head_w, const float* head_b, float* logits, int ncls) {
   const int vec = dtype == 0 ? 4 : 8;
   if ((C % vec) || C > 256 || C < vec) return hipErrorInvalidValue;
+  if (ncls > 0 && (!patch_mean_head_fusable(dtype, C, ncls) || !head_w || !head_b || !logits)) return hipErrorInvalidValue;
   const int nph = (H + patch - 1) / patch, npw = (W + patch - 1) / patch;
   const int npl = 256 / (C / vec);
   const size_t lds = (size_t)npl * C * sizeof(float);
-  if (dtype == 0)
-    hipLaunchKernelGGL(patch_mean_kernel<float>, dim3(B * nph * npw), dim3(256), lds, s, (const float*)feat, out, H, W, C, patch,
-                       nph, npw);
-  else
-    hipLaunchKernelGGL(patch_mean_kernel<__bf16>, dim3(B * nph * npw), dim3(256), lds, s, (const __bf16*)feat, out, H, W, C,
-                       patch, nph, npw);
+  const dim3 grid(B * nph * npw), block(256);
+#define MGU_PM(T, NC) hipLaunchKernelGGL((patch_mean_kernel<T, NC>), grid, block, lds, s, (const T*)feat, out, H, W, C, patch, nph, npw, head_w, head_b, logits)
+#define MGU_PM_T(T)             \
+  do {                          \
+    if (ncls <= 0) MGU_PM(T, 0); \
+    else if (ncls == 1) MGU_PM(T, 1); \
+    else if (ncls == 2) MGU_PM(T, 2); \
+    else if (ncls == 3) MGU_PM(T, 3); \
+    else MGU_PM(T, 4);          \
+  } while (0)
+  if (dtype == 0) MGU_PM_T(float);
+  else MGU_PM_T(__bf16);
+#undef MGU_PM_T
+#undef MGU_PM
   return hipGetLastError();
 }
 

@@ -376,8 +376,14 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
   hipStream_t s = (hipStream_t)hip_stream;
   if (training && c->dtype != MGU_DTYPE_F32)
     return fail(c, MGU_ERR_STATE, "training runs in fp32 only (bf16 storage is an inference mode)");
-  if (training)  // batch-statistics BatchNorm, running-stat update, activations kept for mgu_unet_backward
-    return unet_forward_train(c, (const float*)x_dev, xs_n, xs_c, xs_h, xs_w, B, H, W, (float*)logits_dev, cat_dev, feat_dev, s);
+  if (training) {  // batch-statistics BatchNorm, running-stat update, activations kept for mgu_unet_backward
+    int rc = unet_forward_train(c, (const float*)x_dev, xs_n, xs_c, xs_h, xs_w, B, H, W, (float*)logits_dev, cat_dev, feat_dev, s);
+    if (rc == MGU_OK && c->pm_out) {   // a pending patch-mean request is served by the stand-alone kernel
+      HIPCHK(c, launch_patch_mean(feat_dev[0], 0, (float*)c->pm_out, B, H, W, c->feat, c->pm_patch, s));
+      c->pm_out = nullptr;
+    }
+    return rc;
+  }
   const WsPlan plan = plan_ws(c, B, H, W);
   int rc = ensure(c, &c->ws, &c->ws_bytes, plan.total);
   if (rc) return rc;
@@ -442,7 +448,14 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
   // final 1x1 conv (:143): a few output channels -> HBM-bound head kernel reading the reference's (ncls, C) weight
   {
     const Layer& F = c->layers[li++];
-    if (c->ncls <= 4 && F.w_src && F.b_src) {
+    const int pm_dtype = c->dtype;   // decoder features are stored in the compute dtype
+    if (c->pm_out && F.w_src && F.b_src && patch_mean_head_fusable(pm_dtype, F.Cin, c->ncls) && F.Cin <= 256) {
+      // requested patch means + the 1x1 head in ONE pass over the decoder feature (both are pure bandwidth)
+      ProfScope ps(c, s);
+      HIPCHK(c, launch_patch_mean(cur, pm_dtype, (float*)c->pm_out, B, H, W, F.Cin, c->pm_patch, s, F.w_src, F.b_src,
+                                  (float*)logits_dev, c->ncls));
+      c->pm_out = nullptr;
+    } else if (c->ncls <= 4 && F.w_src && F.b_src) {
       ProfScope ps(c, s);
       HIPCHK(c, launch_conv1x1_head(cur, c->dtype, cur_ld, F.Cin, F.w_src, F.b_src, (float*)logits_dev, c->ncls, c->ncls,
                                     (int64_t)B * H * W, s));   // logits are always fp32
@@ -450,7 +463,26 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
       return rc;
     }
   }
+  if (c->pm_out) {   // request not served by the fused pass (head shape): separate kernel, same result
+    HIPCHK(c, launch_patch_mean(cur, c->dtype, (float*)c->pm_out, B, H, W, c->layers.back().Cin, c->pm_patch, s));
+    c->pm_out = nullptr;
+  }
   if (c->prof) HIPCHK(c, hipEventRecord(c->ev_total[1], s));
+  return MGU_OK;
+}
+
+int mgu_unet_request_patch_mean(mgu_ctx* c, int patch, void* out_dev) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!c->configured) return fail(c, MGU_ERR_STATE, "not configured");
+  if (!out_dev) {   // cancel a pending request
+    c->pm_out = nullptr;
+    return MGU_OK;
+  }
+  if (patch < 1) return fail(c, MGU_ERR_INVALID, "bad patch_mean request");
+  const int C = c->layers.back().Cin, vec = c->dtype == MGU_DTYPE_BF16 ? 8 : 4;
+  if ((C % vec) || C > 256) return fail(c, MGU_ERR_INVALID, "patch means need init_features %% %d == 0 and <= 256 (got %d)", vec, C);
+  c->pm_patch = patch;
+  c->pm_out = out_dev;
   return MGU_OK;
 }
 

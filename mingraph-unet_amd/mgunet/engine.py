@@ -26,9 +26,24 @@ class MinGraphUNet(nn.Module):
         self.graph = PatchGraphConstructor(patch_size)
 
     def forward(self, x):
-        logits, skips, feats = self.unet(x)
         B, _, H, W = x.shape
-        X = self.graph.patch_mean_features(feats[0])
+        X = None
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4:
+            # ask the U-Net forward to emit the node features (patch means of decoder_feats[0]) in the same pass over
+            # the feature map as the final 1x1 conv (mgu_unet_request_patch_mean)
+            p = self.graph.patch_size
+            X = torch.empty((B * ((H + p - 1) // p) * ((W + p - 1) // p), self.unet.init_features), device=x.device,
+                            dtype=torch.float32)
+            ctx = self.unet._context(x.device)
+            _lib.check(_lib.lib().mgu_unet_request_patch_mean(ctx.handle, p, X.data_ptr()), ctx.handle)
+        try:
+            logits, skips, feats = self.unet(x)
+        except Exception:
+            if X is not None:   # the forward was rejected before it could serve the request: cancel it
+                _lib.lib().mgu_unet_request_patch_mean(ctx.handle, 0, None)
+            raise
+        if X is None:
+            X = self.graph.patch_mean_features(feats[0])
         rowptr, col, gp, N, E = self.graph.batched_csr(H, W, B, x.device)
         emb = gat_forward_csr(self.gat, X, rowptr, col, gp)
         return logits, skips, feats, emb

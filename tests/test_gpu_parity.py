@@ -257,3 +257,31 @@ def test_full_size_properties_c3_c4_shapes(cuda):
     assert torch.equal(shard, lgb[24:32]) and bool(torch.isfinite(lgb).all())
     _, pred = mgunet.segment_batch(unet, xb[:4])
     assert torch.equal(pred, torch.argmax(lgb[:4], dim=1))
+
+
+def test_requested_patch_means_equal_standalone_kernel(cuda):
+    """mgu_unet_request_patch_mean: the fused head + patch-mean pass must give the same logits and node features as the
+    stand-alone kernels (final 1x1 conv, mgu_patch_mean), on a size that is not a multiple of the patch."""
+    import mgunet
+    from mgunet import _lib
+    from mgunet.patch_graph import PatchGraphConstructor
+    cfg = (3, 2, 16, 2)
+    p = O.make_unet_params(*cfg, seed=5)
+    x = torch.from_numpy(O.formula_normal("pm/x", (2, 3, 40, 56), seed=5)).to(cuda)
+    model = mgunet.UNet(*cfg)
+    model.load_state_dict(p)
+    model = model.to(cuda).eval()
+    pg = PatchGraphConstructor(16)
+    with torch.no_grad():
+        lg0, _, f0 = model(x)
+        X0 = pg.patch_mean_features(f0[0])
+        X1 = torch.full_like(X0, -7.0)
+        ctx = model._context(cuda)
+        _lib.check(_lib.lib().mgu_unet_request_patch_mean(ctx.handle, 16, X1.data_ptr()), ctx.handle)
+        lg1, _, f1 = model(x)
+        lg2, _, _ = model(x)          # the request is one-shot: this forward must not touch X1 again
+    assert torch.equal(f0[0], f1[0])
+    assert float((X1 - X0).abs().max()) <= 1e-6
+    assert float((lg1 - lg0).abs().max()) <= 1e-5 and torch.equal(lg2, lg0)
+    olg = O.unet_forward({k: v.clone() for k, v in p.items()}, x.cpu(), cfg[3])[0]
+    assert float((lg1.cpu() - olg).abs().max()) <= 1e-3
