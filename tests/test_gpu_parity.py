@@ -55,7 +55,9 @@ def test_unet_tiny_full_tensors(cuda, golden, tag, cfg, shape):
 
 
 @pytest.mark.parametrize("cfg,shape", [((3, 2, 8, 2), (2, 3, 50, 70)), ((2, 5, 12, 3), (1, 2, 41, 33)),
-                                       ((3, 2, 16, 1), (3, 3, 16, 130)), ((4, 2, 32, 4), (1, 4, 96, 80))])
+                                       ((3, 2, 16, 1), (3, 3, 16, 130)), ((4, 2, 32, 4), (1, 4, 96, 80)),
+                                       # Winograd layers + fused max-pool + F.pad on odd sizes at every level
+                                       ((3, 2, 16, 2), (2, 3, 37, 45)), ((3, 3, 32, 3), (1, 3, 70, 93))])
 def test_unet_vs_oracle_ragged_shapes(cuda, cfg, shape):
     p = O.make_unet_params(*cfg, seed=5)
     x = torch.from_numpy(O.formula_normal("ragged/x", shape, seed=5))
