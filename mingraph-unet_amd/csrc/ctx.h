@@ -22,6 +22,7 @@ struct Layer {
   float *wp = nullptr, *scale = nullptr, *shift = nullptr;
   bool first = false;    // fp32 first convolution (<= 4 input channels): VALU kernel, weights kept in wf
   bool wino = false;     // fp32 3x3 layer with Cp % 16 == 0: Winograd-transformed weights kept in wu
+  mutable bool wp_dirty = false;   // direct panel wp not yet rebuilt from w_src (packed on first use)
   float* wu = nullptr;
   float* wf = nullptr;   // first conv (Cp == 4): [9][4][Cout] weights for conv3x3_first_kernel
   // caller-owned parameter tensors recorded by load_weights (used by the training path)

@@ -268,8 +268,14 @@ int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void*
       if ((rc = get(cw + ".weight", (int64_t)L.Cout * L.Cin * L.KS * L.KS, &w))) return rc;
       if ((rc = get(cw + ".bias", L.Cout, &b))) return rc;
       L.w_src = w, L.b_src = b;
-      HIPCHK(c, launch_pack_conv_w(w, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
+      // a layer that runs as Winograd / first-conv reads wu / wf; its direct panel is packed lazily, only if a launch
+      // ever falls back to the implicit-GEMM kernel (run_layer)
+      L.wp_dirty = true;
       if (L.wu) HIPCHK(c, launch_pack_wino_w(w, L.wu, L.Cout, L.Cin, L.Cp, 0, s));
+      if (!L.wu && !L.first) {
+        HIPCHK(c, launch_pack_conv_w(w, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
+        L.wp_dirty = false;
+      }
       if (L.wf) HIPCHK(c, launch_pack_first_w(w, L.wf, L.Cout, L.Cin, s));
       if (!L.bn.empty()) {
         const float *g, *be, *rm, *rv;
@@ -344,6 +350,10 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
   if (pool && c->dtype == MGU_DTYPE_F32 && wino_applicable(d)) {   // the Winograd epilogue also writes the 2x2 max-pooled tensor
     d.pool = (float*)pool, d.ldpool = ldpool;
     if (pool_fused) *pool_fused = true;
+  }
+  if (L.wp_dirty && !(c->dtype == MGU_DTYPE_F32 && wino_applicable(d))) {   // falling back to the direct kernel: build its panel now
+    HIPCHK(c, launch_pack_conv_w(L.w_src, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
+    L.wp_dirty = false;
   }
   ProfScope ps(c, s);
   if (c->dtype == MGU_DTYPE_BF16) HIPCHK(c, launch_igemm_bf16(d, s));

@@ -130,7 +130,6 @@ int conv_dgrad(Bwd& w, const Layer& L, const float* dz, float* out, int ldout) {
   mgu_ctx* c = w.c;
   const int Cop = rup(L.Cout, 4);
   const int Kd = L.KS * L.KS * Cop, Kpd = rup(Kd, 32);
-  HIPCHK(c, launch_pack_dgrad_w(L.w_src, w.dgp, L.Cout, L.Cin, Cop, L.KS, Kpd, w.s));
   IgemmDesc d;
   memset(&d, 0, sizeof d);
   d.in = dz, d.w = w.dgp, d.out = out;
@@ -139,9 +138,11 @@ int conv_dgrad(Bwd& w, const Layer& L, const float* dz, float* out, int ldout) {
   d.N = L.Cin, d.ldout = ldout;
   static const bool no_wd = getenv("MGU_NO_WINO_DGRAD") != nullptr;   // A/B switch
   if (!no_wd && L.wino && L.KS == 3 && Cop % 16 == 0 && use_wino()) {   // same Winograd kernel, weights flipped + transposed
-    HIPCHK(c, launch_pack_wino_w(L.w_src, w.wug, L.Cin, L.Cout, Cop, 1, w.s));
     d.wu = w.wug;
   }
+  // only the weight form the chosen kernel reads is built: Winograd U or the direct flipped/transposed panel
+  if (wino_applicable(d)) HIPCHK(c, launch_pack_wino_w(L.w_src, w.wug, L.Cin, L.Cout, Cop, 1, w.s));
+  else HIPCHK(c, launch_pack_dgrad_w(L.w_src, w.dgp, L.Cout, L.Cin, Cop, L.KS, Kpd, w.s));
   ProfScope ps(c, w.s);
   HIPCHK(c, launch_igemm_f32(d, w.s));
   return MGU_OK;
