@@ -83,6 +83,10 @@ struct WgradDesc {
 };
 hipError_t launch_wgrad_f32(WgradDesc& d, hipStream_t s);
 void set_wgrad_halo(bool on);
+// wino_wgrad_f32.hip: Winograd F(3x3,2x2) weight gradient (Cp % 64 == 0, N % 64 == 0); same partial-panel output as the halo kernel
+bool wino_wgrad_applicable(const WgradDesc& d);
+hipError_t launch_wino_wgrad_f32(WgradDesc& d, hipStream_t s);
+void set_wino_wgrad(bool on);
 
 // train_kernels.hip
 size_t chan_reduce_work_bytes(int Cmax);

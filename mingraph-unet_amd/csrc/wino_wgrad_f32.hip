@@ -1,0 +1,211 @@
+// Winograd F(3x3, 2x2) weight gradient of the 3x3 / pad 1 convolutions on the fp32 matrix cores of gfx950.
+//
+// dW[co][ci][u][v] = sum over images and pixels of dz[co][y][x] * in[ci][y+u-1][x+v-1]  (the backward of
+// model/unet/unet_encoder.py:16,20 through scripts/train_segmentation.py:130).  Per 2x2 tile of dz and its 4x4 input
+// tile d this is a 3x3 correlation with a 2x2 "filter", which the Toom-Cook points (0, 1, -1, inf) turn into
+//     dW += A^T [ (G dz G^T) .* (B^T d B) ] A,   G = [1 0; 1/2 1/2; 1/2 -1/2; 0 -1],   A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1]
+// with the SAME input transform B^T d B as the forward Winograd kernel: 16 products per tile and (co, ci) pair instead of
+// 36.  The 16 element-wise products, summed over tiles, are 16 GEMMs  M[ij][co][ci] = sum_tile S[ij][tile][co] V[ij][tile][ci]
+// whose reduction dimension is the TILE index: v_mfma_f32_32x32x2_f32 with co as rows, ci as columns, two tiles per
+// instruction.  The inverse transform A^T M A happens ONCE per workgroup, after its whole pixel range.
+//
+// MI355X mapping (same skeleton as wino_f32.hip)
+//   * a workgroup of 8 wavefronts owns 64 output x 64 input channels and a range of 8 x 16 pixel patches (32 tiles = 16
+//     MFMA k steps each); wavefront (i, g) owns transform row i and input-channel tile g, for BOTH output-channel tiles;
+//   * the raw input halo (10 x 18 px x 64 ci) and the dz patch (8 x 16 px x 64 co) are staged once per patch in LDS;
+//     neither S nor V is stored: a lane reads 2 x 2 dz values per output tile and 2 x 4 input values (4-byte reads; lanes
+//     run along the channels, so the pixel pitch of 80 floats puts the two tiles of a k step in different bank halves),
+//     combines them with its row's coefficients and issues 8 MFMAs (4 components x 2 output tiles);
+//   * accumulators: 4 components x 2 output tiles x 16 = 128 VGPRs, kept across all patches of the workgroup;
+//   * epilogue: column part of A^T M A in registers, the four row waves meet through LDS, and the nine 3x3 taps are
+//     written as plain 128-byte rows into a PRIVATE partial panel [co][tap * Cp + ci] of this patch group -- the format
+//     of wgrad3x3_halo_f32_kernel, summed in a fixed order by unpack_conv_grad (bitwise reproducible, no atomics).
+#include <type_traits>
+
+#include "common.h"
+
+namespace mgu {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static bool g_wino_wgrad = true;   // MGU_NO_WINO_WGRAD=1: direct weight-gradient kernels only (A/B)
+void set_wino_wgrad(bool on) { g_wino_wgrad = on; }
+
+__device__ __forceinline__ void ww_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(512) void wino_wgrad_f32_kernel(const WgradDesc d, const int tiles_x, const int tiles_y,
+                                                             const int total_patches, const int patches_per_block,
+                                                             const int nci) {
+  constexpr int TH = 8, TW = 16, HWID = TW + 2, HPIX = (TH + 2) * HWID, ZPIX = TH * TW;
+  constexpr int PH = 80, PZ = 80;              // floats per pixel in LDS: 64 channels + 16 (bank-half offset between tiles)
+  constexpr int HR = (HPIX * 16 + 511) / 512;  // float4 staged per thread: input halo (64 ci = 16 float4 per pixel)
+  constexpr int ZR = ZPIX * 16 / 512;          //                           dz patch  (64 co)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Hs = smem;                // [HPIX][PH]
+  float* Zs = smem + HPIX * PH;    // [ZPIX][PZ]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave & 3, wg = wave >> 2;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int cib = blockIdx.y % nci;            // 64-channel input block
+  const int cob = blockIdx.y / nci;            // 64-channel output block
+  const int p_begin = blockIdx.x * patches_per_block;
+  const int npatch = min(patches_per_block, total_patches - p_begin);
+  if (npatch <= 0) return;
+
+  // transform row i:  B^T d: i=0: d0 - d2, i=1: d1 + d2, i=2: d2 - d1, i=3: d1 - d3   (rows ra + sgn * rb)
+  //                   G dz : i=0: z0,      i=1: (z0 + z1)/2, i=2: (z0 - z1)/2, i=3: -z1  (a0 * z0 + a1 * z1)
+  const int ra = wi == 0 ? 0 : (wi == 2 ? 2 : 1);
+  const int rb = wi == 0 ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+  const float sgn = wi == 1 ? 1.f : -1.f;
+  const float a0 = wi == 0 ? 1.f : (wi == 3 ? 0.f : 0.5f);
+  const float a1 = wi == 0 ? 0.f : (wi == 1 ? 0.5f : (wi == 2 ? -0.5f : -1.f));
+
+  // ---- staging: thread -> (pixel t/16 + 32 i, float4 t%16) of the halo and of the dz patch ----
+  const int q16 = tid & 15, px0 = tid >> 4;
+  f32x4 hreg[HR], zreg[ZR];
+  auto load_patch = [&](int p) {
+    const int tx = p % tiles_x, ty = (p / tiles_x) % tiles_y, img = p / (tiles_x * tiles_y);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float* ibase = d.in + (size_t)img * d.H * d.W * d.ldin + d.inoff + cib * 64 + q16 * 4;
+    const float* zbase = d.z + (size_t)img * d.H * d.W * d.ldz + d.zoff + cob * 64 + q16 * 4;
+    // unconditional loads from a mapped address + select (a branch around a load serialises the batch)
+#pragma unroll
+    for (int i = 0; i < HR; ++i) {
+      const int hp = px0 + 32 * i;
+      const int hy = hp / HWID, hx = hp - hy * HWID;
+      const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+      const bool ok = hp < HPIX && y >= 0 && y < d.H && x >= 0 && x < d.W;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? ibase + (size_t)(y * d.W + x) * d.ldin : d.in);
+      hreg[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < ZR; ++i) {
+      const int zp = px0 + 32 * i;
+      const int y = y0 + (zp >> 4), x = x0 + (zp & 15);
+      const bool ok = y < d.H && x < d.W;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? zbase + (size_t)(y * d.W + x) * d.ldz : d.z);
+      zreg[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < HR; ++i)
+      if (px0 + 32 * i < HPIX) *reinterpret_cast<f32x4*>(Hs + (px0 + 32 * i) * PH + q16 * 4) = hreg[i];
+#pragma unroll
+    for (int i = 0; i < ZR; ++i) *reinterpret_cast<f32x4*>(Zs + (px0 + 32 * i) * PZ + q16 * 4) = zreg[i];
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][ct][r] = 0.f;
+
+  load_patch(p_begin);
+  for (int pi = 0; pi < npatch; ++pi) {
+    ww_barrier();            // every wave is done with the previous patch
+    store_patch();
+    ww_barrier();            // patch visible
+    if (pi + 1 < npatch) load_patch(p_begin + pi + 1);   // prefetch into registers while this patch computes
+#pragma unroll 2
+    for (int kk = 0; kk < 16; ++kk) {
+      const int T = 2 * kk + lh;                 // this lane's tile of the k step (adjacent in x: bank halves differ)
+      const int ty = T >> 3, tx = T & 7;
+      // V[i][0..3] for this lane's input channel
+      const float* hb = Hs + ((2 * ty) * HWID + 2 * tx) * PH + wg * 32 + lr;
+      float rr[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) rr[s4] = hb[(ra * HWID + s4) * PH] + sgn * hb[(rb * HWID + s4) * PH];
+      const float v0 = rr[0] - rr[2], v1 = rr[1] + rr[2], v2 = rr[2] - rr[1], v3 = rr[1] - rr[3];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        // S[i][0..3] for this lane's output channel of tile ct
+        const float* zb = Zs + ((2 * ty) * TW + 2 * tx) * PZ + ct * 32 + lr;
+        const float c0 = a0 * zb[0] + a1 * zb[TW * PZ];
+        const float c1 = a0 * zb[PZ] + a1 * zb[TW * PZ + PZ];
+        const float s0 = c0, s1 = 0.5f * (c0 + c1), s2 = 0.5f * (c0 - c1), s3 = -c1;
+        acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, v0, acc[0][ct], 0, 0, 0);
+        acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, v1, acc[1][ct], 0, 0, 0);
+        acc[2][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, v2, acc[2][ct], 0, 0, 0);
+        acc[3][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s3, v3, acc[3][ct], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- inverse transform dW = A^T M A, once per workgroup ---------------------------------------------------------
+  // column part in registers (q = 0..2 over j), row part through LDS (p = 0..2 over i):
+  //   [q0 q1 q2] = [M0+M1+M2, M1-M2, M1+M2+M3];   [p0 p1 p2] = [Z0+Z1+Z2, Z1-Z2, Z1+Z2+Z3]
+  float* Zx = smem;   // exchange: [4 rows i][2 g][4 register quads][64 lanes][4]   (32 KB; the staging buffers are free)
+  float* const part = d.dw + (size_t)blockIdx.x * d.N * d.Kp;
+  const int co0 = cob * 64, ci0 = cib * 64 + wg * 32;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      ww_barrier();   // previous pass consumed (first pass: every wave is past its last LDS operand read)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rq + e;
+          z[e] = q == 0 ? acc[0][ct][r] + acc[1][ct][r] + acc[2][ct][r]
+               : q == 1 ? acc[1][ct][r] - acc[2][ct][r]
+                        : acc[1][ct][r] + acc[2][ct][r] + acc[3][ct][r];
+        }
+        *reinterpret_cast<f32x4*>(Zx + ((((wi * 2 + wg) * 4 + rq) * 64) + lane) * 4) = z;
+      }
+      ww_barrier();
+      // wave i finishes accumulator registers 4i .. 4i+3: rows (co) 8i + 4*lh + (0..3) of output tile ct, column ci = lr
+      const f32x4 z0 = *reinterpret_cast<const f32x4*>(Zx + ((((0 * 2 + wg) * 4 + wi) * 64) + lane) * 4);
+      const f32x4 z1 = *reinterpret_cast<const f32x4*>(Zx + ((((1 * 2 + wg) * 4 + wi) * 64) + lane) * 4);
+      const f32x4 z2 = *reinterpret_cast<const f32x4*>(Zx + ((((2 * 2 + wg) * 4 + wi) * 64) + lane) * 4);
+      const f32x4 z3 = *reinterpret_cast<const f32x4*>(Zx + ((((3 * 2 + wg) * 4 + wi) * 64) + lane) * 4);
+      const f32x4 p0 = z0 + z1 + z2, p1 = z1 - z2, p2 = z1 + z2 + z3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + ct * 32 + 8 * wi + 4 * lh + e;
+        float* row = part + (size_t)co * d.Kp + ci0 + lr;
+        row[(0 * 3 + q) * d.Cp] = p0[e];
+        row[(1 * 3 + q) * d.Cp] = p1[e];
+        row[(2 * 3 + q) * d.Cp] = p2[e];
+      }
+    }
+  }
+}
+
+bool wino_wgrad_applicable(const WgradDesc& d) {
+  return g_wino_wgrad && d.KS == 3 && d.Cp % 64 == 0 && d.N % 64 == 0 && d.K == 9 * d.Cp && (d.ldin & 3) == 0 && (d.ldz & 3) == 0 &&
+         (d.inoff & 3) == 0 && (d.zoff & 3) == 0 && (long)d.H * d.W * d.ldin < (1l << 31) && (long)d.H * d.W * d.ldz < (1l << 31) &&
+         d.dw_capacity >= (size_t)d.N * d.Kp;
+}
+
+hipError_t launch_wino_wgrad_f32(WgradDesc& d, hipStream_t s) {
+  const int tiles_x = (d.W + 15) / 16, tiles_y = (d.H + 7) / 8;
+  const int B = d.M / (d.H * d.W);
+  const int total = tiles_x * tiles_y * B;
+  const int nci = d.Cp / 64, nco = d.N / 64;
+  // one 512-thread workgroup per CU is resident; every patch group writes a private partial panel
+  int groups = (256 + nci * nco - 1) / (nci * nco);
+  const size_t cap_groups = d.dw_capacity / ((size_t)d.N * d.Kp);
+  if ((size_t)groups > cap_groups) groups = (int)cap_groups;
+  int ppb = (total + groups - 1) / groups;
+  if (ppb < 1) ppb = 1;
+  groups = (total + ppb - 1) / ppb;   // every group has >= 1 patch: every partial panel is fully written
+  d.groups = groups;
+  const size_t lds = (size_t)((8 + 2) * 18 * 80 + 8 * 16 * 80) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wino_wgrad_f32_kernel, dim3(groups, nci * nco), dim3(512), lds, s, d, tiles_x, tiles_y, total, ppb, nci);
+  return hipGetLastError();
+}
+
+}  // namespace mgu
