@@ -10,11 +10,13 @@
 // instruction.  The inverse transform A^T M A happens ONCE per workgroup, after its whole pixel range.
 //
 // MI355X mapping (same skeleton as wino_f32.hip)
-//   * a workgroup of 8 wavefronts owns 64 output x 64 input channels and a range of 8 x 16 pixel patches (32 tiles = 16
-//     MFMA k steps each); wavefront (i, g) owns transform row i and input-channel tile g, for BOTH output-channel tiles;
-//   * the raw input halo (10 x 18 px x 64 ci) and the dz patch (8 x 16 px x 64 co) are staged once per patch in LDS;
+//   * a workgroup of 4*CI_T wavefronts owns 32*CO_T output x 32*CI_T input channels (CO_T, CI_T in {1, 2}: 64 x 64 for
+//     the bulk of the network, the narrower tiles for the 32-channel full-resolution layers) and a range of 8 x 16 pixel
+//     patches (32 tiles = 16 MFMA k steps each); wavefront (i, g) owns transform row i and input-channel tile g, for
+//     ALL of the workgroup's output-channel tiles;
+//   * the raw input halo (10 x 18 px) and the dz patch (8 x 16 px) are staged once per patch in LDS;
 //     neither S nor V is stored: a lane reads 2 x 2 dz values per output tile and 2 x 4 input values (4-byte reads; lanes
-//     run along the channels, so the pixel pitch of 80 floats puts the two tiles of a k step in different bank halves),
+//     run along the channels, so a pixel pitch of 32*T + 16 floats puts the two tiles of a k step in different bank halves),
 //     combines them with its row's coefficients and issues 8 MFMAs (4 components x 2 output tiles);
 //   * accumulators: 4 components x 2 output tiles x 16 = 128 VGPRs, kept across all patches of the workgroup;
 //   * epilogue: column part of A^T M A in registers, the four row waves meet through LDS, and the nine 3x3 taps are
@@ -34,13 +36,17 @@ void set_wino_wgrad(bool on) { g_wino_wgrad = on; }
 
 __device__ __forceinline__ void ww_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__global__ __launch_bounds__(512) void wino_wgrad_f32_kernel(const WgradDesc d, const int tiles_x, const int tiles_y,
-                                                             const int total_patches, const int patches_per_block,
-                                                             const int nci) {
+template <int CO_T, int CI_T>
+__global__ __launch_bounds__(256 * CI_T) void wino_wgrad_f32_kernel(const WgradDesc d, const int tiles_x, const int tiles_y,
+                                                                    const int total_patches, const int patches_per_block,
+                                                                    const int nci) {
+  constexpr int NT = 256 * CI_T;               // threads
   constexpr int TH = 8, TW = 16, HWID = TW + 2, HPIX = (TH + 2) * HWID, ZPIX = TH * TW;
-  constexpr int PH = 80, PZ = 80;              // floats per pixel in LDS: 64 channels + 16 (bank-half offset between tiles)
-  constexpr int HR = (HPIX * 16 + 511) / 512;  // float4 staged per thread: input halo (64 ci = 16 float4 per pixel)
-  constexpr int ZR = ZPIX * 16 / 512;          //                           dz patch  (64 co)
+  constexpr int PH = 32 * CI_T + 16, PZ = 32 * CO_T + 16;   // floats per pixel in LDS: channels + 16 (bank-half offset between tiles)
+  constexpr int QI = 8 * CI_T, QZ = 8 * CO_T;  // float4 per pixel: input halo / dz patch
+  constexpr int HPP = NT / QI, ZPP = NT / QZ;  // pixels staged per pass
+  constexpr int HR = (HPIX + HPP - 1) / HPP;   // float4 staged per thread: input halo
+  constexpr int ZR = ZPIX / ZPP;               //                           dz patch
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;                // [HPIX][PH]
   float* Zs = smem + HPIX * PH;    // [ZPIX][PZ]
@@ -49,8 +55,8 @@ __global__ __launch_bounds__(512) void wino_wgrad_f32_kernel(const WgradDesc d, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave & 3, wg = wave >> 2;
   const int lr = lane & 31, lh = lane >> 5;
-  const int cib = blockIdx.y % nci;            // 64-channel input block
-  const int cob = blockIdx.y / nci;            // 64-channel output block
+  const int cib = blockIdx.y % nci;            // input-channel block  (32 * CI_T channels)
+  const int cob = blockIdx.y / nci;            // output-channel block (32 * CO_T channels)
   const int p_begin = blockIdx.x * patches_per_block;
   const int npatch = min(patches_per_block, total_patches - p_begin);
   if (npatch <= 0) return;
@@ -63,18 +69,19 @@ __global__ __launch_bounds__(512) void wino_wgrad_f32_kernel(const WgradDesc d, 
   const float a0 = wi == 0 ? 1.f : (wi == 3 ? 0.f : 0.5f);
   const float a1 = wi == 0 ? 0.f : (wi == 1 ? 0.5f : (wi == 2 ? -0.5f : -1.f));
 
-  // ---- staging: thread -> (pixel t/16 + 32 i, float4 t%16) of the halo and of the dz patch ----
-  const int q16 = tid & 15, px0 = tid >> 4;
+  // ---- staging: thread -> (pixel, float4) of the halo and of the dz patch ----
+  const int hq = tid % QI, hp0 = tid / QI;
+  const int zq = tid % QZ, zp0 = tid / QZ;
   f32x4 hreg[HR], zreg[ZR];
   auto load_patch = [&](int p) {
     const int tx = p % tiles_x, ty = (p / tiles_x) % tiles_y, img = p / (tiles_x * tiles_y);
     const int y0 = ty * TH, x0 = tx * TW;
-    const float* ibase = d.in + (size_t)img * d.H * d.W * d.ldin + d.inoff + cib * 64 + q16 * 4;
-    const float* zbase = d.z + (size_t)img * d.H * d.W * d.ldz + d.zoff + cob * 64 + q16 * 4;
+    const float* ibase = d.in + (size_t)img * d.H * d.W * d.ldin + d.inoff + cib * (32 * CI_T) + hq * 4;
+    const float* zbase = d.z + (size_t)img * d.H * d.W * d.ldz + d.zoff + cob * (32 * CO_T) + zq * 4;
     // unconditional loads from a mapped address + select (a branch around a load serialises the batch)
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
-      const int hp = px0 + 32 * i;
+      const int hp = hp0 + HPP * i;
       const int hy = hp / HWID, hx = hp - hy * HWID;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
       const bool ok = hp < HPIX && y >= 0 && y < d.H && x >= 0 && x < d.W;
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_f32_kernel(const WgradDesc d, 
     }
 #pragma unroll
     for (int i = 0; i < ZR; ++i) {
-      const int zp = px0 + 32 * i;
+      const int zp = zp0 + ZPP * i;
       const int y = y0 + (zp >> 4), x = x0 + (zp & 15);
       const bool ok = y < d.H && x < d.W;
       const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? zbase + (size_t)(y * d.W + x) * d.ldz : d.z);
@@ -93,16 +100,16 @@ __global__ __launch_bounds__(512) void wino_wgrad_f32_kernel(const WgradDesc d, 
   auto store_patch = [&]() {
 #pragma unroll
     for (int i = 0; i < HR; ++i)
-      if (px0 + 32 * i < HPIX) *reinterpret_cast<f32x4*>(Hs + (px0 + 32 * i) * PH + q16 * 4) = hreg[i];
+      if (hp0 + HPP * i < HPIX) *reinterpret_cast<f32x4*>(Hs + (hp0 + HPP * i) * PH + hq * 4) = hreg[i];
 #pragma unroll
-    for (int i = 0; i < ZR; ++i) *reinterpret_cast<f32x4*>(Zs + (px0 + 32 * i) * PZ + q16 * 4) = zreg[i];
+    for (int i = 0; i < ZR; ++i) *reinterpret_cast<f32x4*>(Zs + (zp0 + ZPP * i) * PZ + zq * 4) = zreg[i];
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][CO_T];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < CO_T; ++ct)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][ct][r] = 0.f;
 
@@ -111,7 +118,9 @@ __global__ __launch_bounds__(512) void wino_wgrad_f32_kernel(const WgradDesc d, 
     ww_barrier();            // every wave is done with the previous patch
     store_patch();
     ww_barrier();            // patch visible
-    if (pi + 1 < npatch) load_patch(p_begin + pi + 1);   // prefetch into registers while this patch computes
+    // prefetch into registers while this patch computes -- UNCONDITIONAL (the last trip re-reads its own patch): a branch
+    // around the loads makes hipcc wait for them at the join, i.e. before the MFMA loop instead of after it
+    load_patch(p_begin + min(pi + 1, npatch - 1));
 #pragma unroll 2
     for (int kk = 0; kk < 16; ++kk) {
       const int T = 2 * kk + lh;                 // this lane's tile of the k step (adjacent in x: bank halves differ)
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(512) void wino_wgrad_f32_kernel(const WgradDesc d, 
       for (int s4 = 0; s4 < 4; ++s4) rr[s4] = hb[(ra * HWID + s4) * PH] + sgn * hb[(rb * HWID + s4) * PH];
       const float v0 = rr[0] - rr[2], v1 = rr[1] + rr[2], v2 = rr[2] - rr[1], v3 = rr[1] - rr[3];
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+      for (int ct = 0; ct < CO_T; ++ct) {
         // S[i][0..3] for this lane's output channel of tile ct
         const float* zb = Zs + ((2 * ty) * TW + 2 * tx) * PZ + ct * 32 + lr;
         const float c0 = a0 * zb[0] + a1 * zb[TW * PZ];
@@ -140,11 +149,11 @@ __global__ __launch_bounds__(512) void wino_wgrad_f32_kernel(const WgradDesc d, 
   // ---- inverse transform dW = A^T M A, once per workgroup ---------------------------------------------------------
   // column part in registers (q = 0..2 over j), row part through LDS (p = 0..2 over i):
   //   [q0 q1 q2] = [M0+M1+M2, M1-M2, M1+M2+M3];   [p0 p1 p2] = [Z0+Z1+Z2, Z1-Z2, Z1+Z2+Z3]
-  float* Zx = smem;   // exchange: [4 rows i][2 g][4 register quads][64 lanes][4]   (32 KB; the staging buffers are free)
+  float* Zx = smem;   // exchange: [4 rows i][CI_T g][4 register quads][64 lanes][4]   (<= 32 KB; the staging buffers are free)
   float* const part = d.dw + (size_t)blockIdx.x * d.N * d.Kp;
-  const int co0 = cob * 64, ci0 = cib * 64 + wg * 32;
+  const int co0 = cob * (32 * CO_T), ci0 = cib * (32 * CI_T) + wg * 32;
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
+  for (int ct = 0; ct < CO_T; ++ct) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       ww_barrier();   // previous pass consumed (first pass: every wave is past its last LDS operand read)
@@ -158,14 +167,14 @@ __global__ __launch_bounds__(512) void wino_wgrad_f32_kernel(const WgradDesc d, 
                : q == 1 ? acc[1][ct][r] - acc[2][ct][r]
                         : acc[1][ct][r] + acc[2][ct][r] + acc[3][ct][r];
         }
-        *reinterpret_cast<f32x4*>(Zx + ((((wi * 2 + wg) * 4 + rq) * 64) + lane) * 4) = z;
+        *reinterpret_cast<f32x4*>(Zx + ((((wi * CI_T + wg) * 4 + rq) * 64) + lane) * 4) = z;
       }
       ww_barrier();
       // wave i finishes accumulator registers 4i .. 4i+3: rows (co) 8i + 4*lh + (0..3) of output tile ct, column ci = lr
-      const f32x4 z0 = *reinterpret_cast<const f32x4*>(Zx + ((((0 * 2 + wg) * 4 + wi) * 64) + lane) * 4);
-      const f32x4 z1 = *reinterpret_cast<const f32x4*>(Zx + ((((1 * 2 + wg) * 4 + wi) * 64) + lane) * 4);
-      const f32x4 z2 = *reinterpret_cast<const f32x4*>(Zx + ((((2 * 2 + wg) * 4 + wi) * 64) + lane) * 4);
-      const f32x4 z3 = *reinterpret_cast<const f32x4*>(Zx + ((((3 * 2 + wg) * 4 + wi) * 64) + lane) * 4);
+      const f32x4 z0 = *reinterpret_cast<const f32x4*>(Zx + ((((0 * CI_T + wg) * 4 + wi) * 64) + lane) * 4);
+      const f32x4 z1 = *reinterpret_cast<const f32x4*>(Zx + ((((1 * CI_T + wg) * 4 + wi) * 64) + lane) * 4);
+      const f32x4 z2 = *reinterpret_cast<const f32x4*>(Zx + ((((2 * CI_T + wg) * 4 + wi) * 64) + lane) * 4);
+      const f32x4 z3 = *reinterpret_cast<const f32x4*>(Zx + ((((3 * CI_T + wg) * 4 + wi) * 64) + lane) * 4);
       const f32x4 p0 = z0 + z1 + z2, p1 = z1 - z2, p2 = z1 + z2 + z3;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -180,32 +189,44 @@ __global__ __launch_bounds__(512) void wino_wgrad_f32_kernel(const WgradDesc d, 
 }
 
 bool wino_wgrad_applicable(const WgradDesc& d) {
-  return g_wino_wgrad && d.KS == 3 && d.Cp % 64 == 0 && d.N % 64 == 0 && d.K == 9 * d.Cp && (d.ldin & 3) == 0 && (d.ldz & 3) == 0 &&
+  return g_wino_wgrad && d.KS == 3 && d.Cp % 32 == 0 && d.N % 32 == 0 && d.K == 9 * d.Cp && (d.ldin & 3) == 0 && (d.ldz & 3) == 0 &&
          (d.inoff & 3) == 0 && (d.zoff & 3) == 0 && (long)d.H * d.W * d.ldin < (1l << 31) && (long)d.H * d.W * d.ldz < (1l << 31) &&
          d.dw_capacity >= (size_t)d.N * d.Kp;
 }
 
-hipError_t launch_wino_wgrad_f32(WgradDesc& d, hipStream_t s) {
+template <int CO_T, int CI_T>
+static hipError_t launch_ww(WgradDesc& d, hipStream_t s) {
   const int tiles_x = (d.W + 15) / 16, tiles_y = (d.H + 7) / 8;
   const int B = d.M / (d.H * d.W);
   const int total = tiles_x * tiles_y * B;
-  const int nci = d.Cp / 64, nco = d.N / 64;
-  // one 512-thread workgroup per CU is resident; every patch group writes a private partial panel
-  int groups = (256 + nci * nco - 1) / (nci * nco);
+  const int nci = d.Cp / (32 * CI_T), nco = d.N / (32 * CO_T);
+  // 1 (512 threads) or 2 (256 threads) workgroups per CU are resident; every patch group writes a private partial panel
+  const int want = CI_T == 2 ? 256 : 512;
+  int groups = (want + nci * nco - 1) / (nci * nco);
   const size_t cap_groups = d.dw_capacity / ((size_t)d.N * d.Kp);
   if ((size_t)groups > cap_groups) groups = (int)cap_groups;
   int ppb = (total + groups - 1) / groups;
   if (ppb < 1) ppb = 1;
   groups = (total + ppb - 1) / ppb;   // every group has >= 1 patch: every partial panel is fully written
   d.groups = groups;
-  const size_t lds = (size_t)((8 + 2) * 18 * 80 + 8 * 16 * 80) * sizeof(float);
+  const size_t lds = (size_t)((8 + 2) * 18 * (32 * CI_T + 16) + 8 * 16 * (32 * CO_T + 16)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_f32_kernel<CO_T, CI_T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(wino_wgrad_f32_kernel, dim3(groups, nci * nco), dim3(512), lds, s, d, tiles_x, tiles_y, total, ppb, nci);
+  hipLaunchKernelGGL((wino_wgrad_f32_kernel<CO_T, CI_T>), dim3(groups, nci * nco), dim3(256 * CI_T), lds, s, d, tiles_x, tiles_y, total,
+                     ppb, nci);
   return hipGetLastError();
+}
+
+hipError_t launch_wino_wgrad_f32(WgradDesc& d, hipStream_t s) {
+  const bool co2 = d.N % 64 == 0, ci2 = d.Cp % 64 == 0;
+  if (co2 && ci2) return launch_ww<2, 2>(d, s);
+  if (co2) return launch_ww<2, 1>(d, s);
+  if (ci2) return launch_ww<1, 2>(d, s);
+  return launch_ww<1, 1>(d, s);
 }
 
 }  // namespace mgu
