@@ -96,10 +96,10 @@ hipError_t launch_bn_finalize(const double* sum, const double* sumsq, int64_t M,
                               float* shift, float* run_mean, float* run_var, int C, hipStream_t s);
 hipError_t launch_bn_apply_relu(const float* z, const float* scale, const float* shift, float* y, int ldy, int64_t M, int C,
                                 hipStream_t s);
-hipError_t launch_bn_bwd_reduce(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz,
+hipError_t launch_bn_bwd_reduce(const float* dy, int lddy, const float* fwd_scale, const float* fwd_shift, const float* z, int ldz,
                                 const float* mean, const float* invstd, int64_t M, int C, double* work, double* sums,
                                 float* dbeta, float* dgamma, hipStream_t s);
-hipError_t launch_bn_bwd_apply(const float* dy, int lddy, const float* y, int ldy, const float* z, const float* mean,
+hipError_t launch_bn_bwd_apply(const float* dy, int lddy, const float* fwd_scale, const float* fwd_shift, const float* z, const float* mean,
                                const float* invstd, const float* gamma, const double* sums, int64_t M, int C, float* dz,
                                double* work, float* dbias, hipStream_t s);
 hipError_t launch_colsum(const float* z, int ldz, int64_t M, int C, double* work, float* out, hipStream_t s);

@@ -153,10 +153,10 @@ int bn_relu_bwd(Bwd& w, const Layer& L, const float* dy, int lddy, float* dz) {
   mgu_ctx* c = w.c;
   const int64_t M = (int64_t)L.t_B * L.t_H * L.t_W;
   const int C = L.Cout;
-  HIPCHK(c, launch_bn_bwd_reduce(dy, lddy, L.t_y, L.t_ldy, L.t_z, C, L.mean, L.invstd, M, C, w.red, w.sums,
+  HIPCHK(c, launch_bn_bwd_reduce(dy, lddy, L.tscale, L.tshift, L.t_z, C, L.mean, L.invstd, M, C, w.red, w.sums,
                                  w.flat + L.off_beta, w.flat + L.off_gamma, w.s));
   // dz and, fused, the conv bias gradient = column sum of dz (analytically ~0 under BatchNorm)
-  HIPCHK(c, launch_bn_bwd_apply(dy, lddy, L.t_y, L.t_ldy, L.t_z, L.mean, L.invstd, L.gamma, w.sums, M, C, dz, w.red,
+  HIPCHK(c, launch_bn_bwd_apply(dy, lddy, L.tscale, L.tshift, L.t_z, L.mean, L.invstd, L.gamma, w.sums, M, C, dz, w.red,
                                 w.flat + L.off_b, w.s));
   return MGU_OK;
 }

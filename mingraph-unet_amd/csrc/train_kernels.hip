@@ -23,6 +23,8 @@ static inline int nblk(int64_t work, int threads, int cap = 256 * 8) {
 // "fanin" -- so the adds are spread over 64 x 2C addresses); slot_reduce_kernel then folds the slots.
 //   mode 0: acc0 = sum z,               acc1 = sum z*z                    (BatchNorm batch statistics)
 //   mode 1: g = dy * (y > 0); xh = (z - mean) * invstd;  acc0 = sum g, acc1 = sum g*xh   (BN backward)
+//           y = relu(scale*z + shift) is NOT read back: its sign is recomputed from z with the forward's scale/shift
+//           (one tensor read less in each of the two backward passes: they run at HBM speed, so bytes are time)
 //   mode 2: acc0 = sum z (column sums: bias gradients)
 //   mode 3: BN backward apply: dz = gamma*invstd*(g - sum_g/M - xh*sum_gx/M) written to `dz`, acc0 = sum dz
 // ------------------------------------------------------------------------------------------------
@@ -30,7 +32,7 @@ constexpr int RED_SLOTS = 64;
 
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ dy,
-                                                          int lddy, const float* __restrict__ y, int ldy,
+                                                          int lddy, const float* __restrict__ fsc, const float* __restrict__ fsh,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ gamma, const double* __restrict__ sums,
                                                           float* __restrict__ dz, int64_t M, int C, int rows_per_block,
@@ -43,12 +45,14 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
   const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r_end = min(M, r_begin + rows_per_block);
   if (pl < npl) {
-    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f}, k0 = mu, k1 = mu, k2 = mu;
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f}, k0 = mu, k1 = mu, k2 = mu, sc = is, sh = mu;
     if (MODE == 1 || MODE == 3) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         mu[j] = mean[cq * 4 + j];
         is[j] = invstd[cq * 4 + j];
+        sc[j] = fsc[cq * 4 + j];
+        sh[j] = fsh[cq * 4 + j];
       }
     }
     if (MODE == 3) {
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
         a1 += zv * zv;
       } else if (MODE == 1 || MODE == 3) {
         const f32x4 dv = *reinterpret_cast<const f32x4*>(dy + r * lddy + cq * 4);
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * ldy + cq * 4);
+        const f32x4 yv = zv * sc + sh;   // pre-ReLU output of the forward (bn_apply_relu_kernel's expression)
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -124,7 +128,7 @@ __global__ void slot_reduce_kernel(double* __restrict__ slots, int n, int pitch,
 size_t chan_reduce_work_bytes(int Cmax) { return (size_t)RED_SLOTS * 2 * Cmax * sizeof(double); }
 
 // work: chan_reduce_work_bytes(C) of scratch.  Results: outd[0..n) doubles (n = 2C for modes 0/1, C for 2/3).
-static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const float* dy, int lddy, const float* y, int ldy,
+static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const float* dy, int lddy, const float* fsc, const float* fsh,
                                      const float* mean, const float* invstd, const float* gamma, const double* sums,
                                      float* dz, int64_t M, int C, double* work, double* outd, float* outf0, int n0,
                                      float* outf1, hipStream_t s) {
@@ -136,7 +140,7 @@ static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const fl
   const int npl = 256 / (C >> 2);
   const size_t lds = (size_t)2 * npl * C * sizeof(float);
   dim3 g((unsigned)blocks), b(256);
-#define MGU_CR(MODE) hipLaunchKernelGGL(chan_reduce_kernel<MODE>, g, b, lds, s, z, ldz, dy, lddy, y, ldy, mean, invstd, gamma, sums, dz, M, C, rows, work)
+#define MGU_CR(MODE) hipLaunchKernelGGL(chan_reduce_kernel<MODE>, g, b, lds, s, z, ldz, dy, lddy, fsc, fsh, mean, invstd, gamma, sums, dz, M, C, rows, work)
   if (mode == 0) MGU_CR(0);
   else if (mode == 1) MGU_CR(1);
   else if (mode == 2) MGU_CR(2);
@@ -148,24 +152,24 @@ static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const fl
 }
 
 hipError_t launch_bn_stats(const float* z, int ldz, int64_t M, int C, double* work, double* sums, hipStream_t s) {
-  return launch_chan_reduce(0, z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, work, sums,
+  return launch_chan_reduce(0, z, ldz, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, work, sums,
                             nullptr, 0, nullptr, s);
 }
 // sums[0..C) = sum g (= dbeta), sums[C..2C) = sum g*xhat (= dgamma); fp32 copies go straight to the flat gradient
-hipError_t launch_bn_bwd_reduce(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz,
+hipError_t launch_bn_bwd_reduce(const float* dy, int lddy, const float* fsc, const float* fsh, const float* z, int ldz,
                                 const float* mean, const float* invstd, int64_t M, int C, double* work, double* sums,
                                 float* dbeta, float* dgamma, hipStream_t s) {
-  return launch_chan_reduce(1, z, ldz, dy, lddy, y, ldy, mean, invstd, nullptr, nullptr, nullptr, M, C, work, sums, dbeta, C,
+  return launch_chan_reduce(1, z, ldz, dy, lddy, fsc, fsh, mean, invstd, nullptr, nullptr, nullptr, M, C, work, sums, dbeta, C,
                             dgamma, s);
 }
 // dz (dense, pitch C) and its column sum (the conv bias gradient) in one pass
-hipError_t launch_bn_bwd_apply(const float* dy, int lddy, const float* y, int ldy, const float* z, const float* mean,
+hipError_t launch_bn_bwd_apply(const float* dy, int lddy, const float* fsc, const float* fsh, const float* z, const float* mean,
                                const float* invstd, const float* gamma, const double* sums, int64_t M, int C, float* dz,
                                double* work, float* dbias, hipStream_t s) {
-  return launch_chan_reduce(3, z, C, dy, lddy, y, ldy, mean, invstd, gamma, sums, dz, M, C, work, nullptr, dbias, C, nullptr, s);
+  return launch_chan_reduce(3, z, C, dy, lddy, fsc, fsh, mean, invstd, gamma, sums, dz, M, C, work, nullptr, dbias, C, nullptr, s);
 }
 hipError_t launch_colsum(const float* z, int ldz, int64_t M, int C, double* work, float* out, hipStream_t s) {
-  return launch_chan_reduce(2, z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, work, nullptr,
+  return launch_chan_reduce(2, z, ldz, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, work, nullptr,
                             out, C, nullptr, s);
 }
 
