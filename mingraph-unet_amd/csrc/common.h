@@ -39,6 +39,9 @@ struct IgemmDesc {
   // optional fused MaxPool2d(2) of the output (Winograd kernel only): pool[(img, y/2, x/2)*ldpool + n], floor semantics
   float* pool;
   int ldpool;
+  // optional (Winograd kernel, training forward): per-channel sum / sum of squares of the stored output accumulated into the
+  // slotted double accumulator [64][2 * N] (train_kernels.hip), folded by launch_bn_finalize_slots
+  double* stat_slots;
   // optional split epilogue (out_mode 0): columns n >= split_n go to out2[m*ld2 + (n - split_n)] (0 = off)
   int split_n;
   float* out2;
@@ -94,6 +97,9 @@ hipError_t launch_bn_stats(const float* z, int ldz, int64_t M, int C, double* wo
 hipError_t launch_bn_finalize(const double* sum, const double* sumsq, int64_t M, float eps, float momentum,
                               const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
                               float* shift, float* run_mean, float* run_var, int C, hipStream_t s);
+hipError_t launch_bn_finalize_slots(double* slots, double* sums, int64_t M, float eps, float momentum, const float* gamma,
+                                    const float* beta, float* mean, float* invstd, float* scale, float* shift, float* run_mean,
+                                    float* run_var, int C, hipStream_t s);
 hipError_t launch_bn_apply_relu(const float* z, const float* scale, const float* shift, float* y, int ldy, int64_t M, int C,
                                 hipStream_t s);
 hipError_t launch_bn_bwd_reduce(const float* dy, int lddy, const float* fwd_scale, const float* fwd_shift, const float* z, int ldz,

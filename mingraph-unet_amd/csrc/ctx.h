@@ -144,7 +144,8 @@ inline void level_dims(int H, int W, int depth, std::vector<int>& hs, std::vecto
 // one fused conv / convT / 1x1 launch described by a Layer (scale/shift chosen by the caller)
 int run_layer(mgu_ctx* c, const Layer& L, const void* in, int ldin, int B, int H, int W, void* out, int ldout, int coff,
               int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s,
-              void* pool = nullptr, int ldpool = 0, bool* pool_fused = nullptr);   // optional fused MaxPool2d(2) output
+              void* pool = nullptr, int ldpool = 0, bool* pool_fused = nullptr,   // optional fused MaxPool2d(2) output
+              double* stat_slots = nullptr, bool* stat_fused = nullptr);          // optional fused BatchNorm batch statistics
 
 // training path (mgunet_train.hip)
 int unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int64_t xs_w, int B, int H,

@@ -317,7 +317,7 @@ int mgu_unet_reserve(mgu_ctx* c, int B, int H, int W, int training) {
 
 int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int B, int H, int W, void* out_v, int ldout,
                     int coff, int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s,
-                    void* pool, int ldpool, bool* pool_fused) {
+                    void* pool, int ldpool, bool* pool_fused, double* stat_slots, bool* stat_fused) {
   IgemmDesc d;
   memset(&d, 0, sizeof d);
   d.in = (const float*)in_v;   // element type follows c->dtype; the descriptor carries raw pointers
@@ -343,11 +343,16 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
   d.Hout = Hout;
   d.Wout = Wout;
   if (pool_fused) *pool_fused = false;
+  if (stat_fused) *stat_fused = false;
   if (L.wf && c->dtype == MGU_DTYPE_F32 && ldin == 4 && first_conv_applicable(L.Cin, L.Cp, L.Cout, ldout, coff) &&
       (int64_t)B * H * W * std::max(ldout, 4) < (1ll << 31)) {
     ProfScope ps(c, s);
     HIPCHK(c, launch_first_conv((const float*)in_v, L.wf, scale, shift, (float*)out_v, B, H, W, L.Cin, L.Cout, ldout, coff, relu, s));
     return MGU_OK;
+  }
+  if (stat_slots && c->dtype == MGU_DTYPE_F32 && wino_applicable(d)) {   // the Winograd epilogue also accumulates sum z, sum z^2
+    d.stat_slots = stat_slots;
+    if (stat_fused) *stat_fused = true;
   }
   if (pool && c->dtype == MGU_DTYPE_F32 && wino_applicable(d)) {   // the Winograd epilogue also writes the 2x2 max-pooled tensor
     d.pool = (float*)pool, d.ldpool = ldpool;
@@ -367,7 +372,7 @@ static int run_conv(mgu_ctx* c, const Layer& L, const void* in, int ldin, int B,
                     int coff, int relu, int Hout, int Wout, hipStream_t s, void* pool = nullptr, int ldpool = 0,
                     bool* pool_fused = nullptr) {  // eval: folded BN scale/shift
   return run_layer(c, L, in, ldin, B, H, W, out, ldout, coff, relu, L.bn.empty() ? nullptr : L.scale, L.shift, Hout, Wout, s,
-                   pool, ldpool, pool_fused);
+                   pool, ldpool, pool_fused, nullptr, nullptr);
 }
 
 extern "C" {

@@ -87,11 +87,17 @@ int conv_bn_relu_train(mgu_ctx* c, Layer& L, const float* in, int ldin, int B, i
                        double* sums, double* red, hipStream_t s) {
   const int64_t M = (int64_t)B * H * W;
   const int C = L.Cout;
-  int rc = run_layer(c, L, in, ldin, B, H, W, z, C, 0, 0, nullptr, L.b_src, 0, 0, s);  // unet_encoder.py:16 / :20
+  bool stats_done = false;   // Winograd layers accumulate sum z / sum z^2 in the conv epilogue
+  int rc = run_layer(c, L, in, ldin, B, H, W, z, C, 0, 0, nullptr, L.b_src, 0, 0, s, nullptr, 0, nullptr, red, &stats_done);  // unet_encoder.py:16 / :20
   if (rc) return rc;
-  HIPCHK(c, launch_bn_stats(z, C, M, C, red, sums, s));
-  HIPCHK(c, launch_bn_finalize(sums, sums + C, M, 1e-5f, 0.1f, L.gamma, L.beta, L.mean, L.invstd, L.tscale, L.tshift,
-                               L.run_mean, L.run_var, C, s));  // nn.BatchNorm2d defaults, unet_encoder.py:12-13
+  if (stats_done) {
+    HIPCHK(c, launch_bn_finalize_slots(red, sums, M, 1e-5f, 0.1f, L.gamma, L.beta, L.mean, L.invstd, L.tscale, L.tshift, L.run_mean,
+                                       L.run_var, C, s));  // nn.BatchNorm2d defaults, unet_encoder.py:12-13
+  } else {
+    HIPCHK(c, launch_bn_stats(z, C, M, C, red, sums, s));
+    HIPCHK(c, launch_bn_finalize(sums, sums + C, M, 1e-5f, 0.1f, L.gamma, L.beta, L.mean, L.invstd, L.tscale, L.tshift,
+                                 L.run_mean, L.run_var, C, s));
+  }
   HIPCHK(c, launch_bn_apply_relu(z, L.tscale, L.tshift, y, ldy, M, C, s));
   L.t_in = in, L.t_ldin = ldin, L.t_z = z, L.t_y = y, L.t_ldy = ldy, L.t_B = B, L.t_H = H, L.t_W = W;
   return MGU_OK;

@@ -205,6 +205,48 @@ hipError_t launch_bn_finalize(const double* sum, const double* sumsq, int64_t M,
   return hipGetLastError();
 }
 
+// ---- finalize straight from the slotted accumulator (statistics accumulated by the conv epilogue) -----------------
+// Folds the 64 slots of channel c (sum at [k][c], sum of squares at [k][C + c]), clears them, and finishes BatchNorm2d
+// exactly as bn_finalize_kernel does: one launch instead of reduction + slot fold + finalize.
+__global__ void bn_finalize_slots_kernel(double* __restrict__ slots, double* __restrict__ sums, double M, float eps, float momentum,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean,
+                                         float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+                                         float* __restrict__ run_mean, float* __restrict__ run_var, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int k = 0; k < RED_SLOTS; ++k) {
+    double* sp = slots + (size_t)k * 2 * C;
+    s0 += sp[i];
+    s1 += sp[C + i];
+    sp[i] = 0.0;
+    sp[C + i] = 0.0;
+  }
+  if (sums) sums[i] = s0, sums[C + i] = s1;
+  const double mu = s0 / M;
+  double var = s1 / M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[i] = (float)mu;
+  invstd[i] = is;
+  const float sc = gamma[i] * is;
+  scale[i] = sc;
+  shift[i] = beta[i] - (float)mu * sc;
+  if (run_mean) {
+    const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+    run_mean[i] = (1.f - momentum) * run_mean[i] + momentum * (float)mu;
+    run_var[i] = (1.f - momentum) * run_var[i] + momentum * (float)unb;
+  }
+}
+
+hipError_t launch_bn_finalize_slots(double* slots, double* sums, int64_t M, float eps, float momentum, const float* gamma,
+                                    const float* beta, float* mean, float* invstd, float* scale, float* shift, float* run_mean,
+                                    float* run_var, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_slots_kernel, dim3((C + 63) / 64), dim3(64), 0, s, slots, sums, (double)M, eps, momentum, gamma, beta,
+                     mean, invstd, scale, shift, run_mean, run_var, C);
+  return hipGetLastError();
+}
+
 // ---- y = relu(scale*z + shift), output with pitch/offset ---------------------------------------------
 __global__ void bn_apply_relu_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                      const float* __restrict__ shift, float* __restrict__ y, int ldy, int64_t M, int C) {

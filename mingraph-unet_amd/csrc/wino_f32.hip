@@ -245,6 +245,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   prep_next();
   load_next();              // chunk 1 of the stream, parked at the top of chunk 0
   int cg = 0;               // k group whose fragments sit in bf[0] at the top of a chunk
+  f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};   // training: sum z, sum z^2 of this thread's channel quad
   int buf = 0;              // raw buffer of the chunk being computed
   for (int pi = 0; pi < npatch; ++pi) {
     for (int c = 0; c < nC; ++c) {
@@ -375,6 +376,12 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
           for (int e = 0; e < 4; ++e) ya[e] = fmaxf(ya[e], 0.f), yb[e] = fmaxf(yb[e], 0.f);
         }
         const int oy = y0 + 2 * (T >> 4), ox = x0 + 2 * (T & 15) + q;
+        if (d.stat_slots) {   // BatchNorm batch statistics of the train-mode forward ride in the epilogue (no extra pass over z)
+          const float ma = (interior || (ox < d.W && oy < d.H)) ? 1.f : 0.f;
+          const float mb = (interior || (ox < d.W && oy + 1 < d.H)) ? 1.f : 0.f;
+          st1 += ma * ya + mb * yb;
+          st2 += ma * ya * ya + mb * yb * yb;
+        }
         const unsigned idx = (unsigned)((oy * d.W + ox) * d.ldout + n0);
         if (interior) {
           *reinterpret_cast<f32x4*>(img_out + idx) = ya;
@@ -418,6 +425,22 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][mi][r] = 0.f;
+  }
+  if (d.stat_slots) {
+    // fold the per-thread sums of a channel quad (512 / QPT threads each) through LDS, then one double atomic per channel
+    // and sum into slot (workgroup % 64) of the slotted accumulator [64][2 * N] that bn_finalize_slots_kernel folds
+    float* red = smem;   // [512][8]
+    lds_barrier();
+    *reinterpret_cast<f32x4*>(red + tid * 8) = st1;
+    *reinterpret_cast<f32x4*>(red + tid * 8 + 4) = st2;
+    lds_barrier();
+    if (tid < 8 * QPT) {   // thread -> (which sum, channel quad, element)
+      const int which = tid / (4 * QPT), rem = tid - which * 4 * QPT, qd = rem >> 2, e = rem & 3;
+      double sum = 0.0;
+      for (int k = qd; k < 512; k += QPT) sum += (double)red[k * 8 + which * 4 + e];
+      const int n = nblock * NC + qd * 4 + e;
+      if (n < d.N) atomicAdd(d.stat_slots + (size_t)(blockIdx.x & 63) * 2 * d.N + which * d.N + n, sum);
+    }
   }
 }
 
