@@ -4,7 +4,7 @@ conv launches (3x3 Winograd / direct, ConvTranspose, 1x1 head) of the LAST U-Net
 import csv, glob, json, os, sys
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_traffic.json"
-summary = sys.argv[3] if len(sys.argv) > 3 else "profiles/r01_i_pmc_summary.txt"
+summary = sys.argv[3] if len(sys.argv) > 3 else "profiles/r01_j_pmc_summary.txt"
 
 def per_dispatch(tag, counter):
     f = max(glob.glob(f"{root}/pmc_{tag}/runc/*counter_collection.csv"), key=os.path.getmtime)
@@ -17,7 +17,7 @@ def per_dispatch(tag, counter):
     return [acc[k] for k in sorted(acc)]
 
 def conv(name):
-    return any(t in name for t in ("wino3x3", "conv3x3_halo", "conv3x3_first", "igemm_kernel", "conv1x1_head"))
+    return any(t in name for t in ("wino3x3", "conv3x3_halo", "conv3x3_first", "igemm_kernel", "conv1x1_head", "patch_mean_kernel"))
 
 def last_step(rows):
     c = [r for r in rows if conv(r[0])]
@@ -36,7 +36,7 @@ j = {
               "--no-cpu-baseline --no-profile-pass`; tools/gpu_pmc.sh + tools/traffic_json.py; summary " + summary,
     "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md HBM section; checked: the 1x1 head reads "
                   "268.5 MB corrected vs 268.4 MB algorithmic); WRITE_SIZE exact",
-    "kernels": "conv3x3_first_kernel + wino3x3_f32_kernel (17) + igemm_kernel (4 ConvTranspose) + conv1x1_head_kernel: the 23 conv launches of one U-Net forward, B=8 3x512x512",
+    "kernels": "conv3x3_first_kernel + wino3x3_f32_kernel (17) + igemm_kernel (4 ConvTranspose) + patch_mean_kernel<float,2> (1x1 head fused with the patch means): the 23 conv launches of one U-Net forward, B=8 3x512x512",
     "launches_per_step": 23,
     "read_bytes_per_step": read_b,
     "write_bytes_per_step": write_b,
