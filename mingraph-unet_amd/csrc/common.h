@@ -62,6 +62,8 @@ bool wino_applicable(const IgemmDesc& d);
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s);
 void set_use_wino(bool on);
 void set_wino_mode(int v);
+void set_wino_prec(int v);   // 0: fp32 MFMA operands, 1: three exact bf16 pieces per operand on the bf16 MFMA
+int wino_prec();
 bool use_wino();
 void set_use_halo(bool on);
 void set_halo_max_ppb(int n);

@@ -67,6 +67,8 @@ int mgu_create(int device_id, mgu_ctx** out) {
   set_use_wino(!(nwi && nwi[0] == '1'));
   const char* wmo = getenv("MGU_WINO_MODE");
   set_wino_mode(wmo ? atoi(wmo) : -1);
+  const char* wpr = getenv("MGU_WINO_PREC");
+  set_wino_prec(wpr ? atoi(wpr) : 0);
   const char* nww = getenv("MGU_NO_WINO_WGRAD");
   set_wino_wgrad(!(nww && nww[0] == '1'));
   const char* t1 = getenv("MGU_HALO_TPS1");

@@ -31,6 +31,29 @@ namespace mgu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// exact three-way split of two fp32 values into packed bf16 pieces (low half: a, high half: b)
+__device__ __forceinline__ void split3_pack(const float a, const float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  p0 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+  const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
+  const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+  p1 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+  const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
+  p2 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 // Workgroup barrier for LDS hand-offs ONLY.  __syncthreads() is a workgroup-scope fence + barrier, and the fence makes
 // hipcc wait for vmcnt(0): every outstanding global load AND store (CDNA4 counts stores in vmcnt).  In this kernel that
@@ -43,10 +66,27 @@ static bool g_use_wino = true;   // MGU_NO_WINOGRAD=1: direct (halo implicit-GEM
 void set_use_wino(bool on) { g_use_wino = on; }
 bool use_wino() { return g_use_wino; }
 
+// Operand precision of the 16 GEMMs (PREC):
+//   0: v_mfma_f32_32x32x2_f32 on the fp32 operands;
+//   1: every fp32 operand is split EXACTLY into three bf16 pieces (8 + 8 + 8 mantissa bits, by truncation:
+//      a = a0 + a1 + a2) and the product is formed from the six piece products of weight >= 2^-16,
+//        a b ~= a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a2 b0 + a1 b1),
+//      on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The dropped terms (a1 b2, a2 b1, a2 b2) are below
+//      2^-23 |a b|, the size of one fp32 rounding, so this is an fp32 GEMM in accuracy; it costs 6 bf16 MFMA passes of
+//      K = 16 (6 x 32 cycles) against 8 fp32 MFMAs of K = 2 (8 x 64 cycles) -- and, measured (tools/ubench/
+//      mfma_valu.hip), the fp32 MFMA blocks the VALU while it runs whereas the bf16 MFMA does not, so the input
+//      transform hides under the matrix pipe here.
+static int g_wino_prec = 0;
+void set_wino_prec(int v) { g_wino_prec = v; }
+int wino_prec() { return g_wino_prec; }
+
 // U[ntile][cin/8][i*4+j][lane (h = lane>>5, r = lane&31)][t]  =  (G g G^T)[i][j]  of  cout = 32*ntile + r,
 // cin = 8*(cin/8) + 4*h + t.   dgrad = 1: the data-gradient conv, g'[u][v] = w[c][n][2-u][2-v] (roles swapped).
+//
+// prec = 1 (three bf16 pieces):  Ux[ntile][cin/16][i*4+j][piece][lane (h = lane>>5, r = lane&31)][e]  (uint16),
+// cout = 32*ntile + r, cin = 16*(cin/16) + 8*h + e: the B fragment of v_mfma_f32_32x32x16_bf16, one 16-byte lane load.
 __global__ void pack_wino_w_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Cp, int Np,
-                                   int dgrad) {
+                                   int dgrad, int prec) {
   const int64_t total = (int64_t)Np * Cp;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(idx % Cp), n = (int)(idx / Cp);
@@ -71,25 +111,49 @@ __global__ void pack_wino_w_kernel(const float* __restrict__ w, float* __restric
       t[2][v] = 0.5f * (g[0][v] - g[1][v] + g[2][v]);
       t[3][v] = g[2][v];
     }
-    float* dst = U + (((int64_t)(n >> 5) * (Cp >> 3) + (c >> 3)) * 16) * 256 + ((((c >> 2) & 1) * 32 + (n & 31)) * 4 + (c & 3));
+    float u[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      dst[(i * 4 + 0) * 256] = t[i][0];
-      dst[(i * 4 + 1) * 256] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
-      dst[(i * 4 + 2) * 256] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
-      dst[(i * 4 + 3) * 256] = t[i][2];
+      u[i][0] = t[i][0];
+      u[i][1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+      u[i][2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+      u[i][3] = t[i][2];
+    }
+    if (prec == 0) {
+      float* dst = U + (((int64_t)(n >> 5) * (Cp >> 3) + (c >> 3)) * 16) * 256 + ((((c >> 2) & 1) * 32 + (n & 31)) * 4 + (c & 3));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[(i * 4 + j) * 256] = u[i][j];
+    } else {
+      uint16_t* dst = reinterpret_cast<uint16_t*>(U) + (((int64_t)(n >> 5) * (Cp >> 4) + (c >> 4)) * 16) * (3 * 512) +
+                      ((((c >> 3) & 1) * 32 + (n & 31)) * 8 + (c & 7));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned b0 = __float_as_uint(u[i][j]) & 0xffff0000u;
+          const float r1 = u[i][j] - __uint_as_float(b0);            // exact
+          const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
+          const float r2 = r1 - __uint_as_float(b1);                 // exact; 8 significant bits are left
+          uint16_t* q = dst + (i * 4 + j) * (3 * 512);
+          q[0] = (uint16_t)(b0 >> 16);
+          q[512] = (uint16_t)(b1 >> 16);
+          q[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
+        }
     }
   }
 }
 
-size_t wino_u_floats(int Cout, int Cp) { return (size_t)((Cout + 63) / 64 * 64) * Cp * 16; }   // n tiles padded to pairs
+// n tiles padded to pairs; 6 bytes per value in the three-piece layout (sized for either)
+size_t wino_u_floats(int Cout, int Cp) { return (size_t)((Cout + 63) / 64 * 64) * Cp * 24; }
 
 hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int Cp, int dgrad, hipStream_t s) {
-  if (Cp & 7) return hipErrorInvalidValue;
+  if (Cp & (g_wino_prec ? 15 : 7)) return hipErrorInvalidValue;
   const int Np = (Cout + 63) / 64 * 64;
   int64_t blocks = ((int64_t)Np * Cp + 255) / 256;
   if (blocks > 65535) blocks = 65535;
-  hipLaunchKernelGGL(pack_wino_w_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, U, Cout, Cin, Cp, Np, dgrad);
+  hipLaunchKernelGGL(pack_wino_w_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, U, Cout, Cin, Cp, Np, dgrad, g_wino_prec);
   return hipGetLastError();
 }
 
@@ -102,7 +166,7 @@ hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int C
 // every thread parks chunk c+1 (loaded one chunk ago into VGPRs) in the idle buffer and issues the loads of chunk
 // c+2; the weight fragments of k group g+1 are issued before the MFMAs of group g.  Nothing is waited for in the step
 // it was issued in.
-template <int MODE>
+template <int MODE, int PREC>
 __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y, const int total_patches,
                         const int patches_per_block, const int ngroups, const int nitems, const int per_xcd) {
   constexpr int NWAVES = 8;
@@ -147,13 +211,15 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   for (int mi = 0; mi < MT; ++mi) {
     const int m_abs = MODE == 1 ? wg : mi;
     const int rowbase = 2 * (2 * m_abs + ty);
-    offA[mi] = ((rowbase + ra) * 34 + tx) * PLD + lh * 4;
-    offB[mi] = ((rowbase + rb) * 34 + tx) * PLD + lh * 4;
+    offA[mi] = ((rowbase + ra) * 34 + tx) * PLD + lh * (PREC ? 8 : 4);
+    offB[mi] = ((rowbase + rb) * 34 + tx) * PLD + lh * (PREC ? 8 : 4);
   }
   const int ncg = d.Cp >> 3;                       // 8-channel k groups
   const int nC = d.Cp >> 4;                        // 16-channel raw chunks
   const int ntg = nblock * NTB + (MODE == 0 ? wg : 0);
   const float* const up = d.wu + ((size_t)ntg * ncg * 16 + wi * 4) * 256 + lane * 4;
+  // three-piece layout: 16-byte lane loads, [chunk][i*4+j][piece][lane]
+  const u32x4* const upx = reinterpret_cast<const u32x4*>(d.wu) + ((size_t)ntg * nC * 16 + wi * 4) * 192 + lane;
 
   // ---- raw halo staging: thread -> (pixel hp0 + HSTRIDE i, 16-byte piece kq) ----
   const int kq = tid & 3, hp0 = tid >> 2;
@@ -229,6 +295,11 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
 #pragma unroll
     for (int j = 0; j < 4; ++j) bf[slot][j] = *reinterpret_cast<const f32x4*>(up + (size_t)cg * 4096 + j * 256);
   };
+  u32x4 bx[4][3];   // PREC 1: the three pieces of this wave's four components, one 16-channel chunk
+  auto load_bx = [&](int j, int chunk) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) bx[j][pc] = upx[(size_t)chunk * (16 * 192) + j * 192 + pc * 64];
+  };
 
   f32x16 acc[4][MT];
 #pragma unroll
@@ -240,7 +311,12 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
 
   prep_next();
   load_next();              // chunk 0 of the first patch
-  load_b(0, 0);
+  if constexpr (PREC == 0) {
+    load_b(0, 0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_bx(j, 0);
+  }
   store_halo(smem);
   prep_next();
   load_next();              // chunk 1 of the stream, parked at the top of chunk 0
@@ -252,82 +328,155 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
       prep_next();
       lds_barrier();   // the chunk to compute is visible in buffer buf; every wave has left buffer buf ^ 1
       const float* Hs = smem + buf * RAWF;
-      auto operands = [&](const int kg, const int mi, f32x4 (&v)[4]) {   // V[i][0..3] of this lane's tile, 4 channels
-        const float* pa = Hs + offA[mi] + kg * 8;
-        const float* pb = Hs + offB[mi] + kg * 8;
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(pa) + sgn * *reinterpret_cast<const f32x4*>(pb);
-        const f32x4 r1 = *reinterpret_cast<const f32x4*>(pa + S1) + sgn * *reinterpret_cast<const f32x4*>(pb + S1);
-        const f32x4 r2 = *reinterpret_cast<const f32x4*>(pa + S2) + sgn * *reinterpret_cast<const f32x4*>(pb + S2);
-        const f32x4 r3 = *reinterpret_cast<const f32x4*>(pa + S3) + sgn * *reinterpret_cast<const f32x4*>(pb + S3);
-        v[0] = r0 - r2;
-        v[1] = r1 + r2;
-        v[2] = r2 - r1;
-        v[3] = r1 - r3;
-      };
-      auto mfma16 = [&](const f32x4 (&v)[4], const int slot, const int mi) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[j][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][t], bf[slot][j][t], acc[j][mi], 0, 0, 0);
-      };
-      // The staging of a chunk -- 3 LDS stores (chunk c+1), the next k group's 4 fragment loads, 3 halo loads (chunk
-      // c+2) -- has no dependence on this chunk's MFMAs.  Left as a phase of its own it costs ~1500 cycles per chunk in
-      // which NO wave of the workgroup feeds the matrix pipe (all eight are in the same phase, by the barrier); a wave
-      // has ~60 free issue cycles behind every MFMA, so the staging instructions are threaded between the first m
-      // tile's MFMAs instead (sched_group_barrier pattern below).  Issue order: fragment loads BEFORE halo loads (vmcnt
-      // retires in order; the halo is the long-latency stream and must not sit in front of the kg = 1 fragment wait).
-      f32x4 va[4], vb[4];
-      operands(0, 0, va);
-      store_halo(smem + (buf ^ 1) * RAWF);
-      int nx = cg + 1 == ncg ? 0 : cg + 1;
-      load_b(nx, 1);
-      load_next();
-      mfma16(va, 0, 0);
-      if (MT == 2) {
-        operands(0, 1, vb);
-        mfma16(vb, 0, 1);
-      }
-#pragma unroll
-      for (int i = 0; i < HR; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4 + HR; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-      if (MT == 2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      if constexpr (PREC == 0) {
+        auto operands = [&](const int kg, const int mi, f32x4 (&v)[4]) {   // V[i][0..3] of this lane's tile, 4 channels
+          const float* pa = Hs + offA[mi] + kg * 8;
+          const float* pb = Hs + offB[mi] + kg * 8;
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(pa) + sgn * *reinterpret_cast<const f32x4*>(pb);
+          const f32x4 r1 = *reinterpret_cast<const f32x4*>(pa + S1) + sgn * *reinterpret_cast<const f32x4*>(pb + S1);
+          const f32x4 r2 = *reinterpret_cast<const f32x4*>(pa + S2) + sgn * *reinterpret_cast<const f32x4*>(pb + S2);
+          const f32x4 r3 = *reinterpret_cast<const f32x4*>(pa + S3) + sgn * *reinterpret_cast<const f32x4*>(pb + S3);
+          v[0] = r0 - r2;
+          v[1] = r1 + r2;
+          v[2] = r2 - r1;
+          v[3] = r1 - r3;
+        };
+        auto mfma16 = [&](const f32x4 (&v)[4], const int slot, const int mi) {
+  #pragma unroll
+          for (int j = 0; j < 4; ++j)
+  #pragma unroll
+            for (int t = 0; t < 4; ++t)
+              acc[j][mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][t], bf[slot][j][t], acc[j][mi], 0, 0, 0);
+        };
+        // The staging of a chunk -- 3 LDS stores (chunk c+1), the next k group's 4 fragment loads, 3 halo loads (chunk
+        // c+2) -- has no dependence on this chunk's MFMAs.  Left as a phase of its own it costs ~1500 cycles per chunk in
+        // which NO wave of the workgroup feeds the matrix pipe (all eight are in the same phase, by the barrier); a wave
+        // has ~60 free issue cycles behind every MFMA, so the staging instructions are threaded between the first m
+        // tile's MFMAs instead (sched_group_barrier pattern below).  Issue order: fragment loads BEFORE halo loads (vmcnt
+        // retires in order; the halo is the long-latency stream and must not sit in front of the kg = 1 fragment wait).
+        f32x4 va[4], vb[4];
+        operands(0, 0, va);
+        store_halo(smem + (buf ^ 1) * RAWF);
+        int nx = cg + 1 == ncg ? 0 : cg + 1;
+        load_b(nx, 1);
+        load_next();
+        mfma16(va, 0, 0);
+        if (MT == 2) {
+          operands(0, 1, vb);
+          mfma16(vb, 0, 1);
         }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      nx = nx + 1 == ncg ? 0 : nx + 1;
-      cg = nx;
-      operands(1, 0, va);
-      load_b(nx, 0);   // first k group of the next chunk (wraps to the next patch's first)
-      mfma16(va, 1, 0);
-      if (MT == 2) {
-        operands(1, 1, vb);
-        mfma16(vb, 1, 1);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
-      }
-      if (MT == 2) {
-#pragma unroll
+  #pragma unroll
+        for (int i = 0; i < HR; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+  #pragma unroll
+        for (int i = 0; i < 4 + HR; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        if (MT == 2) {
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        nx = nx + 1 == ncg ? 0 : nx + 1;
+        cg = nx;
+        operands(1, 0, va);
+        load_b(nx, 0);   // first k group of the next chunk (wraps to the next patch's first)
+        mfma16(va, 1, 0);
+        if (MT == 2) {
+          operands(1, 1, vb);
+          mfma16(vb, 1, 1);
+        }
+  #pragma unroll
         for (int i = 0; i < 4; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
         }
+        if (MT == 2) {
+  #pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        // three-piece path: one K = 16 slab per chunk.  Lane (tile, h) forms V[i][0..3] for channels 8h .. 8h+7 (two
+        // 4-channel halves), splits each component into packed bf16 pieces and issues the six piece products.
+        // Per chunk and wave that is ~490 VALU instructions against 48 MFMAs: the VALU is the busier pipe, so the code
+        // is software-pipelined in eight steps (m tile, component j): the MFMAs of step s are interleaved with the
+        // split of step s+1 (and the second m tile's transform), which the bf16 MFMA lets the VALU do concurrently.
+        const int cn = c + 1 == nC ? 0 : c + 1;
+        f32x4 v[2][4][2];   // [m tile][j][half]
+        auto transform = [&](const int mi, const int hf) {
+          const float* pa = Hs + offA[mi] + hf * 4;
+          const float* pb = Hs + offB[mi] + hf * 4;
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(pa) + sgn * *reinterpret_cast<const f32x4*>(pb);
+          const f32x4 r1 = *reinterpret_cast<const f32x4*>(pa + S1) + sgn * *reinterpret_cast<const f32x4*>(pb + S1);
+          const f32x4 r2 = *reinterpret_cast<const f32x4*>(pa + S2) + sgn * *reinterpret_cast<const f32x4*>(pb + S2);
+          const f32x4 r3 = *reinterpret_cast<const f32x4*>(pa + S3) + sgn * *reinterpret_cast<const f32x4*>(pb + S3);
+          v[mi][0][hf] = r0 - r2;
+          v[mi][1][hf] = r1 + r2;
+          v[mi][2][hf] = r2 - r1;
+          v[mi][3][hf] = r1 - r3;
+        };
+        u32x4 pc[2][3];     // [step parity][piece]
+        auto split = [&](const int mi, const int j, const int slot) {
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              unsigned p0, p1, p2;
+              split3_pack(v[mi][j][hf][2 * e], v[mi][j][hf][2 * e + 1], p0, p1, p2);
+              pc[slot][0][hf * 2 + e] = p0, pc[slot][1][hf * 2 + e] = p1, pc[slot][2][hf * 2 + e] = p2;
+            }
+        };
+        auto mfma6 = [&](const int mi, const int j, const int slot) {
+          f32x16 t = acc[j][mi];
+          t = mfma_bf16(pc[slot][2], bx[j][0], t);
+          t = mfma_bf16(pc[slot][0], bx[j][2], t);
+          t = mfma_bf16(pc[slot][1], bx[j][1], t);
+          t = mfma_bf16(pc[slot][1], bx[j][0], t);
+          t = mfma_bf16(pc[slot][0], bx[j][1], t);
+          t = mfma_bf16(pc[slot][0], bx[j][0], t);
+          acc[j][mi] = t;
+        };
+        transform(0, 0);
+        transform(0, 1);
+        split(0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NS = 4 * MT;
+        static_for<0, NS>([&](auto st_c) {
+          constexpr int st = decltype(st_c)::value;
+          constexpr int mi = st >> 2, j = st & 3;
+          mfma6(mi, j, st & 1);
+          if constexpr (st + 1 < NS) split((st + 1) >> 2, (st + 1) & 3, (st + 1) & 1);
+          if constexpr (MT == 2 && st == 1) transform(1, 0);
+          if constexpr (MT == 2 && st == 2) transform(1, 1);
+          if constexpr (st == NS - 2) {          // staging of the next chunks rides in a late step
+            store_halo(smem + (buf ^ 1) * RAWF);
+            load_next();
+          }
+          if constexpr (mi == MT - 1 && j > 0) load_bx(j - 1, cn);   // pieces of the next chunk (or the next patch's first)
+          constexpr int nvalu = (st + 1 < NS ? 44 : 0) + ((MT == 2 && (st == 1 || st == 2)) ? 32 : 0) + (st == NS - 2 ? 16 : 0);
+          constexpr int per = (nvalu + 5) / 6;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (MT == 2 && (st == 1 || st == 2)) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if constexpr (per > 0) __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+            if constexpr (st == NS - 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if constexpr (st == NS - 2 || (mi == MT - 1 && j > 0)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        load_bx(3, cn);
       }
-      __builtin_amdgcn_sched_barrier(0);
       buf ^= 1;
     }
     // ---- inverse transform + epilogue of patch pi --------------------------------------------------------
@@ -447,7 +596,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
 static int g_wino_mode = -1;   // MGU_WINO_MODE=1: force work split 1 on every layer (A/B); default: 0 for N > 32
 void set_wino_mode(int v) { g_wino_mode = v; }
 
-template <int MODE>
+template <int MODE, int PREC>
 static hipError_t launch_wino_mode(const IgemmDesc& d, hipStream_t s) {
   constexpr int NTB = MODE == 0 ? 2 : 1, NWAVES = 8;
   const int tiles_x = (d.W + 31) / 32, tiles_y = (d.H + 7) / 8;
@@ -465,11 +614,11 @@ static hipError_t launch_wino_mode(const IgemmDesc& d, hipStream_t s) {
   const size_t lds = (size_t)(2 * RAWF + 4 * 64 * (32 * NTB + 8)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino3x3_f32_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino3x3_f32_kernel<MODE, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wino3x3_f32_kernel<MODE>), grid, dim3(64 * NWAVES), lds, s, d, tiles_x, tiles_y, total, ppb, ngroups,
+  hipLaunchKernelGGL((wino3x3_f32_kernel<MODE, PREC>), grid, dim3(64 * NWAVES), lds, s, d, tiles_x, tiles_y, total, ppb, ngroups,
                      ngroups * nblk, per_xcd);
   return hipGetLastError();
 }
@@ -480,8 +629,9 @@ bool wino_applicable(const IgemmDesc& d) {
 }
 
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
-  if (d.N > 32 && g_wino_mode != 1) return launch_wino_mode<0>(d, s);
-  return launch_wino_mode<1>(d, s);
+  const bool wide = d.N > 32 && g_wino_mode != 1;
+  if (g_wino_prec) return wide ? launch_wino_mode<0, 1>(d, s) : launch_wino_mode<1, 1>(d, s);
+  return wide ? launch_wino_mode<0, 0>(d, s) : launch_wino_mode<1, 0>(d, s);
 }
 
 }  // namespace mgu
