@@ -64,6 +64,8 @@ void set_use_wino(bool on);
 void set_wino_mode(int v);
 void set_wino_prec(int v);   // 0: fp32 MFMA operands, 1: three exact bf16 pieces per operand on the bf16 MFMA
 int wino_prec();
+bool wino_x3_applicable(const IgemmDesc& d);
+hipError_t launch_wino_x3(const IgemmDesc& d, hipStream_t s);   // wino_x3.hip: the four-wavefront three-piece kernel (prec 2)
 bool use_wino();
 void set_use_halo(bool on);
 void set_halo_max_ppb(int n);

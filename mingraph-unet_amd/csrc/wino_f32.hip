@@ -405,12 +405,57 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-      } else {
+      } else if constexpr (MT == 2) {
         // three-piece path: one K = 16 slab per chunk.  Lane (tile, h) forms V[i][0..3] for channels 8h .. 8h+7 (two
         // 4-channel halves), splits each component into packed bf16 pieces and issues the six piece products.
-        // Per chunk and wave that is ~490 VALU instructions against 48 MFMAs: the VALU is the busier pipe, so the code
-        // is software-pipelined in eight steps (m tile, component j): the MFMAs of step s are interleaved with the
-        // split of step s+1 (and the second m tile's transform), which the bf16 MFMA lets the VALU do concurrently.
+        // (Two m tiles per wave leave no registers for the software pipeline of the MT == 1 branch below -- it spills
+        //  105 VGPRs -- so this one is left to the compiler's own schedule: measured 15-20 % faster than the fp32 MFMA
+        //  path on the deep layers.)
+        store_halo(smem + (buf ^ 1) * RAWF);
+        load_next();
+        const int cn = c + 1 == nC ? 0 : c + 1;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          f32x4 v[4][2];
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const float* pa = Hs + offA[mi] + hf * 4;
+            const float* pb = Hs + offB[mi] + hf * 4;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(pa) + sgn * *reinterpret_cast<const f32x4*>(pb);
+            const f32x4 r1 = *reinterpret_cast<const f32x4*>(pa + S1) + sgn * *reinterpret_cast<const f32x4*>(pb + S1);
+            const f32x4 r2 = *reinterpret_cast<const f32x4*>(pa + S2) + sgn * *reinterpret_cast<const f32x4*>(pb + S2);
+            const f32x4 r3 = *reinterpret_cast<const f32x4*>(pa + S3) + sgn * *reinterpret_cast<const f32x4*>(pb + S3);
+            v[0][hf] = r0 - r2;
+            v[1][hf] = r1 + r2;
+            v[2][hf] = r2 - r1;
+            v[3][hf] = r1 - r3;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            u32x4 a0, a1, a2;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                unsigned p0, p1, p2;
+                split3_pack(v[j][hf][2 * e], v[j][hf][2 * e + 1], p0, p1, p2);
+                a0[hf * 2 + e] = p0, a1[hf * 2 + e] = p1, a2[hf * 2 + e] = p2;
+              }
+            f32x16 t = acc[j][mi];
+            t = mfma_bf16(a2, bx[j][0], t);
+            t = mfma_bf16(a0, bx[j][2], t);
+            t = mfma_bf16(a1, bx[j][1], t);
+            t = mfma_bf16(a1, bx[j][0], t);
+            t = mfma_bf16(a0, bx[j][1], t);
+            t = mfma_bf16(a0, bx[j][0], t);
+            acc[j][mi] = t;
+            if (mi == MT - 1) load_bx(j, cn);   // this component's pieces of the next chunk (or the next patch's first)
+          }
+        }
+      } else {
+        // three-piece path, one m tile per wave: ~250 VALU instructions against 24 MFMAs per chunk and wave, so the VALU
+        // is the busier pipe; the code is software-pipelined in four steps (component j): the MFMAs of step s are
+        // interleaved with the split of step s+1, which the bf16 MFMA lets the VALU do concurrently.
         const int cn = c + 1 == nC ? 0 : c + 1;
         f32x4 v[2][4][2];   // [m tile][j][half]
         auto transform = [&](const int mi, const int hf) {
@@ -630,6 +675,7 @@ bool wino_applicable(const IgemmDesc& d) {
 
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
   const bool wide = d.N > 32 && g_wino_mode != 1;
+  if (g_wino_prec == 2 && wino_x3_applicable(d)) return launch_wino_x3(d, s);
   if (g_wino_prec) return wide ? launch_wino_mode<0, 1>(d, s) : launch_wino_mode<1, 1>(d, s);
   return wide ? launch_wino_mode<0, 0>(d, s) : launch_wino_mode<1, 0>(d, s);
 }

@@ -121,6 +121,43 @@ def test_winograd_conv_vs_torch_and_direct(cuda, B, H, W, Cin, Cout, monkeypatch
     assert not torch.equal(wino, direct)   # the two paths really are different kernels
 
 
+@pytest.mark.parametrize("prec", ["1", "2"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (2, 12, 10, 64, 64),    # 64-channel work split, four chunks
+    (1, 9, 70, 32, 96),     # ragged patches, N tail
+    (1, 31, 33, 128, 32),   # the 32-channel work split
+    (1, 8, 32, 48, 40),     # odd chunk count: mode 2 falls back to the mode-1 kernel
+])
+def test_winograd_three_piece_operand_modes(cuda, B, H, W, Cin, Cout, prec, monkeypatch):
+    """MGU_WINO_PREC=1/2 (read at mgu_create): every fp32 operand of the 16 Winograd GEMMs is split exactly into three
+    bf16 pieces and multiplied on the bf16 MFMA with fp32 accumulation (csrc/wino_f32.hip PREC 1, csrc/wino_x3.hip).
+    Same tolerance as the fp32-MFMA kernel: the six kept piece products lose less than one fp32 rounding."""
+    x = torch.from_numpy(O.formula_normal("k3/x", (B, Cin, H, W), seed=H))
+    w = torch.from_numpy(O.formula_uniform("k3/w", (Cout, Cin, 3, 3), -0.2, 0.2, seed=W))
+    b = torch.zeros(Cout)
+    sc = torch.from_numpy(O.formula_uniform("k3/sc", (Cout,), 0.5, 1.5, seed=1))
+    sh = torch.from_numpy(O.formula_uniform("k3/sh", (Cout,), -0.5, 0.5, seed=2))
+    ref = F.relu(F.conv2d(x.double(), w.double(), None, padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    from mgunet import gat as G
+
+    def run():
+        G._CTX.clear()   # new mgu_ctx: the environment switch is read by mgu_create
+        got = conv_gpu(cuda, x, w, b, 3, 1, ld_out=Cout + 8, c_off=4, scale=sc, shift=sh)
+        return got[..., 4:4 + Cout].permute(0, 3, 1, 2).double()
+
+    base = run()
+    monkeypatch.setenv("MGU_WINO_PREC", prec)
+    split = run()
+    monkeypatch.delenv("MGU_WINO_PREC")
+    G._CTX.clear()
+    _context(cuda)   # back to the default for the rest of the process
+    e_base, e_split = float((base - ref).abs().max()), float((split - ref).abs().max())
+    assert e_base <= tol and e_split <= tol, (e_base, e_split)
+    assert e_split <= 2.0 * e_base + 1e-6, (e_base, e_split)   # as accurate as the fp32 MFMA path
+    assert not torch.equal(base, split)                           # really a different kernel
+
+
 def test_conv2d_scale_shift_relu_and_channel_slice_store(cuda):
     x = torch.from_numpy(O.formula_normal("ks/x", (1, 16, 12, 10), seed=1))
     w = torch.from_numpy(O.formula_uniform("ks/w", (24, 16, 3, 3), -0.2, 0.2, seed=1))
