@@ -313,6 +313,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   load_next();              // chunk 0 of the first patch
   if constexpr (PREC == 0) {
     load_b(0, 0);
+    load_b(1, 1);
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) load_bx(j, 0);
@@ -354,11 +355,14 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
         // has ~60 free issue cycles behind every MFMA, so the staging instructions are threaded between the first m
         // tile's MFMAs instead (sched_group_barrier pattern below).  Issue order: fragment loads BEFORE halo loads (vmcnt
         // retires in order; the halo is the long-latency stream and must not sit in front of the kg = 1 fragment wait).
+        // Fragment prefetch distance is ONE WHOLE CHUNK (slot 0 is reloaded at the start of the second half, slot 1 at
+        // the end of the chunk): vmcnt counts stores too and retires in order, so a load issued after the epilogue's
+        // output stores cannot be waited for before those stores have gone all the way to memory (~2-3 us).  With both
+        // k groups of a patch's first chunk already in flight BEFORE the previous epilogue, nothing issued behind the
+        // stores is needed for at least half a chunk.
         f32x4 va[4], vb[4];
         operands(0, 0, va);
         store_halo(smem + (buf ^ 1) * RAWF);
-        int nx = cg + 1 == ncg ? 0 : cg + 1;
-        load_b(nx, 1);
         load_next();
         mfma16(va, 0, 0);
         if (MT == 2) {
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
           __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
   #pragma unroll
-        for (int i = 0; i < 4 + HR; ++i) {
+        for (int i = 0; i < HR; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        nx = nx + 1 == ncg ? 0 : nx + 1;
+        int nx = cg + 2 >= ncg ? cg + 2 - ncg : cg + 2;
         cg = nx;
         operands(1, 0, va);
         load_b(nx, 0);   // first k group of the next chunk (wraps to the next patch's first)
@@ -392,6 +396,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
           operands(1, 1, vb);
           mfma16(vb, 1, 1);
         }
+        load_b(nx + 1 == ncg ? 0 : nx + 1, 1);   // second k group of the next chunk, issued as its slot drains
   #pragma unroll
         for (int i = 0; i < 4; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
