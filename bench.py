@@ -248,8 +248,9 @@ def main():
                          "executed_* are the FLOPs the matrix cores really issue against the same peak"),
                 "executed": round(exe, 2), "executed_frac": round(exe / peak, 4),
                 "executed_flop_per_launch": round(exe_flops / max(launches // nprof, 1)),
-                "kernel": ("wino3x3_f32_kernel (16 conv3x3) + igemm_kernel (first conv, 4 ConvTranspose) + conv1x1_head_kernel: "
-                           "the 23 conv launches of a step" if a.dtype == "f32" else
+                "kernel": ("wino3x3_f32_kernel (17 conv3x3) + conv3x3_first_kernel + igemm_kernel (4 ConvTranspose) + "
+                           "patch_mean_kernel<float,2> (1x1 head fused with the patch means): the 23 conv launches of a step"
+                           if a.dtype == "f32" else
                            "conv3x3_halo_kernel<bf16> + igemm_kernel<bf16>: the 23 conv launches of a step"),
                 "launches_per_step": launches // nprof, "kernel_ms_per_step": round(conv_ms / nprof, 4),
                 "unet_ms_per_step_with_events": round(tot_ms / nprof, 4), "gflop_per_step": round(flops / 1e9, 2)}
