@@ -257,7 +257,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(2, H, W, 3)
+        cpu = cpu_baseline(2, H, W, 14)   # ~12 s of host work on the GPU box's 16-core share
 
     if rank == 0:
         line = {"metric": "segmented Mpix/sec, full MinGraph-UNet forward (U-Net + patch-graph GAT), 512x512 batch",
