@@ -94,6 +94,10 @@ void set_wgrad_halo(bool on);
 bool wino_wgrad_applicable(const WgradDesc& d);
 hipError_t launch_wino_wgrad_f32(WgradDesc& d, hipStream_t s);
 void set_wino_wgrad(bool on);
+// wgrad_thin.hip: the first 3x3 conv (Cin 3) and the 1x1 head: HBM-bound streaming kernels, same partial-panel output
+bool wgrad_thin_applicable(const WgradDesc& d);
+hipError_t launch_wgrad_thin(WgradDesc& d, hipStream_t s);
+void set_wgrad_thin(bool on);
 
 // train_kernels.hip
 size_t chan_reduce_work_bytes(int Cmax);

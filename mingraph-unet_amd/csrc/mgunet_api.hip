@@ -71,6 +71,8 @@ int mgu_create(int device_id, mgu_ctx** out) {
   set_wino_prec(wpr ? atoi(wpr) : 0);
   const char* nww = getenv("MGU_NO_WINO_WGRAD");
   set_wino_wgrad(!(nww && nww[0] == '1'));
+  const char* ntw = getenv("MGU_NO_THIN_WGRAD");
+  set_wgrad_thin(!(ntw && ntw[0] == '1'));
   const char* t1 = getenv("MGU_HALO_TPS1");
   set_halo_tps3(!(t1 && t1[0] == '1'));
   const char* pp = getenv("MGU_HALO_PPB");

@@ -354,6 +354,7 @@ hipError_t launch_wgrad_f32(WgradDesc& d, hipStream_t s) {
   if (d.M <= 0 || d.N <= 0 || d.K <= 0) return hipSuccess;
   if ((d.N & 3) || (d.ldz & 3) || (d.zoff & 3) || (d.Cp & 3) || (d.ldin & 3) || (d.inoff & 3) || d.K > d.Kp)
     return hipErrorInvalidValue;
+  if (wgrad_thin_applicable(d)) return launch_wgrad_thin(d, s);       // first conv / 1x1 head: streaming kernels (wgrad_thin.hip)
   if (wino_wgrad_applicable(d)) return launch_wino_wgrad_f32(d, s);   // F(3x3,2x2): 2.25x fewer multiplies (wino_wgrad_f32.hip)
   if (g_wgrad_halo && d.KS == 3 && d.Cp % 32 == 0 && d.N % 32 == 0 && d.K == 9 * d.Cp &&
       (long)d.H * d.W * d.ldin < (1l << 31) && (long)d.H * d.W * d.ldz < (1l << 31) &&
