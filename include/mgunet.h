@@ -158,6 +158,22 @@ int mgu_gat_layer_forward(mgu_ctx* ctx, const void* X_dev, int N, int Fin,
                           const void* W_dev, const void* a_dev, int heads, int Fout_head,
                           int concat, float alpha, void* out_dev, void* hip_stream);
 
+/* ---- MinCut stage of the patch-graph branch: replaces
+ *      model/graph_partition/mincut_refinement.py:30-52 (edge weights), :55-160 (normalized-cut loss), :188-205
+ *      (softmax of the segment logits + loss), scripts/train_end_to_end.py:356 (hard labels) ---------------------- */
+/* w[e] = exp(-|f_src - f_tgt|^2 / 2) for the reference's COO int64 (2,E) edge list (row 0 sources, row 1 targets),
+ * in edge order (MinCutRefinement.compute_edge_weights_for_ncut). */
+int mgu_ncut_edge_weights(mgu_ctx* ctx, const float* feats_dev, int N, int D, const int64_t* edge_index_dev, int64_t E,
+                          float* w_dev, void* hip_stream);
+/* loss = sum_k cut_k / assoc_k (segments with assoc_k <= 1e-8 skipped), feats (N,D) fp32, CSR BY SOURCE
+ * (rowptr int32[N+1], col int32[E] = targets: the reference sums the degree over the source index, :96).
+ * assign_dev (N,K): segment logits (assign_is_logits = 1: softmax over K written to soft_dev, first-arg-max labels to
+ * hard_dev if not NULL -- MinCutRefinement.forward) or soft assignments (0: normalized_cut_loss called directly;
+ * soft_dev / hard_dev unused).  1 <= K <= 16.  loss_dev: one float. */
+int mgu_ncut_forward(mgu_ctx* ctx, const float* feats_dev, int N, int D, const int32_t* rowptr_src_dev,
+                     const int32_t* col_tgt_dev, int64_t E, const float* assign_dev, int K, int assign_is_logits,
+                     float* soft_dev, int32_t* hard_dev, float* loss_dev, void* hip_stream);
+
 /* ---- introspection for bench.py / profiles ------------------------------------------------------ */
 /* FLOPs (2*MAC, convolutions only) of one U-Net forward over B images: SURVEY 8d table. */
 double mgu_unet_flops(mgu_ctx* ctx, int B, int H, int W);

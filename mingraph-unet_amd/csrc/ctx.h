@@ -52,6 +52,8 @@ struct mgu_ctx {
   int pm_patch = 0;
   void* wuws = nullptr;     // Winograd weight scratch of the mgu_conv2d_nhwc building block
   size_t wuws_bytes = 0;
+  void* ncws = nullptr;     // normalized-cut accumulators (mgu_ncut_forward)
+  size_t ncws_bytes = 0;
   int in_ch = 0, ncls = 0, feat = 0, depth = 0, dtype = 0, Cp0 = 0;
   std::vector<Layer> layers;  // enc[i].conv1, enc[i].conv2 ..., bott.conv1, bott.conv2, dec[b].up, dec[b].conv1, dec[b].conv2 ..., final
   int64_t nparams = 0;

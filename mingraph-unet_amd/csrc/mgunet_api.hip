@@ -91,6 +91,7 @@ void mgu_destroy(mgu_ctx* c) {
   if (c->tws) (void)hipFree(c->tws);
   if (c->redws) (void)hipFree(c->redws);
   if (c->wuws) (void)hipFree(c->wuws);
+  if (c->ncws) (void)hipFree(c->ncws);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   for (auto e : c->ev_total)
     if (e) (void)hipEventDestroy(e);

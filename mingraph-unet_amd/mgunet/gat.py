@@ -75,12 +75,18 @@ def _context(device: torch.device):
 
 
 def stacked_head_weights(heads, cache):
-    """(H*Fh, Fin4) W panel and (H, 2*Fh) a panel of a layer's heads, rebuilt only when a parameter changes."""
+    """(H*Fh4, Fin4) W panel and (H, 2*Fh4) a panel of a layer's heads, rebuilt only when a parameter changes.
+    Fh4 = the per-head width rounded up to a multiple of 4 (16-byte lanes): the extra output features have zero weights
+    and zero attention coefficients, so they are exactly ELU(0) = 0 and the caller slices them off."""
     sig = tuple((h.W.weight.data_ptr(), h.W.weight._version, h.a.weight.data_ptr(), h.a.weight._version) for h in heads)
     ent = cache.get("weights")
     if ent is None or ent[0] != sig:
-        W = torch.cat([h.W.weight for h in heads], 0).detach()
-        a = torch.cat([h.a.weight for h in heads], 0).detach().contiguous()
+        Fh = heads[0].out_features
+        pad = (-Fh) % 4
+        Ws = [F.pad(h.W.weight.detach(), (0, 0, 0, pad)) for h in heads]
+        As = [torch.cat([F.pad(h.a.weight.detach()[:, :Fh], (0, pad)), F.pad(h.a.weight.detach()[:, Fh:], (0, pad))], 1) for h in heads]
+        W = torch.cat(Ws, 0)
+        a = torch.cat(As, 0).contiguous()
         if W.shape[1] % 4:
             W = F.pad(W, (0, 4 - W.shape[1] % 4))
         ent = cache["weights"] = (sig, W.contiguous(), a)
@@ -101,12 +107,11 @@ def _gat_layer_forward(heads, X, edge_index, concat, alpha, training, dropout_ra
     dev = X.device
     N, Fin = X.shape
     H = len(heads)
-    Fh = heads[0].out_features
-    if Fh % 4:
-        raise ValueError("per-head output width must be a multiple of 4 (16-byte lanes)")
+    Fh_true = heads[0].out_features
+    Fh = (Fh_true + 3) // 4 * 4   # narrow heads (e.g. the 2-segment predictor) run zero-padded, see stacked_head_weights
     W, a = stacked_head_weights(heads, cache)
     if heads[0].W.weight.shape[1] != Fin:
-        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({N}x{Fin} and {heads[0].W.weight.shape[1]}x{Fh})")
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({N}x{Fin} and {heads[0].W.weight.shape[1]}x{Fh_true})")
     Xc = X.detach().contiguous()
     if Fin % 4:  # zero-pad K to a multiple of 4: exact (W is padded the same way in stacked_head_weights)
         Xc = F.pad(Xc, (0, 4 - Fin % 4))
@@ -128,6 +133,8 @@ def _gat_layer_forward(heads, X, edge_index, concat, alpha, training, dropout_ra
                                               W.data_ptr(), a.data_ptr(), H, Fh, 1 if concat else 0, float(alpha),
                                               out.data_ptr(), _lib.current_stream_ptr(dev))
     _lib.check(rc, ctx.handle)
+    if Fh != Fh_true:
+        out = out.view(N, -1, Fh)[:, :, :Fh_true].reshape(N, -1).contiguous()
     return out
 
 

@@ -7,7 +7,7 @@ weights / inputs of oracle/mgunet_oracle.py, checks that the oracle restatement 
 stores the reference's outputs as small fixtures.  Fixtures hold data only (inputs that are
 not formula-derivable, expected outputs, sample indices) -- never reference source text.
 
-Usage:  python oracle/make_golden.py [--only tiny,gat,graph,c1,c2,c4,c5]
+Usage:  python oracle/make_golden.py [--only tiny,gat,graph,mincut,c1,c2,c4,c5]
 """
 import argparse
 import os
@@ -27,6 +27,7 @@ import mgunet_oracle as O  # noqa: E402
 from model.unet.unet_model import UNet as RefUNet  # noqa: E402
 from model.gat.graph_attention import GATNetwork as RefGAT, MultiHeadGATLayer as RefMH  # noqa: E402
 from preprocessing.graph_construction.patch_graph_construction import PatchGraphConstructor as RefPGC  # noqa: E402
+from model.graph_partition.mincut_refinement import MinCutRefinement as RefMinCut  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 TOL = 1e-5
@@ -147,6 +148,71 @@ def gen_gat():
     check("mh_concat", oc, yc)
     out["mhc_out"] = yc.numpy()
     save("gat_small.npz", **out)
+
+
+def gen_mincut():
+    print("[mincut] segment predictor + normalized-cut loss (SURVEY 8f row 1)")
+    out = {}
+    ref = RefMinCut()
+
+    def ref_predictor(in_dim, K, hidden, use_gnn, heads, params):
+        # PatchSegmentPredictor is defined inside scripts/train_end_to_end.py (:40-70), a script whose import runs the
+        # whole training set-up; it is exactly this wrapper: GATNetwork(in, hidden, K, heads, 1 layer) or Linear-ReLU-Linear
+        if use_gnn:
+            g = RefGAT(in_dim, hidden if hidden else in_dim, K, heads, num_gat_layers=1, dropout_rate=0.1, alpha=0.2).eval()
+            g.load_state_dict({k[len("gnn_predictor."):]: v for k, v in params.items()})
+            return lambda x, ei: g(x, ei)
+        hd = hidden if hidden is not None else in_dim * 2
+        m = torch.nn.Sequential(torch.nn.Linear(in_dim, hd), torch.nn.ReLU(), torch.nn.Linear(hd, K)).eval()
+        m.load_state_dict({k[len("mlp_predictor."):]: v for k, v in params.items()})
+        return lambda x, ei: m(x)
+
+    def run(tag, X, ei, K, hidden, use_gnn, heads, seed, logit_shift=None):
+        eit = torch.from_numpy(ei)
+        p = O.make_segment_predictor_params(X.shape[1], K, hidden, use_gnn, heads, seed=seed)
+        pred = ref_predictor(X.shape[1], K, hidden, use_gnn, heads, p)
+        net = pred if logit_shift is None else (lambda x, e: pred(x, e) + logit_shift)
+        with torch.no_grad():
+            loss, soft = ref(X, eit, K, net)                       # MinCutRefinement.forward, :163-205
+            w = ref.compute_edge_weights_for_ncut(X, eit)          # :30-52
+            lg = O.segment_predictor_forward(p, X, eit, use_gnn, heads)
+            if logit_shift is not None:
+                lg = lg + logit_shift
+            oloss, osoft, ohard = O.mincut_forward(X, eit, K, lg)
+        check(tag + ".soft", osoft, soft)
+        check(tag + ".loss", oloss.reshape(1), torch.as_tensor(loss, dtype=torch.float32).reshape(1), tol=1e-5 * max(1.0, float(loss)))
+        check(tag + ".w", O.ncut_edge_weights(X, eit), w)
+        assert torch.equal(ohard, torch.argmax(soft, dim=1))        # train_end_to_end.py:356
+        out[tag + "_loss"] = np.float32(float(loss))
+        out[tag + "_soft"] = soft.numpy()
+        out[tag + "_w"] = w.numpy()
+        out[tag + "_logits"] = lg.numpy()
+        print(f"   {tag}: N={X.shape[0]} E={ei.shape[1]} K={K} loss={float(loss):.6f} w range [{float(w.min()):.3e}, {float(w.max()):.3e}]")
+
+    # (a) the configuration of train_end_to_end.py:155-163 on an 8x8 patch graph: GAT predictor 64 -> 2, 2 heads
+    ei8 = O.patch_graph_edges(128, 128, 16)
+    Xa = torch.from_numpy(O.formula_normal("mincut/a/x", (64, 64), seed=1)) * 0.15
+    run("a", Xa, ei8, 2, 32, True, 2, seed=5)
+    # (b) MLP predictor, K = 3, a DIRECTED random graph (degree is summed over the SOURCE index only, :96), node 49 has
+    #     no outgoing edge, node 48 no edge at all
+    u = O.formula_uniform("mincut/b/e", (2, 200), 0.0, 1.0, 3)
+    eib = np.stack([np.minimum((u[0] * 48).astype(np.int64), 47), np.minimum((u[1] * 50).astype(np.int64), 49)])
+    Xb = torch.from_numpy(O.formula_normal("mincut/b/x", (50, 24), seed=2)) * 0.2
+    out["b_edges"] = eib
+    run("b", Xb, eib, 3, None, False, 1, seed=6)
+    # (c) a segment nobody belongs to: its association is below 1e-8 and the term is skipped (:152-153)
+    run("c", Xb, eib, 3, None, False, 1, seed=6, logit_shift=torch.tensor([0.0, -60.0, 0.0]))
+    # (d) the headline graph: 1024 patches of a 512x512 image, 64 features
+    ei32 = O.patch_graph_edges(512, 512, 16)
+    Xd = torch.from_numpy(O.formula_normal("mincut/d/x", (1024, 64), seed=4)) * 0.15
+    run("d", Xd, ei32, 2, 32, True, 2, seed=7)
+    # the reference's own shape check (:73-74)
+    try:
+        ref.normalized_cut_loss(Xa, torch.from_numpy(ei8), torch.zeros(64, 3), 2)
+        raise AssertionError("expected ValueError")
+    except ValueError:
+        pass
+    save("mincut.npz", **out)
 
 
 def gen_graph():
@@ -317,11 +383,11 @@ def gen_c5():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,gat,graph,c1,c2,c4,c5")
+    ap.add_argument("--only", default="tiny,gat,graph,mincut,c1,c2,c4,c5")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    fns = {"tiny": gen_tiny, "gat": gen_gat, "graph": gen_graph, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
+    fns = {"tiny": gen_tiny, "gat": gen_gat, "graph": gen_graph, "mincut": gen_mincut, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
     for k in a.only.split(","):
         t0 = time.time()
         fns[k]()

@@ -322,6 +322,81 @@ def gat_network_forward(p, X, edge_index, num_heads, num_gat_layers=1, alpha=0.2
 
 
 # --------------------------------------------------------------------------------------
+# MinCut stage: segment predictor + normalized-cut loss
+# (model/graph_partition/mincut_refinement.py, scripts/train_end_to_end.py:40-70,154-164,347-356)
+# --------------------------------------------------------------------------------------
+def ncut_edge_weights(node_features, edge_index):
+    """MinCutRefinement.compute_edge_weights_for_ncut, mincut_refinement.py:30-52: w = exp(-|f_s - f_t|^2 / 2)."""
+    d = node_features[edge_index[0]] - node_features[edge_index[1]]  # :43-44
+    return torch.exp(-torch.sum(d ** 2, dim=1) / 2.0)  # :46-51 (sigma = 1)
+
+
+def normalized_cut_loss(node_features, edge_index, soft, num_segments):
+    """MinCutRefinement.normalized_cut_loss, mincut_refinement.py:55-160, literally: degree = scatter_add of the edge
+    weights over the SOURCE index (:96), assoc_k = sum_i P_ik deg_i (:104), cut_k = sum_e w_e P_src,k (1 - P_tgt,k)
+    (:150), a segment contributes cut/assoc only if assoc > 1e-8 (:152-153)."""
+    N = node_features.shape[0]
+    if tuple(soft.shape) != (N, num_segments):
+        raise ValueError("segment_assignments_soft shape mismatch.")  # :73-74
+    w = ncut_edge_weights(node_features, edge_index)  # :77
+    total = torch.zeros((), dtype=node_features.dtype)
+    for k in range(num_segments):  # :83
+        pk = soft[:, k]
+        deg = torch.zeros(N, dtype=node_features.dtype).scatter_add_(0, edge_index[0], w)  # :93-96
+        assoc = torch.sum(pk * deg)  # :104
+        cut = torch.sum(w * pk[edge_index[0]] * (1 - pk[edge_index[1]]))  # :116-117,150
+        if assoc > 1e-8:  # :152
+            total = total + cut / assoc
+    return total
+
+
+def segment_predictor_param_shapes(in_dim, num_segments, hidden_dim=None, use_gnn=False, num_heads=1):
+    """state_dict keys of PatchSegmentPredictor (train_end_to_end.py:40-60; one GAT layer as configured at :156-163)."""
+    out: "OrderedDict[str, tuple]" = OrderedDict()
+    if use_gnn:
+        shapes, _ = gat_param_shapes(in_dim, hidden_dim if hidden_dim else in_dim, num_segments, num_heads, 1)  # :46-54
+        for k, v in shapes.items():
+            out["gnn_predictor." + k] = v
+    else:
+        hd = hidden_dim if hidden_dim is not None else in_dim * 2  # :57
+        out["mlp_predictor.0.weight"] = (hd, in_dim)  # :58-62
+        out["mlp_predictor.0.bias"] = (hd,)
+        out["mlp_predictor.2.weight"] = (num_segments, hd)
+        out["mlp_predictor.2.bias"] = (num_segments,)
+    return out
+
+
+def make_segment_predictor_params(in_dim, num_segments, hidden_dim=None, use_gnn=False, num_heads=1, seed=0):
+    params = OrderedDict()
+    for name, shape in segment_predictor_param_shapes(in_dim, num_segments, hidden_dim, use_gnn, num_heads).items():
+        if len(shape) == 2:
+            a = 1.414 * float(np.sqrt(6.0 / (shape[0] + shape[1])))
+        else:
+            a = 0.1
+        params[name] = torch.from_numpy(formula_uniform(name, shape, -a, a, seed))
+    return params
+
+
+def segment_predictor_forward(p, X, edge_index, use_gnn, num_heads=1, alpha=0.2):
+    """PatchSegmentPredictor.forward in eval mode, train_end_to_end.py:64-70."""
+    if use_gnn:
+        if edge_index is None:
+            raise ValueError("edge_index must be provided for GNN-based segment predictor.")  # :66-67
+        gp = OrderedDict((k[len("gnn_predictor."):], v) for k, v in p.items())
+        return gat_network_forward(gp, X, edge_index, num_heads, 1, alpha)  # :68
+    h = F.relu(X @ p["mlp_predictor.0.weight"].t() + p["mlp_predictor.0.bias"])  # :58-62
+    return h @ p["mlp_predictor.2.weight"].t() + p["mlp_predictor.2.bias"]
+
+
+def mincut_forward(node_features, edge_index, num_segments, segment_logits):
+    """MinCutRefinement.forward after the predictor call, mincut_refinement.py:188-205: softmax over segments, the
+    loss on the same features, and the hard labels train_end_to_end.py:356 takes from the soft assignments."""
+    soft = F.softmax(segment_logits, dim=1)  # :190
+    loss = normalized_cut_loss(node_features, edge_index, soft, num_segments)  # :193-198
+    return loss, soft, torch.argmax(soft, dim=1)
+
+
+# --------------------------------------------------------------------------------------
 # Step loops (scripts/train_segmentation.py:117-137, experiments/segmentation_performance.py:119-144)
 # --------------------------------------------------------------------------------------
 def eval_step(p, x, depth=4):

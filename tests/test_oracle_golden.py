@@ -115,3 +115,42 @@ def test_c5_small_train_step(golden):
     flat_p = torch.cat([newp[k].reshape(-1) for k in names])
     assert np.abs(flat_p[g["s_idx"]].numpy() - g["s_param_s"]).max() <= 2e-5
     assert np.abs(stats["encoder.encoder_blocks.0.bn1.running_mean"].numpy() - g["s_bn_rm"]).max() <= 1e-5
+
+
+MINCUT_CASES = {  # tag -> (N, D, K, hidden, use_gnn, heads, seed, x name/seed/scale, logit shift)
+    "a": (64, 64, 2, 32, True, 2, 5, ("mincut/a/x", 1, 0.15), None),
+    "b": (50, 24, 3, None, False, 1, 6, ("mincut/b/x", 2, 0.2), None),
+    "c": (50, 24, 3, None, False, 1, 6, ("mincut/b/x", 2, 0.2), [0.0, -60.0, 0.0]),
+    "d": (1024, 64, 2, 32, True, 2, 7, ("mincut/d/x", 4, 0.15), None),
+}
+
+
+def mincut_case(golden, tag):
+    N, D, K, hidden, use_gnn, heads, seed, (xn, xs, xscale), shift = MINCUT_CASES[tag]
+    g = golden["mincut"]
+    ei = {"a": O.patch_graph_edges(128, 128, 16), "d": O.patch_graph_edges(512, 512, 16)}.get(tag)
+    if ei is None:
+        ei = g["b_edges"]
+    X = torch.from_numpy(O.formula_normal(xn, (N, D), seed=xs)) * xscale
+    p = O.make_segment_predictor_params(D, K, hidden, use_gnn, heads, seed=seed)
+    return g, X, torch.from_numpy(ei), K, p, use_gnn, heads, hidden, (torch.tensor(shift) if shift else None)
+
+
+@pytest.mark.parametrize("tag", list(MINCUT_CASES))
+def test_mincut_stage_vs_reference_fixture(golden, tag):
+    """PatchSegmentPredictor + MinCutRefinement.forward: predictor logits, softmax, edge weights and the
+    normalized-cut loss against what the reference's own classes produced (oracle/make_golden.py gen_mincut)."""
+    g, X, ei, K, p, use_gnn, heads, hidden, shift = mincut_case(golden, tag)
+    lg = O.segment_predictor_forward(p, X, ei, use_gnn, heads)
+    if shift is not None:
+        lg = lg + shift
+    assert np.abs(lg.numpy() - g[f"{tag}_logits"]).max() <= 1e-5
+    loss, soft, hard = O.mincut_forward(X, ei, K, lg)
+    assert np.abs(soft.numpy() - g[f"{tag}_soft"]).max() <= 1e-6
+    assert np.abs(O.ncut_edge_weights(X, ei).numpy() - g[f"{tag}_w"]).max() <= 1e-6
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) <= 1e-5 * max(1.0, float(g[f"{tag}_loss"]))
+    assert np.array_equal(hard.numpy(), g[f"{tag}_soft"].argmax(1))
+    if tag == "c":   # the empty segment is skipped, not divided by (mincut_refinement.py:152-153)
+        assert float(soft[:, 1].max()) < 1e-20 and 0.9 < float(loss) < 1.1
+    with pytest.raises(ValueError):
+        O.normalized_cut_loss(X, ei, torch.zeros(X.shape[0], K + 1), K)
