@@ -8,7 +8,8 @@ path can be checked on a box where the reference's Python does not exist.  Only 
 
 Parity status: PINNED.  `oracle/make_golden.py` (run in the build container, where
 `/root/reference` is importable) loads the same formula weights into the reference's own
-`model.unet.unet_model.UNet`, `model.gat.graph_attention.GATNetwork` and
+`model.unet.unet_model.UNet`, `model.gat.graph_attention.GATNetwork`,
+`model.graph_partition.mincut_refinement.MinCutRefinement` and
 `preprocessing.graph_construction.patch_graph_construction.PatchGraphConstructor`, asserts
 this restatement agrees (<= 1e-5 abs on O(1) logits; index maps bit-exact) and writes the
 reference's outputs to `tests/golden/`.  `tests/test_oracle_golden.py` re-checks this file against
