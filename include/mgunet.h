@@ -174,6 +174,19 @@ int mgu_ncut_forward(mgu_ctx* ctx, const float* feats_dev, int N, int D, const i
                      const int32_t* col_tgt_dev, int64_t E, const float* assign_dev, int K, int assign_is_logits,
                      float* soft_dev, int32_t* hard_dev, float* loss_dev, void* hip_stream);
 
+/* ---- Region stage + fusion of the e2e forward: replaces scripts/train_end_to_end.py:366-373
+ *      (label-mean pooling), :403-421 (region embedding -> patches -> nearest upsample) and the concat of
+ *      FeatureFusion.forward (model/fusion_detection/feature_fusion.py:78,145-150) ------------------------------------ */
+/* out (B*K, D)[b*K + k] = mean of feats (B*Np, D) rows of image b whose hard label is k; zeros for an empty segment.
+ * D % 4 == 0, D <= 1024. */
+int mgu_region_mean_pool(mgu_ctx* ctx, const float* feats_dev, const int32_t* hard_dev, int B, int Np, int D, int K,
+                         float* out_dev, void* hip_stream);
+/* out NHWC (B,H,W,Cu+D): channels [0,Cu) = fu_nhwc (B,H,W,Cu) (Cu may be 0), channels [Cu,Cu+D) = the region embedding
+ * (B*K, D) of the segment of the patch the pixel maps to under torch's 'nearest' interpolation of the (nph, npw) grid
+ * to (H, W): label = hard[b][min(floor(y*nph/H), nph-1)][min(floor(x*npw/W), npw-1)].  Cu, D multiples of 4. */
+int mgu_region_fuse_nhwc(mgu_ctx* ctx, const float* fu_nhwc_dev, int Cu, const float* region_emb_dev, const int32_t* hard_dev,
+                         int B, int H, int W, int nph, int npw, int K, int D, float* out_nhwc_dev, void* hip_stream);
+
 /* ---- introspection for bench.py / profiles ------------------------------------------------------ */
 /* FLOPs (2*MAC, convolutions only) of one U-Net forward over B images: SURVEY 8d table. */
 double mgu_unet_flops(mgu_ctx* ctx, int B, int H, int W);

@@ -5,9 +5,10 @@ from .engine import MinGraphUNet, Trainer, allreduce_mean_, argmax_classes, gat_
 from .gat import GATNetwork, GraphAttentionLayer, MultiHeadGATLayer  # noqa: F401
 from .mincut import MinCutRefinement, PatchSegmentPredictor  # noqa: F401
 from .patch_graph import PatchGraphConstructor  # noqa: F401
+from .region import FeatureFusion, region_edge_index, region_fuse, region_mean_pool, region_stage  # noqa: F401
 from .unet import ConvBlock, DecoderBlock, UNet, UNetDecoder, UNetEncoder  # noqa: F401
 from ._lib import build, lib  # noqa: F401
 
-__all__ = ["MinCutRefinement", "PatchSegmentPredictor", "UNet", "UNetEncoder", "UNetDecoder", "ConvBlock", "DecoderBlock", "GATNetwork", "MultiHeadGATLayer",
+__all__ = ["FeatureFusion", "region_stage", "region_mean_pool", "region_fuse", "region_edge_index", "MinCutRefinement", "PatchSegmentPredictor", "UNet", "UNetEncoder", "UNetDecoder", "ConvBlock", "DecoderBlock", "GATNetwork", "MultiHeadGATLayer",
            "GraphAttentionLayer", "PatchGraphConstructor", "MinGraphUNet", "segment_batch", "argmax_classes",
            "gat_forward_csr", "shard_batch", "Trainer", "allreduce_mean_", "load_config", "get_config_recursively", "build_from_config", "build", "lib"]

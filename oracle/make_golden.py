@@ -7,7 +7,7 @@ weights / inputs of oracle/mgunet_oracle.py, checks that the oracle restatement 
 stores the reference's outputs as small fixtures.  Fixtures hold data only (inputs that are
 not formula-derivable, expected outputs, sample indices) -- never reference source text.
 
-Usage:  python oracle/make_golden.py [--only tiny,gat,graph,mincut,c1,c2,c4,c5]
+Usage:  python oracle/make_golden.py [--only tiny,gat,graph,mincut,region,c1,c2,c4,c5]
 """
 import argparse
 import os
@@ -28,6 +28,7 @@ from model.unet.unet_model import UNet as RefUNet  # noqa: E402
 from model.gat.graph_attention import GATNetwork as RefGAT, MultiHeadGATLayer as RefMH  # noqa: E402
 from preprocessing.graph_construction.patch_graph_construction import PatchGraphConstructor as RefPGC  # noqa: E402
 from model.graph_partition.mincut_refinement import MinCutRefinement as RefMinCut  # noqa: E402
+from model.fusion_detection.feature_fusion import FeatureFusion as RefFusion  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 TOL = 1e-5
@@ -215,6 +216,67 @@ def gen_mincut():
     save("mincut.npz", **out)
 
 
+def gen_region():
+    print("[region] label-mean pooling -> region GAT -> map back -> nearest upsample -> FeatureFusion (SURVEY 8f row 2)")
+    import torch.nn.functional as TF
+    out = {}
+
+    def ref_region_stage(feats, hard, K, gat, nph, npw, H, W):
+        # scripts/train_end_to_end.py:366-421 is loop-body code, not a function: the same torch calls in the same order,
+        # with the reference's GATNetwork as the region model
+        reg = torch.zeros(K, feats.shape[1])
+        for k in range(K):
+            mk = hard == k
+            if mk.sum() > 0:
+                reg[k] = feats[mk].mean(dim=0)
+        if K > 1:
+            s_, t_ = torch.triu_indices(K, K, offset=1)
+            ei = torch.stack([torch.cat([s_, t_]), torch.cat([t_, s_])], dim=0)
+        else:
+            ei = torch.empty((2, 0), dtype=torch.long)
+        emb = gat(reg, ei) if ei.numel() > 0 else reg
+        mapped = emb[hard]
+        pix = TF.interpolate(mapped.T.reshape(emb.shape[1], nph, npw).unsqueeze(0), size=(H, W), mode="nearest").squeeze(0)
+        return emb, pix
+
+    cases = (("a", 64, 64, 2, 4, 16), ("b", 37, 45, 3, 2, 16), ("c", 32, 48, 1, 4, 16), ("d", 512, 512, 2, 4, 16))
+    for tag, H, W, K, heads, patch in cases:
+        nph, npw = O.patch_grid(H, W, patch)
+        Np, D = nph * npw, 64
+        feats = torch.from_numpy(O.formula_normal(f"region/{tag}/x", (Np, D), seed=1)) * 0.5
+        hard = torch.from_numpy(O.formula_labels(f"region/{tag}/y", (Np,), K, seed=2))
+        if tag == "b":
+            hard[hard == 1] = 0          # an empty segment: its region feature stays zero (:369-373)
+        p = O.make_gat_params(D, 128, D, heads, 1, seed=9)
+        gat = RefGAT(D, 128, D, heads, num_gat_layers=1).eval()
+        gat.load_state_dict(p)
+        with torch.no_grad():
+            emb, pix = ref_region_stage(feats, hard, K, gat, nph, npw, H, W)
+            oemb, opix = O.region_stage(feats, hard, K, p, heads, nph, npw, H, W)
+        check(f"{tag}.emb", oemb, emb)
+        check(f"{tag}.pix", opix, pix)
+        out[f"{tag}_emb"] = emb.numpy()
+        out[f"{tag}_hard"] = hard.numpy()
+        idx = sample_idx(f"region/{tag}/idx", pix.numel(), 2048)
+        out[f"{tag}_pix_idx"] = idx
+        out[f"{tag}_pix"] = pix.reshape(-1).numpy()[idx]
+        # FeatureFusion (train_end_to_end.py:433-437): one F_u scale + the pixel-mapped F_g
+        fu = torch.from_numpy(O.formula_normal(f"region/{tag}/fu", (1, 32, H, W), seed=3))
+        fuser = RefFusion(unet_feature_dims=[32], gat_feature_dim=D)
+        with torch.no_grad():
+            ff = fuser(f_u_list=[fu], f_g=pix.unsqueeze(0), target_spatial_size=(H, W))
+        check(f"{tag}.fused", O.feature_fusion([fu], opix.unsqueeze(0)), ff)
+        assert tuple(ff.shape) == (1, 32 + D, H, W)
+        fidx = sample_idx(f"region/{tag}/fidx", ff.numel(), 2048)
+        out[f"{tag}_fused_idx"] = fidx
+        out[f"{tag}_fused"] = ff.reshape(-1).numpy()[fidx]
+        print(f"   {tag}: {H}x{W} -> {nph}x{npw} patches, K={K}, emb max {float(emb.abs().max()):.3f}")
+    fa = RefFusion([64], 64, fusion_method="add")
+    a_, b_ = torch.ones(1, 64, 4, 4), torch.full((1, 64, 4, 4), 2.0)
+    assert torch.equal(fa([a_], b_), O.feature_fusion([a_], b_, "add"))
+    save("region.npz", **out)
+
+
 def gen_graph():
     print("[graph] COO index maps: 128^2/p32, 130x140/p32, 512^2/p16, 1024^2/p16, 16x16/p16 (empty)")
     out = {}
@@ -383,11 +445,11 @@ def gen_c5():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,gat,graph,mincut,c1,c2,c4,c5")
+    ap.add_argument("--only", default="tiny,gat,graph,mincut,region,c1,c2,c4,c5")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    fns = {"tiny": gen_tiny, "gat": gen_gat, "graph": gen_graph, "mincut": gen_mincut, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
+    fns = {"tiny": gen_tiny, "gat": gen_gat, "graph": gen_graph, "mincut": gen_mincut, "region": gen_region, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
     for k in a.only.split(","):
         t0 = time.time()
         fns[k]()

@@ -9,7 +9,8 @@ path can be checked on a box where the reference's Python does not exist.  Only 
 Parity status: PINNED.  `oracle/make_golden.py` (run in the build container, where
 `/root/reference` is importable) loads the same formula weights into the reference's own
 `model.unet.unet_model.UNet`, `model.gat.graph_attention.GATNetwork`,
-`model.graph_partition.mincut_refinement.MinCutRefinement` and
+`model.graph_partition.mincut_refinement.MinCutRefinement`,
+`model.fusion_detection.feature_fusion.FeatureFusion` and
 `preprocessing.graph_construction.patch_graph_construction.PatchGraphConstructor`, asserts
 this restatement agrees (<= 1e-5 abs on O(1) logits; index maps bit-exact) and writes the
 reference's outputs to `tests/golden/`.  `tests/test_oracle_golden.py` re-checks this file against
@@ -395,6 +396,52 @@ def mincut_forward(node_features, edge_index, num_segments, segment_logits):
     soft = F.softmax(segment_logits, dim=1)  # :190
     loss = normalized_cut_loss(node_features, edge_index, soft, num_segments)  # :193-198
     return loss, soft, torch.argmax(soft, dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# Region stage + feature fusion (first half): scripts/train_end_to_end.py:358-437,
+# model/fusion_detection/feature_fusion.py:43-162
+# --------------------------------------------------------------------------------------
+def region_edge_index(K: int) -> torch.Tensor:
+    """The fully connected placeholder region graph, train_end_to_end.py:375-380."""
+    if K > 1:
+        src, tgt = torch.triu_indices(K, K, offset=1)
+        return torch.stack([torch.cat([src, tgt]), torch.cat([tgt, src])], dim=0)
+    return torch.empty((2, 0), dtype=torch.long)
+
+
+def region_stage(patch_feats, hard_labels, K, region_gat_params, num_heads, nph, npw, H, W):
+    """One image: label-mean pooling (:369-373), region GAT on the K-node graph (:382-390), map back to patches
+    (:403-406), patch grid -> pixels by nearest interpolation (:410-421).  Returns (region embeddings (K, D'),
+    f_g_pixel (D', H, W))."""
+    D = patch_feats.shape[1]
+    reg = torch.zeros(K, D, dtype=patch_feats.dtype)
+    for k in range(K):
+        m = hard_labels == k
+        if m.sum() > 0:
+            reg[k] = patch_feats[m].mean(dim=0)
+    ei = region_edge_index(K)
+    if K > 0 and ei.numel() > 0:
+        emb = gat_network_forward(region_gat_params, reg, ei, num_heads, 1)  # :383-384
+    else:
+        emb = reg  # :385-387
+    mapped = emb[hard_labels]  # :403-404
+    grid = mapped.t().reshape(emb.shape[1], nph, npw)  # :410
+    pix = F.interpolate(grid.unsqueeze(0), size=(H, W), mode="nearest").squeeze(0)  # :416-420
+    return emb, pix
+
+
+def feature_fusion(f_u_list, f_g, method="concat"):
+    """FeatureFusion.forward for spatially aligned inputs (feature_fusion.py:64-78, 145-160): the case the e2e loop
+    uses (train_end_to_end.py:433-437: one F_u scale, F_g already (B, D, H, W) at the same size)."""
+    f_u = torch.cat(list(f_u_list), dim=1)  # :78
+    if method == "concat":
+        return torch.cat([f_u, f_g], dim=1)  # :150
+    if method == "add":
+        if f_u.shape[1] != f_g.shape[1]:
+            raise ValueError("Channel dimensions must match for 'add' fusion or implement adaptation.")  # :153-154
+        return f_u + f_g
+    raise NotImplementedError(f"Fusion method '{method}' not implemented.")  # :157
 
 
 # --------------------------------------------------------------------------------------

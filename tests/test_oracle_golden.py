@@ -154,3 +154,32 @@ def test_mincut_stage_vs_reference_fixture(golden, tag):
         assert float(soft[:, 1].max()) < 1e-20 and 0.9 < float(loss) < 1.1
     with pytest.raises(ValueError):
         O.normalized_cut_loss(X, ei, torch.zeros(X.shape[0], K + 1), K)
+
+
+REGION_CASES = {"a": (64, 64, 2, 4), "b": (37, 45, 3, 2), "c": (32, 48, 1, 4), "d": (512, 512, 2, 4)}   # tag -> (H, W, K, heads)
+
+
+def region_case(golden, tag):
+    H, W, K, heads = REGION_CASES[tag]
+    g = golden["region"]
+    nph, npw = O.patch_grid(H, W, 16)
+    feats = torch.from_numpy(O.formula_normal(f"region/{tag}/x", (nph * npw, 64), seed=1)) * 0.5
+    hard = torch.from_numpy(g[f"{tag}_hard"])
+    p = O.make_gat_params(64, 128, 64, heads, 1, seed=9)
+    fu = torch.from_numpy(O.formula_normal(f"region/{tag}/fu", (1, 32, H, W), seed=3))
+    return g, H, W, K, heads, nph, npw, feats, hard, p, fu
+
+
+@pytest.mark.parametrize("tag", list(REGION_CASES))
+def test_region_stage_and_fusion_vs_reference_fixture(golden, tag):
+    """Label-mean pooling -> region GAT -> map back -> nearest upsample -> FeatureFusion concat against
+    the reference's GATNetwork / F.interpolate / FeatureFusion outputs (oracle/make_golden.py gen_region)."""
+    g, H, W, K, heads, nph, npw, feats, hard, p, fu = region_case(golden, tag)
+    emb, pix = O.region_stage(feats, hard, K, p, heads, nph, npw, H, W)
+    assert np.abs(emb.numpy() - g[f"{tag}_emb"]).max() <= 1e-6
+    assert np.abs(pix.reshape(-1).numpy()[g[f"{tag}_pix_idx"]] - g[f"{tag}_pix"]).max() <= 1e-6
+    fused = O.feature_fusion([fu], pix.unsqueeze(0))
+    assert tuple(fused.shape) == (1, 96, H, W)
+    assert np.abs(fused.reshape(-1).numpy()[g[f"{tag}_fused_idx"]] - g[f"{tag}_fused"]).max() <= 1e-6
+    if tag == "b":   # the emptied segment's region feature is zero before the GAT (train_end_to_end.py:369-373)
+        assert int((hard == 1).sum()) == 0
