@@ -187,6 +187,15 @@ int mgu_region_mean_pool(mgu_ctx* ctx, const float* feats_dev, const int32_t* ha
 int mgu_region_fuse_nhwc(mgu_ctx* ctx, const float* fu_nhwc_dev, int Cu, const float* region_emb_dev, const int32_t* hard_dev,
                          int B, int H, int W, int nph, int npw, int K, int D, float* out_nhwc_dev, void* hip_stream);
 
+/* ---- per-channel building blocks of the DetectionHead: model/fusion_detection/detection_head.py ---- */
+/* y[m][c] = act(scale[c] * x[m][c] + shift[c]) over an (M, C) NHWC view with row pitches ldx / ldy (floats); scale / shift
+ * may be NULL (1 / 0); act 0 = none (the BatchNorm2d that follows a ReLU, :33-38), 1 = ReLU, 2 = sigmoid (:101,104).
+ * C, ldx, ldy multiples of 4. */
+int mgu_channel_affine_nhwc(mgu_ctx* ctx, const float* x_dev, int ldx, int64_t M, int C, const float* scale_dev,
+                            const float* shift_dev, int act, float* y_dev, int ldy, void* hip_stream);
+/* out[c] = sum over the M rows of x[m][c]: AdaptiveAvgPool2d((1,1)) (:39) per image is this sum / (H W). 4 <= C <= 1024. */
+int mgu_channel_sum_nhwc(mgu_ctx* ctx, const float* x_dev, int ldx, int64_t M, int C, float* out_dev, void* hip_stream);
+
 /* ---- introspection for bench.py / profiles ------------------------------------------------------ */
 /* FLOPs (2*MAC, convolutions only) of one U-Net forward over B images: SURVEY 8d table. */
 double mgu_unet_flops(mgu_ctx* ctx, int B, int H, int W);

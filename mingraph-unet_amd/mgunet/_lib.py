@@ -65,6 +65,9 @@ _PROTOS = {
     "mgu_region_mean_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mgu_region_fuse_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mgu_channel_affine_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.c_int, C.c_void_p]),
+    "mgu_channel_sum_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mgu_unet_request_patch_mean": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mgu_unet_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgu_unet_mfma_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),

@@ -7,7 +7,7 @@ weights / inputs of oracle/mgunet_oracle.py, checks that the oracle restatement 
 stores the reference's outputs as small fixtures.  Fixtures hold data only (inputs that are
 not formula-derivable, expected outputs, sample indices) -- never reference source text.
 
-Usage:  python oracle/make_golden.py [--only tiny,gat,graph,mincut,region,c1,c2,c4,c5]
+Usage:  python oracle/make_golden.py [--only tiny,gat,graph,mincut,region,dethead,c1,c2,c4,c5]
 """
 import argparse
 import os
@@ -29,6 +29,7 @@ from model.gat.graph_attention import GATNetwork as RefGAT, MultiHeadGATLayer as
 from preprocessing.graph_construction.patch_graph_construction import PatchGraphConstructor as RefPGC  # noqa: E402
 from model.graph_partition.mincut_refinement import MinCutRefinement as RefMinCut  # noqa: E402
 from model.fusion_detection.feature_fusion import FeatureFusion as RefFusion  # noqa: E402
+from model.fusion_detection.detection_head import DetectionHead as RefDet  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 TOL = 1e-5
@@ -277,6 +278,30 @@ def gen_region():
     save("region.npz", **out)
 
 
+def gen_dethead():
+    print("[dethead] DetectionHead: conv-ReLU-BN x2, global average pool, MLP, sigmoid heads (SURVEY 8f row 2)")
+    out = {}
+    for tag, B, C, H, W, ncls, flat in (("a", 2, 96, 24, 40, 1, False), ("b", 1, 96, 128, 128, 3, False), ("c", 3, 64, 17, 9, 2, False),
+                                        ("f", 4, 24, 0, 0, 1, True)):
+        p = O.make_detection_head_params(C, ncls, 256, flat, seed=13)
+        m = RefDet(C, ncls, fc_hidden_dim=256, input_is_flat=flat).eval()
+        sd = dict(p)
+        for k in ("2", "5"):
+            if f"conv_block.{k}.weight" in sd:
+                sd[f"conv_block.{k}.num_batches_tracked"] = torch.tensor(0)
+        m.load_state_dict(sd)
+        x = torch.from_numpy(O.formula_normal(f"det/{tag}/x", (B, C) if flat else (B, C, H, W), seed=2))
+        with torch.no_grad():
+            ref = m(x)
+            got = O.detection_head_forward(p, x, ncls, flat)
+        assert len(ref) == len(got) == (3 if ncls > 1 else 2)
+        for nm, r, g_ in zip(("bbox", "conf", "cls"), ref, got):
+            check(f"{tag}.{nm}", g_, r)
+            out[f"{tag}_{nm}"] = r.numpy()
+        print(f"   {tag}: input {tuple(x.shape)} classes {ncls} -> bbox {tuple(ref[0].shape)} conf {tuple(ref[1].shape)}")
+    save("dethead.npz", **out)
+
+
 def gen_graph():
     print("[graph] COO index maps: 128^2/p32, 130x140/p32, 512^2/p16, 1024^2/p16, 16x16/p16 (empty)")
     out = {}
@@ -445,11 +470,11 @@ def gen_c5():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,gat,graph,mincut,region,c1,c2,c4,c5")
+    ap.add_argument("--only", default="tiny,gat,graph,mincut,region,dethead,c1,c2,c4,c5")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    fns = {"tiny": gen_tiny, "gat": gen_gat, "graph": gen_graph, "mincut": gen_mincut, "region": gen_region, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
+    fns = {"tiny": gen_tiny, "gat": gen_gat, "graph": gen_graph, "mincut": gen_mincut, "region": gen_region, "dethead": gen_dethead, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
     for k in a.only.split(","):
         t0 = time.time()
         fns[k]()

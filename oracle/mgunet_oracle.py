@@ -10,7 +10,8 @@ Parity status: PINNED.  `oracle/make_golden.py` (run in the build container, whe
 `/root/reference` is importable) loads the same formula weights into the reference's own
 `model.unet.unet_model.UNet`, `model.gat.graph_attention.GATNetwork`,
 `model.graph_partition.mincut_refinement.MinCutRefinement`,
-`model.fusion_detection.feature_fusion.FeatureFusion` and
+`model.fusion_detection.feature_fusion.FeatureFusion`,
+`model.fusion_detection.detection_head.DetectionHead` and
 `preprocessing.graph_construction.patch_graph_construction.PatchGraphConstructor`, asserts
 this restatement agrees (<= 1e-5 abs on O(1) logits; index maps bit-exact) and writes the
 reference's outputs to `tests/golden/`.  `tests/test_oracle_golden.py` re-checks this file against
@@ -442,6 +443,72 @@ def feature_fusion(f_u_list, f_g, method="concat"):
             raise ValueError("Channel dimensions must match for 'add' fusion or implement adaptation.")  # :153-154
         return f_u + f_g
     raise NotImplementedError(f"Fusion method '{method}' not implemented.")  # :157
+
+
+# --------------------------------------------------------------------------------------
+# DetectionHead (second half): model/fusion_detection/detection_head.py:4-114
+# --------------------------------------------------------------------------------------
+def detection_head_param_shapes(in_ch, num_classes, fc_hidden_dim=256, input_is_flat=False):
+    """state_dict keys of DetectionHead (detection_head.py:31-66)."""
+    out: "OrderedDict[str, tuple]" = OrderedDict()
+    if not input_is_flat:
+        c1, c2 = in_ch // 2, in_ch // 4
+        out["conv_block.0.weight"], out["conv_block.0.bias"] = (c1, in_ch, 3, 3), (c1,)  # :33
+        for k, c in (("2", c1), ("5", c2)):  # :35, :38
+            out[f"conv_block.{k}.weight"], out[f"conv_block.{k}.bias"] = (c,), (c,)
+            out[f"conv_block.{k}.running_mean"], out[f"conv_block.{k}.running_var"] = (c,), (c,)
+        out["conv_block.3.weight"], out["conv_block.3.bias"] = (c2, c1, 3, 3), (c2,)  # :36
+        fc_in = c2
+    else:
+        fc_in = in_ch
+    out["fc_layers.0.weight"], out["fc_layers.0.bias"] = (fc_hidden_dim, fc_in), (fc_hidden_dim,)  # :46
+    out["fc_layers.3.weight"], out["fc_layers.3.bias"] = (fc_hidden_dim // 2, fc_hidden_dim), (fc_hidden_dim // 2,)  # :49
+    out["fc_bbox.weight"], out["fc_bbox.bias"] = (4, fc_hidden_dim // 2), (4,)  # :56
+    out["fc_confidence.weight"], out["fc_confidence.bias"] = (1, fc_hidden_dim // 2), (1,)  # :59
+    if num_classes > 1:
+        out["fc_class_scores.weight"], out["fc_class_scores.bias"] = (num_classes, fc_hidden_dim // 2), (num_classes,)  # :65-66
+    return out
+
+
+def make_detection_head_params(in_ch, num_classes, fc_hidden_dim=256, input_is_flat=False, seed=0):
+    params = OrderedDict()
+    for name, shape in detection_head_param_shapes(in_ch, num_classes, fc_hidden_dim, input_is_flat).items():
+        if name.endswith("running_var"):
+            v = formula_uniform(name, shape, 0.5, 1.5, seed)
+        elif name.endswith("running_mean"):
+            v = formula_uniform(name, shape, -0.2, 0.2, seed)
+        elif len(shape) == 1 and ("conv_block.2" in name or "conv_block.5" in name) and name.endswith("weight"):
+            v = formula_uniform(name, shape, -1.5, 1.5, seed)   # BatchNorm gamma of both signs: the affine follows the ReLU
+        elif len(shape) == 1:
+            v = formula_uniform(name, shape, -0.2, 0.2, seed)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            a = float(np.sqrt(6.0 / fan_in))
+            v = formula_uniform(name, shape, -a, a, seed)
+        params[name] = torch.from_numpy(v)
+    return params
+
+
+def detection_head_forward(p, f_fused, num_classes, input_is_flat=False, eps=1e-5):
+    """DetectionHead.forward in eval mode (dropout = identity, BatchNorm on running statistics), detection_head.py:69-114.
+    Note the order Conv -> ReLU -> BatchNorm (:33-38): the affine comes AFTER the ReLU."""
+    if not input_is_flat:
+        x = F.relu(F.conv2d(f_fused, p["conv_block.0.weight"], p["conv_block.0.bias"], padding=1))
+        x = F.batch_norm(x, p["conv_block.2.running_mean"], p["conv_block.2.running_var"], p["conv_block.2.weight"],
+                         p["conv_block.2.bias"], False, 0.1, eps)
+        x = F.relu(F.conv2d(x, p["conv_block.3.weight"], p["conv_block.3.bias"], padding=1))
+        x = F.batch_norm(x, p["conv_block.5.running_mean"], p["conv_block.5.running_var"], p["conv_block.5.weight"],
+                         p["conv_block.5.bias"], False, 0.1, eps)
+        x = torch.flatten(F.adaptive_avg_pool2d(x, (1, 1)), 1)  # :39, :93
+    else:
+        x = f_fused
+    x = F.relu(x @ p["fc_layers.0.weight"].t() + p["fc_layers.0.bias"])  # :45-52
+    x = F.relu(x @ p["fc_layers.3.weight"].t() + p["fc_layers.3.bias"])
+    bboxes = torch.sigmoid(x @ p["fc_bbox.weight"].t() + p["fc_bbox.bias"])  # :101
+    conf = torch.sigmoid(x @ p["fc_confidence.weight"].t() + p["fc_confidence.bias"])  # :104
+    if num_classes > 1:
+        return bboxes, conf, x @ p["fc_class_scores.weight"].t() + p["fc_class_scores.bias"]  # :107-111
+    return bboxes, conf
 
 
 # --------------------------------------------------------------------------------------

@@ -183,3 +183,25 @@ def test_region_stage_and_fusion_vs_reference_fixture(golden, tag):
     assert np.abs(fused.reshape(-1).numpy()[g[f"{tag}_fused_idx"]] - g[f"{tag}_fused"]).max() <= 1e-6
     if tag == "b":   # the emptied segment's region feature is zero before the GAT (train_end_to_end.py:369-373)
         assert int((hard == 1).sum()) == 0
+
+
+DETHEAD_CASES = {"a": (2, 96, 24, 40, 1, False), "b": (1, 96, 128, 128, 3, False), "c": (3, 64, 17, 9, 2, False), "f": (4, 24, 0, 0, 1, True)}
+
+
+def dethead_case(tag):
+    B, C, H, W, ncls, flat = DETHEAD_CASES[tag]
+    p = O.make_detection_head_params(C, ncls, 256, flat, seed=13)
+    x = torch.from_numpy(O.formula_normal(f"det/{tag}/x", (B, C) if flat else (B, C, H, W), seed=2))
+    return p, x, ncls, flat, C
+
+
+@pytest.mark.parametrize("tag", list(DETHEAD_CASES))
+def test_detection_head_vs_reference_fixture(golden, tag):
+    """DetectionHead.forward in eval mode (detection_head.py:69-114) against the reference class's outputs."""
+    p, x, ncls, flat, _ = dethead_case(tag)
+    g = golden["dethead"]
+    with torch.no_grad():
+        got = O.detection_head_forward(p, x, ncls, flat)
+    assert len(got) == (3 if ncls > 1 else 2)
+    for nm, t in zip(("bbox", "conf", "cls"), got):
+        assert np.abs(t.numpy() - g[f"{tag}_{nm}"]).max() <= 1e-6
