@@ -2,7 +2,7 @@
 model/ API over libmgunet.so).  Importing works without a GPU; running anything needs one."""
 from .config import build_from_config, get_config_recursively, load_config  # noqa: F401
 from .detection import DetectionHead  # noqa: F401
-from .engine import MinGraphUNet, Trainer, allreduce_mean_, argmax_classes, gat_forward_csr, segment_batch, shard_batch  # noqa: F401
+from .engine import MinGraphUNet, MinGraphUNetE2E, Trainer, allreduce_mean_, argmax_classes, gat_forward_csr, segment_batch, shard_batch  # noqa: F401
 from .gat import GATNetwork, GraphAttentionLayer, MultiHeadGATLayer  # noqa: F401
 from .mincut import MinCutRefinement, PatchSegmentPredictor  # noqa: F401
 from .patch_graph import PatchGraphConstructor  # noqa: F401
@@ -11,5 +11,5 @@ from .unet import ConvBlock, DecoderBlock, UNet, UNetDecoder, UNetEncoder  # noq
 from ._lib import build, lib  # noqa: F401
 
 __all__ = ["DetectionHead", "FeatureFusion", "region_stage", "region_mean_pool", "region_fuse", "region_edge_index", "MinCutRefinement", "PatchSegmentPredictor", "UNet", "UNetEncoder", "UNetDecoder", "ConvBlock", "DecoderBlock", "GATNetwork", "MultiHeadGATLayer",
-           "GraphAttentionLayer", "PatchGraphConstructor", "MinGraphUNet", "segment_batch", "argmax_classes",
+           "GraphAttentionLayer", "PatchGraphConstructor", "MinGraphUNet", "MinGraphUNetE2E", "segment_batch", "argmax_classes",
            "gat_forward_csr", "shard_batch", "Trainer", "allreduce_mean_", "load_config", "get_config_recursively", "build_from_config", "build", "lib"]

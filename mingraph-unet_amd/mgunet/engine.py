@@ -49,6 +49,45 @@ class MinGraphUNet(nn.Module):
         return logits, skips, feats, emb
 
 
+class MinGraphUNetE2E(nn.Module):
+    """Stages 1-7 of the reference's end-to-end forward (scripts/train_end_to_end.py:270-453) for a whole batch, on
+    deterministic node features: U-Net -> patch-mean node features -> patch GAT -> segment predictor +
+    normalized-cut loss (mean over images, :425) -> region stage -> FeatureFusion with the shallowest decoder feature ->
+    DetectionHead.  Returns a dict with the tensors the loop produces: logits, node embeddings, loss_partition, soft /
+    hard patch assignments, region embeddings, fused features, boxes, confidence (and class scores)."""
+
+    def __init__(self, unet: UNet, patch_gat: GATNetwork, segment_predictor, mincut, region_gat: GATNetwork, detection_head,
+                 num_segments: int, patch_size: int = 16):
+        super().__init__()
+        self.core = MinGraphUNet(unet, patch_gat, patch_size)
+        self.segment_predictor, self.mincut, self.region_gat, self.detection_head = segment_predictor, mincut, region_gat, detection_head
+        self.num_segments = num_segments
+
+    def forward(self, x):
+        from .region import region_stage
+        B, _, H, W = x.shape
+        logits, skips, feats, emb = self.core(x)
+        graph = self.core.graph
+        nph, npw = graph.grid(H, W)
+        K = self.num_segments
+        ei_one = graph.edge_index(H, W, x.device)                                   # one image's COO (all images share it)
+        if getattr(self.segment_predictor, "use_gnn", False):
+            ei_all = graph.edge_index(H, W, x.device, B)
+            gp = graph.batched_csr(H, W, B, x.device)[2]                            # per-graph max e (graph_attention.py:86)
+            seg_logits = self.segment_predictor.gnn_predictor(emb, ei_all, graph_ptr=gp)
+        else:
+            seg_logits = self.segment_predictor(emb)
+        losses, soft, hard = self.mincut.forward_batched(emb, ei_one, B, K, seg_logits.contiguous())
+        region_emb, fused = region_stage(emb, hard, B, K, self.region_gat, nph, npw, H, W, f_u=feats[0])
+        det = self.detection_head(fused)
+        out = {"logits": logits, "skips": skips, "decoder_feats": feats, "node_embeddings": emb, "loss_partition": losses.mean(),
+               "soft_assignments": soft, "hard_labels": hard, "region_embeddings": region_emb, "fused": fused,
+               "bboxes": det[0], "confidence": det[1]}
+        if len(det) > 2:
+            out["class_scores"] = det[2]
+        return out
+
+
 def gat_forward_csr(gat: GATNetwork, X, rowptr, col, graph_ptr):
     """GATNetwork.forward on a prebuilt device CSR (skips the COO->CSR conversion of the COO API)."""
     h = X

@@ -134,6 +134,18 @@ class MinCutRefinement(nn.Module):
         _lib.check(rc, ctx.handle)
         return loss[0], soft, hard
 
+    def forward_batched(self, patch_features, edge_index_single, B, num_expected_segments, segment_logits):
+        """The per-image loop of train_end_to_end.py:347-356 for B images that share one patch-graph topology:
+        patch_features (B*Np, D), segment_logits (B*Np, K) -> (losses (B,), soft (B*Np, K), hard labels (B*Np,) int64).
+        The loss is a quotient per image, so each image is one mgu_ncut_forward call on its slice."""
+        N = patch_features.size(0) // B
+        losses, softs, hards = [], [], []
+        for b in range(B):
+            l, s, h = self._ncut(patch_features[b * N:(b + 1) * N], edge_index_single, segment_logits[b * N:(b + 1) * N],
+                                 num_expected_segments, True)
+            losses.append(l), softs.append(s), hards.append(h)
+        return torch.stack(losses), torch.cat(softs, 0), torch.cat(hards, 0).to(torch.int64)
+
     def normalized_cut_loss(self, node_features, edge_index, segment_assignments_soft, num_segments_k):
         """sum_k cut(A_k, V \\ A_k) / assoc(A_k, V) with soft assignments (:55-160)."""
         N = node_features.size(0)

@@ -61,6 +61,22 @@ class PatchGraphConstructor:
         ei = torch.from_numpy(coo.copy()).to(patch_features_flat.device)
         return patch_features_flat, ei
 
+    def grid(self, H, W):
+        """(nph, npw) of an H x W image (ceil division, patch_graph_construction.py:67-68)."""
+        _, _, _, nph, npw = self._maps(H, W)
+        return nph, npw
+
+    def edge_index(self, H, W, device, B=1):
+        """The reference's COO int64 (2, E) edge list of one H x W image (B = 1) or the block-diagonal list of B images,
+        cached per (H, W, B, device) so that CSR caches keyed on the tensor keep hitting."""
+        key = ("coo", H, W, self.patch_size, B, str(device))
+        if key not in self._cache:
+            coo, _, _, nph, npw = self._maps(H, W)
+            one = torch.from_numpy(coo.copy())
+            N = nph * npw
+            self._cache[key] = (torch.cat([one + N * b for b in range(B)], dim=1) if B > 1 else one).to(device)
+        return self._cache[key]
+
     def batched_csr(self, H, W, B, device):
         """Block-diagonal CSR-by-target of B copies of the H x W patch graph, on `device`:
         (rowptr int32[B*N+1], col int32[B*E], graph_ptr int32[B+1], N, E)."""

@@ -56,3 +56,51 @@ def test_detection_head_on_fused_features_and_errors(cuda):
         m(fused.cpu())
     with pytest.raises(RuntimeError, match="eval"):
         m.train()(fused)
+
+
+def test_e2e_forward_stages_1_to_7_vs_oracle_composition(cuda):
+    """mgunet.MinGraphUNetE2E (train_end_to_end.py:270-453 on deterministic node features) against the oracle's stage
+    functions chained the same way, 2 x 3 x 64 x 64: every tensor the loop produces."""
+    B, H, W, K = 2, 64, 64, 2
+    up = O.make_unet_params(3, 2, 32, 4, seed=1)
+    gp_ = O.make_gat_params(32, 128, 64, 4, 1, seed=2)
+    pp = O.make_segment_predictor_params(64, K, 32, True, 2, seed=3)
+    rp = O.make_gat_params(64, 128, 64, 4, 1, seed=4)
+    dp = O.make_detection_head_params(96, 1, 256, False, seed=5)
+    x = torch.from_numpy(O.formula_normal("e2e/x", (B, 3, H, W), seed=6))
+
+    unet = mgunet.UNet(3, 2, 32, 4); unet.load_state_dict(up)
+    pgat = mgunet.GATNetwork(32, 128, 64, 4, 1); pgat.load_state_dict(gp_)
+    pred = mgunet.PatchSegmentPredictor(64, K, hidden_dim=32, use_gnn=True, num_heads=2); pred.load_state_dict(pp)
+    rgat = mgunet.GATNetwork(64, 128, 64, 4, 1); rgat.load_state_dict(rp)
+    det = mgunet.DetectionHead(96, 1)
+    sd = dict(dp); sd["conv_block.2.num_batches_tracked"] = sd["conv_block.5.num_batches_tracked"] = torch.tensor(0)
+    det.load_state_dict(sd)
+    model = mgunet.MinGraphUNetE2E(unet, pgat, pred, mgunet.MinCutRefinement(), rgat, det, num_segments=K).to(cuda).eval()
+    out = model(x.to(cuda))
+
+    nph, npw = O.patch_grid(H, W, 16)
+    ei = torch.from_numpy(O.patch_graph_edges(H, W, 16))
+    with torch.no_grad():
+        lg, _, ft = O.unet_forward(up, x, 4)
+        losses, fused_ref, embs, softs = [], [], [], []
+        for b in range(B):
+            X = O.patch_mean_features(ft[0][b], 16)
+            emb = O.gat_network_forward(gp_, X, ei, 4)
+            sl = O.segment_predictor_forward(pp, emb, ei, True, 2)
+            loss, soft, hard = O.mincut_forward(emb, ei, K, sl)
+            _, pix = O.region_stage(emb, hard, K, rp, 4, nph, npw, H, W)
+            fused_ref.append(O.feature_fusion([ft[0][b:b + 1]], pix.unsqueeze(0)))
+            losses.append(loss), embs.append(emb), softs.append(soft)
+        fused_ref = torch.cat(fused_ref, 0)
+        bb, cf = O.detection_head_forward(dp, fused_ref, 1)
+    assert float((out["logits"].cpu() - lg).abs().max()) <= 1e-3
+    assert float((out["node_embeddings"].cpu() - torch.cat(embs)).abs().max()) <= 1e-4
+    assert float((out["soft_assignments"].cpu() - torch.cat(softs)).abs().max()) <= 1e-4
+    assert abs(float(out["loss_partition"]) - float(torch.stack(losses).mean())) <= 1e-4
+    # the hard labels decide which region embedding a pixel gets: compare the fused map only if no assignment is a near-tie
+    margin = (torch.cat(softs)[:, 0] - torch.cat(softs)[:, 1]).abs().min()
+    if float(margin) > 1e-3:
+        assert float((out["fused"].cpu() - fused_ref).abs().max()) <= 1e-3
+        assert float((out["bboxes"].cpu() - bb).abs().max()) <= 1e-4 and float((out["confidence"].cpu() - cf).abs().max()) <= 1e-4
+    assert tuple(out["fused"].shape) == (B, 96, H, W) and tuple(out["bboxes"].shape) == (B, 4)
