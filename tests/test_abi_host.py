@@ -128,3 +128,31 @@ def test_shard_batch_covers_batch_exactly():
             assert spans[0][0] == 0 and spans[-1][1] == gb
             assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_checkpoint_interchange_both_pth_layouts(tmp_path):
+    """SURVEY 8f row 4 (checkpoint part): a `.pth` written the way the reference writes it -- a bare state_dict
+    (train_segmentation.py:158-168) or {'model_state_dict': ...} (infer_segmentation.py:92-95) -- loads into the
+    mirror unchanged, and a checkpoint saved from the mirror has exactly the reference's keys and values."""
+    ref_sd = O.make_unet_params(3, 2, 32, 4, seed=3)
+    for i, payload in enumerate((ref_sd, {"model_state_dict": ref_sd, "epoch": 7})):
+        path = tmp_path / f"ck{i}.pth"
+        torch.save(payload, path)
+        ck = torch.load(path, map_location="cpu")
+        sd = ck["model_state_dict"] if isinstance(ck, dict) and "model_state_dict" in ck else ck   # infer_segmentation.py:92-95
+        m = mgunet.UNet(3, 2, 32, 4)
+        res = m.load_state_dict(sd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        out = tmp_path / f"out{i}.pth"
+        torch.save(m.state_dict(), out)
+        back = torch.load(out, map_location="cpu")
+        assert list(back.keys()) == list(ref_sd.keys())
+        assert all(torch.equal(back[k], ref_sd[k]) for k in ref_sd)
+    # the modules of SURVEY 8f rows 1-2 carry the reference's keys too
+    pred = mgunet.PatchSegmentPredictor(64, 2, hidden_dim=32, use_gnn=True, num_heads=2)
+    assert list(pred.state_dict().keys()) == list(O.segment_predictor_param_shapes(64, 2, 32, True, 2).keys())
+    mlp = mgunet.PatchSegmentPredictor(24, 3)
+    assert list(mlp.state_dict().keys()) == list(O.segment_predictor_param_shapes(24, 3, None, False, 1).keys())
+    det = mgunet.DetectionHead(96, 3)
+    want = set(O.detection_head_param_shapes(96, 3).keys()) | {"conv_block.2.num_batches_tracked", "conv_block.5.num_batches_tracked"}
+    assert set(det.state_dict().keys()) == want
