@@ -25,6 +25,7 @@
 //   * inverse transform: each wave folds its own row (M[i][.] A) in registers, the four row waves meet through a
 //     small LDS exchange, and lanes store one channel each (32 lanes = one 128-byte line of a pixel).
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace mgu {
@@ -652,10 +653,13 @@ static hipError_t launch_wino_mode(const IgemmDesc& d, hipStream_t s) {
   const int tiles_x = (d.W + 31) / 32, tiles_y = (d.H + 7) / 8;
   const int B = d.M / (d.H * d.W);
   const int total = tiles_x * tiles_y * B, nblk = (d.N + 32 * NTB - 1) / (32 * NTB);
-  // one 512-thread workgroup per CU is resident: keep ~2 rounds of them in the grid, each walking its patches
-  int ppb = (int)(((long)total * nblk) / (256 * 2));
+  // one workgroup per CU is resident: ONE round of them, each walking up to 32 patches (measured against 2-4 rounds of
+  // shorter walks: fewer pipeline prologues and no second-round tail, 0.7 % of the headline step)
+  static const int rounds = getenv("MGU_WINO_ROUNDS") ? atoi(getenv("MGU_WINO_ROUNDS")) : 1;
+  static const int cap = getenv("MGU_WINO_PPB_CAP") ? atoi(getenv("MGU_WINO_PPB_CAP")) : 32;
+  int ppb = (int)(((long)total * nblk) / (256 * rounds));
   if (ppb < 1) ppb = 1;
-  if (ppb > 16) ppb = 16;
+  if (ppb > cap) ppb = cap;
   const int ngroups = (total + ppb - 1) / ppb;
   const int per_xcd = (ngroups * nblk + 7) / 8;
   dim3 grid(8 * per_xcd, 1);
