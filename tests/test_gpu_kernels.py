@@ -4,6 +4,8 @@ implicit-GEMM tile configurations (N <= 32, <= 64, > 64), the K tail, the M tail
 channel-slice (concat) stores."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -92,6 +94,8 @@ def test_winograd_conv_vs_torch_and_direct(cuda, B, H, W, Cin, Cout, monkeypatch
     """The fp32 3x3 layers with Cin % 16 == 0 route to wino3x3_f32_kernel (Winograd F(2x2,3x3), csrc/wino_f32.hip):
     compare against torch fp32 AND against the direct implicit-GEMM kernel (MGU_NO_WINOGRAD=1, read at mgu_create)
     on the same operands, including the scale/shift/ReLU epilogue into a channel slice of a wider buffer."""
+    if os.environ.get("MGU_NO_WINOGRAD") or os.environ.get("MGU_WINO_PREC"):
+        pytest.skip("an A/B of these switches: meaningless when one of them is forced for the whole run")
     x = torch.from_numpy(O.formula_normal("kw/x", (B, Cin, H, W), seed=H))
     w = torch.from_numpy(O.formula_uniform("kw/w", (Cout, Cin, 3, 3), -0.2, 0.2, seed=W))
     b = torch.zeros(Cout)
@@ -132,6 +136,8 @@ def test_winograd_three_piece_operand_modes(cuda, B, H, W, Cin, Cout, prec, monk
     """MGU_WINO_PREC=1/2 (read at mgu_create): every fp32 operand of the 16 Winograd GEMMs is split exactly into three
     bf16 pieces and multiplied on the bf16 MFMA with fp32 accumulation (csrc/wino_f32.hip PREC 1, csrc/wino_x3.hip).
     Same tolerance as the fp32-MFMA kernel: the six kept piece products lose less than one fp32 rounding."""
+    if os.environ.get("MGU_NO_WINOGRAD") or os.environ.get("MGU_WINO_PREC"):
+        pytest.skip("an A/B of these switches: meaningless when one of them is forced for the whole run")
     x = torch.from_numpy(O.formula_normal("k3/x", (B, Cin, H, W), seed=H))
     w = torch.from_numpy(O.formula_uniform("k3/w", (Cout, Cin, 3, 3), -0.2, 0.2, seed=W))
     b = torch.zeros(Cout)
