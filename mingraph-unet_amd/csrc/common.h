@@ -52,8 +52,8 @@ hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
 hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s);  // in / w / out point to bf16, sizes in elements
 // elementwise.hip: first convolution (<= 4 input channels on the packed NHWC4 input), VALU + scalar-cache weights
 hipError_t launch_pack_first_w(const float* w, float* wf, int Cout, int Cin, hipStream_t s);
-bool first_conv_applicable(int Cin, int Cp, int Cout, int ldout, int coff);
-hipError_t launch_first_conv(const float* in, const float* wf, const float* scale, const float* shift, float* out, int B, int H, int W,
+bool first_conv_applicable(int dtype, int Cin, int Cp, int Cout, int ldout, int coff);
+hipError_t launch_first_conv(int dtype, const void* in, const float* wf, const float* scale, const float* shift, void* out, int B, int H, int W,
                              int Cin, int Cout, int ldout, int coff, int relu, hipStream_t s);
 // wino_f32.hip: Winograd F(2x2,3x3) for fp32 3x3 layers with Cp % 16 == 0
 size_t wino_u_floats(int Cout, int Cp);

@@ -338,11 +338,14 @@ hipError_t launch_conv1x1_head(const void* in, int dtype, int ldin, int C, const
 // output channels: the nine taps are nine coalesced 16-byte loads, the weights are wave-uniform, so they arrive through
 // the scalar cache and every multiply-add is a VALU op with an SGPR operand -- no LDS, no barrier; the 128-byte channel
 // vector of the pixel is stored as NCO/4 16-byte pieces.  HBM-bound.
-template <int NCO, int CIN>
-__global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restrict__ in /*NHWC4*/, const float* __restrict__ wf /*[9][4][NCO]*/,
+// T = float: NHWC4 fp32 in, fp32 out.  T = __bf16 (bf16 storage mode): NHWC8 bf16 in (pack_input pads the 3 channels to one
+// 16-byte pixel), bf16 out (8 channels per 16-byte store); the weights stay fp32 scalars either way.
+template <typename T, int NCO, int CIN>
+__global__ __launch_bounds__(256) void conv3x3_first_kernel(const T* __restrict__ in, const float* __restrict__ wf /*[9][4][NCO]*/,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            float* __restrict__ out, int64_t npix, int H, int W, int ldout, int coff,
+                                                            T* __restrict__ out, int64_t npix, int H, int W, int ldout, int coff,
                                                             int relu) {
+  constexpr int LDI = sizeof(T) == 4 ? 4 : 8;   // elements per input pixel
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = p < npix;   // (lanes past the end still take part in the wave's LDS transpose)
   const int x = (int)(p % W);
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restr
   float acc[NCO];
 #pragma unroll
   for (int co = 0; co < NCO; ++co) acc[co] = 0.f;
-  const float* base = in + p * 4;
+  const T* base = in + p * LDI;
   // one tap per trip, NOT unrolled: unrolled, hipcc hoists all 9 * CIN * NCO scalar weight loads to the top and spills
   // hundreds of SGPRs through v_writelane/v_readlane
 #pragma unroll 1
@@ -358,8 +361,16 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restr
     const int r = tap / 3, sx = tap - 3 * r;
     const bool ok = live && (unsigned)(y + r - 1) < (unsigned)H && (unsigned)(x + sx - 1) < (unsigned)W;
     // unconditional load from a mapped address + select (a branch around a load serialises the batch)
-    const float4 v = *reinterpret_cast<const float4*>(ok ? base + ((r - 1) * W + (sx - 1)) * 4 : in);
-    const float vv[4] = {ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f};
+    const T* src = ok ? base + ((r - 1) * W + (sx - 1)) * LDI : in;
+    float vv[4];
+    if constexpr (sizeof(T) == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src);
+      vv[0] = ok ? v.x : 0.f, vv[1] = ok ? v.y : 0.f, vv[2] = ok ? v.z : 0.f, vv[3] = ok ? v.w : 0.f;
+    } else {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) vv[c] = ok ? (float)v[c] : 0.f;
+    }
     const float* wt = wf + tap * 4 * NCO;   // wave-uniform: scalar loads
 #pragma unroll
     for (int c = 0; c < CIN; ++c)
@@ -388,15 +399,24 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const float* __restr
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  constexpr int LPP = NCO / 4;            // lanes per pixel
+  constexpr int CPL = sizeof(T) == 4 ? 4 : 8;   // channels per 16-byte store
+  constexpr int LPP = NCO / CPL;          // lanes per pixel
   constexpr int PPI = 64 / LPP;           // pixels per store instruction
   const int64_t p0 = p - lane;            // first pixel of this wave (wave-uniform)
   const int qd = lane % LPP, pl = lane / LPP;
 #pragma unroll
   for (int k = 0; k < LPP; ++k) {
     const int px = pl + k * PPI;          // pixel of the wave this lane stores in pass k
-    const float4 t = *reinterpret_cast<const float4*>(slab + px * (NCO + 4) + 4 * qd);
-    if (p0 + px < npix) *reinterpret_cast<float4*>(out + (p0 + px) * ldout + coff + 4 * qd) = t;
+    const float4 t = *reinterpret_cast<const float4*>(slab + px * (NCO + 4) + CPL * qd);
+    if constexpr (sizeof(T) == 4) {
+      if (p0 + px < npix) *reinterpret_cast<float4*>(out + (p0 + px) * ldout + coff + 4 * qd) = t;
+    } else {
+      const float4 u = *reinterpret_cast<const float4*>(slab + px * (NCO + 4) + CPL * qd + 4);
+      bf16x8 o;
+      o[0] = (__bf16)t.x, o[1] = (__bf16)t.y, o[2] = (__bf16)t.z, o[3] = (__bf16)t.w;
+      o[4] = (__bf16)u.x, o[5] = (__bf16)u.y, o[6] = (__bf16)u.z, o[7] = (__bf16)u.w;
+      if (p0 + px < npix) *reinterpret_cast<bf16x8*>(out + (p0 + px) * ldout + coff + 8 * qd) = o;
+    }
   }
 }
 
@@ -413,26 +433,33 @@ hipError_t launch_pack_first_w(const float* w, float* wf, int Cout, int Cin, hip
   return hipGetLastError();
 }
 
-bool first_conv_applicable(int Cin, int Cp, int Cout, int ldout, int coff) {
-  return Cp == 4 && Cin >= 1 && Cin <= 4 && (Cout == 16 || Cout == 32 || Cout == 64) && (ldout % 4) == 0 && (coff % 4) == 0;
+bool first_conv_applicable(int dtype, int Cin, int Cp, int Cout, int ldout, int coff) {
+  const int v = dtype == 0 ? 4 : 8;   // channels per 16 bytes
+  return Cp == v && Cin >= 1 && Cin <= 4 && (Cout == 16 || Cout == 32 || Cout == 64) && (ldout % v) == 0 && (coff % v) == 0;
 }
 
-hipError_t launch_first_conv(const float* in, const float* wf, const float* scale, const float* shift, float* out, int B, int H, int W,
+hipError_t launch_first_conv(int dtype, const void* in, const float* wf, const float* scale, const float* shift, void* out, int B, int H, int W,
                              int Cin, int Cout, int ldout, int coff, int relu, hipStream_t s) {
   const int64_t npix = (int64_t)B * H * W;
   const dim3 grid((unsigned)((npix + 255) / 256)), block(256);
-#define MGU_FC(NCO, CIN) hipLaunchKernelGGL((conv3x3_first_kernel<NCO, CIN>), grid, block, 0, s, in, wf, scale, shift, out, npix, H, W, ldout, coff, relu)
-#define MGU_FC_CIN(NCO)            \
-  do {                             \
-    if (Cin == 1) MGU_FC(NCO, 1);  \
-    else if (Cin == 2) MGU_FC(NCO, 2); \
-    else if (Cin == 3) MGU_FC(NCO, 3); \
-    else MGU_FC(NCO, 4);           \
+#define MGU_FC(T, NCO, CIN) hipLaunchKernelGGL((conv3x3_first_kernel<T, NCO, CIN>), grid, block, 0, s, (const T*)in, wf, scale, shift, (T*)out, npix, H, W, ldout, coff, relu)
+#define MGU_FC_CIN(T, NCO)            \
+  do {                                \
+    if (Cin == 1) MGU_FC(T, NCO, 1);  \
+    else if (Cin == 2) MGU_FC(T, NCO, 2); \
+    else if (Cin == 3) MGU_FC(T, NCO, 3); \
+    else MGU_FC(T, NCO, 4);           \
   } while (0)
-  if (Cout == 16) MGU_FC_CIN(16);
-  else if (Cout == 32) MGU_FC_CIN(32);
-  else if (Cout == 64) MGU_FC_CIN(64);
-  else return hipErrorInvalidValue;
+#define MGU_FC_T(T)                   \
+  do {                                \
+    if (Cout == 16) MGU_FC_CIN(T, 16);      \
+    else if (Cout == 32) MGU_FC_CIN(T, 32); \
+    else if (Cout == 64) MGU_FC_CIN(T, 64); \
+    else return hipErrorInvalidValue; \
+  } while (0)
+  if (dtype == 0) MGU_FC_T(float);
+  else MGU_FC_T(__bf16);
+#undef MGU_FC_T
 #undef MGU_FC_CIN
 #undef MGU_FC
   return hipGetLastError();

@@ -163,7 +163,7 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     total += (size_t)L.Np * L.Kp + 2 * (size_t)L.Np + (L.bn.empty() ? 0 : 4 * (size_t)L.Np);
     L.wino = dtype == MGU_DTYPE_F32 && !L.convt && L.KS == 3 && L.Cp % 16 == 0;   // Winograd F(2x2,3x3) layers (wino_f32.hip)
     if (L.wino) total += wino_u_floats(L.Cout, L.Cp);
-    L.first = dtype == MGU_DTYPE_F32 && !L.convt && L.KS == 3 && first_conv_applicable(L.Cin, L.Cp, L.Cout, 4, 0);
+    L.first = !L.convt && L.KS == 3 && first_conv_applicable(dtype, L.Cin, L.Cp, L.Cout, 8, 0);
     if (L.first) total += 9 * 4 * (size_t)L.Cout;
   }
   // flat parameter order = the reference's named_parameters(): per ConvBlock conv1.{w,b}, conv2.{w,b},
@@ -349,10 +349,10 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
   d.Wout = Wout;
   if (pool_fused) *pool_fused = false;
   if (stat_fused) *stat_fused = false;
-  if (L.wf && c->dtype == MGU_DTYPE_F32 && ldin == 4 && first_conv_applicable(L.Cin, L.Cp, L.Cout, ldout, coff) &&
-      (int64_t)B * H * W * std::max(ldout, 4) < (1ll << 31)) {
+  if (L.wf && ldin == L.Cp && first_conv_applicable(c->dtype, L.Cin, L.Cp, L.Cout, ldout, coff) &&
+      (int64_t)B * H * W * std::max(ldout, 8) < (1ll << 31)) {
     ProfScope ps(c, s);
-    HIPCHK(c, launch_first_conv((const float*)in_v, L.wf, scale, shift, (float*)out_v, B, H, W, L.Cin, L.Cout, ldout, coff, relu, s));
+    HIPCHK(c, launch_first_conv(c->dtype, in_v, L.wf, scale, shift, out_v, B, H, W, L.Cin, L.Cout, ldout, coff, relu, s));
     return MGU_OK;
   }
   if (stat_slots && c->dtype == MGU_DTYPE_F32 && wino_applicable(d)) {   // the Winograd epilogue also accumulates sum z, sum z^2
