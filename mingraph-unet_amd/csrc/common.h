@@ -49,6 +49,7 @@ struct IgemmDesc {
 };
 
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
+bool halo_pool_fusable(const IgemmDesc& d, int dtype);   // the halo conv kernel will run: MaxPool2d(2) can ride in its epilogue
 hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s);  // in / w / out point to bf16, sizes in elements
 // elementwise.hip: first convolution (<= 4 input channels on the packed NHWC4 input), VALU + scalar-cache weights
 hipError_t launch_pack_first_w(const float* w, float* wf, int Cout, int Cin, hipStream_t s);

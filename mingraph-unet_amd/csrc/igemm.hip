@@ -484,6 +484,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
             const unsigned lane_idx = (unsigned)((y0 * d.W + x0 + 4 * lh) * d.ldout + n);
 #pragma unroll
             for (int mi = 0; mi < WMT; ++mi) {
+              float vv[16];
 #pragma unroll
               for (int rr = 0; rr < 16; ++rr) {
                 // pixel of this accumulator register inside the patch: pp = 32*(wm*WMT+mi) + 8*(rr>>2) + 4*lh + (rr&3)
@@ -491,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
                 const int pxc = 8 * ((rr >> 2) & 1) + (rr & 3);             // patch column (without the 4*lh part)
                 float v = acc[mi][ni][rr] * sc + sh;
                 if (d.relu) v = fmaxf(v, 0.f);
+                vv[rr] = v;
                 const unsigned idx = lane_idx + (unsigned)pyc * sA + (unsigned)pxc * sB;
                 if (!GUARDED) {
                   img_out[idx] = (T)v;
@@ -498,6 +500,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
                   img_out[idx] = (T)v;
                 }
                 acc[mi][ni][rr] = 0.f;
+              }
+              if (d.pool) {
+                // fused MaxPool2d(2): registers rr, rr^1 (x neighbour) and rr^8 (y neighbour) of a lane are one pooling
+                // window (patch origins are even), so the pooled tensor costs four max operations per window and no
+                // second pass over the feature map
+                T* const pool_img = reinterpret_cast<T*>(d.pool) + (size_t)img * (d.H >> 1) * (d.W >> 1) * d.ldpool;
+#pragma unroll
+                for (int a = 0; a < 8; a += 2) {   // rr with bit 0 and bit 3 clear: 0, 2, 4, 6
+                  const float m = fmaxf(fmaxf(vv[a], vv[a + 1]), fmaxf(vv[a + 8], vv[a + 9]));
+                  const int pyc = 2 * (wm * WMT + mi), pxc = 8 * ((a >> 2) & 1) + (a & 3) + 4 * lh;
+                  const int py = (y0 + pyc) >> 1, px = (x0 + pxc) >> 1;
+                  if (!GUARDED || (nvalid && y0 + pyc + 1 < d.H && x0 + pxc + 1 < d.W))
+                    pool_img[((size_t)py * (d.W >> 1) + px) * d.ldpool + n] = (T)m;
+                }
               }
             }
           }
@@ -571,6 +587,12 @@ static hipError_t launch_halo_tiles(const IgemmDesc& d, hipStream_t s) {
   if (d.N > 32) return launch_halo<T, NP, 16, 4, 1, 2, 2, 1>(d, s);    // 16x16 px x 64 ch,  wave 64x64
   if (g_halo_tps3) return launch_halo<T, NP, 16, 4, 1, 2, 1, 3>(d, s);  // 16x16 px x 32 ch, wave 64x32, 3 taps per barrier
   return launch_halo<T, NP, 16, 4, 1, 2, 1, 1>(d, s);
+}
+
+// does a descriptor run on the halo kernel (whose epilogue can also write the 2x2 max-pooled tensor, IgemmDesc::pool)?
+bool halo_pool_fusable(const IgemmDesc& d, int dtype) {
+  if (d.out_mode != 0 || d.split_n) return false;
+  return dtype == 0 ? (!wino_applicable(d) && halo_np<float>(d) == 8) : halo_np<__bf16>(d) != 0;
 }
 
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s) {

@@ -359,7 +359,8 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
     d.stat_slots = stat_slots;
     if (stat_fused) *stat_fused = true;
   }
-  if (pool && c->dtype == MGU_DTYPE_F32 && wino_applicable(d)) {   // the Winograd epilogue also writes the 2x2 max-pooled tensor
+  if (pool && ((c->dtype == MGU_DTYPE_F32 && wino_applicable(d)) || halo_pool_fusable(d, c->dtype))) {
+    // the Winograd / halo epilogue also writes the 2x2 max-pooled tensor
     d.pool = (float*)pool, d.ldpool = ldpool;
     if (pool_fused) *pool_fused = true;
   }
