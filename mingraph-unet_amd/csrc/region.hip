@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void region_fuse_kernel(const float* __restric
       const int lbl = hard[(size_t)b * nph * npw + py * npw + px];
       v = *reinterpret_cast<const f32x4r*>(emb + ((size_t)b * K + lbl) * D + (cq * 4 - Cu));
     }
-    *reinterpret_cast<f32x4r*>(out + pix * (Cu + D) + cq * 4) = v;
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4r*>(out + pix * (Cu + D) + cq * 4));   // write-once stream: keep it out of L2
   }
 }
 
