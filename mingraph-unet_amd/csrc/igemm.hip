@@ -22,9 +22,6 @@
 #include "common.h"
 #include <type_traits>
 
-#ifndef HALO_MIN_WAVES
-#define HALO_MIN_WAVES 3
-#endif
 namespace mgu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
