@@ -62,7 +62,9 @@ int64_t mgu_unet_param_count(mgu_ctx* ctx);
  * eval folds bias + BatchNorm running stats (unet_encoder.py:12-13, eps 1e-5) into a per-channel
  * scale/shift applied in the conv epilogue.  Must be re-called after the parameters change. */
 int mgu_unet_load_weights(mgu_ctx* ctx, const mgu_tensor_desc* named, int n, void* hip_stream);
-/* Bytes of library-owned scratch a forward of this shape uses (allocated on first use). */
+/* Bytes of library-owned scratch a forward of this shape uses (allocated on first use).  training = 1: the train-mode
+ * forward + backward scratch (every layer's pre-activation and activation, gradient temporaries, weight-gradient partial
+ * panels: about 1.9 GB at 4 x 3x512x512), a separate allocation from the eval scratch. */
 int mgu_unet_workspace_bytes(mgu_ctx* ctx, int B, int H, int W, int training, size_t* out);
 /* Pre-allocate that scratch (synchronous); forward does it lazily otherwise. */
 int mgu_unet_reserve(mgu_ctx* ctx, int B, int H, int W, int training);
@@ -88,6 +90,16 @@ int mgu_unet_forward(mgu_ctx* ctx, const void* x_dev, int B, int H, int W,
 int mgu_conv2d_nhwc(mgu_ctx* ctx, const void* in_dev, int B, int H, int W, int Cin, const void* w_oihw_dev,
                     const void* bias_dev, const void* scale_dev, const void* shift_dev, int Cout, int ksize,
                     int relu, void* out_dev, int ld_out, int c_off, void* hip_stream);
+/* Steady-state form of mgu_conv2d_nhwc: mgu_conv2d_nhwc repacks the OIHW weight into the kernels' panels (and the Winograd
+ * transform) on EVERY call; a caller whose weights are constant between calls (an eval-mode nn.Conv2d, e.g. the two
+ * convolutions of DetectionHead, detection_head.py:33,36) packs them once.  The handle is owned by the library and stays
+ * valid until mgu_conv2d_release; re-prepare after the weight tensor changes.  bias/scale/shift as for mgu_conv2d_nhwc. */
+typedef struct mgu_conv_weights mgu_conv_weights;
+int mgu_conv2d_prepare(mgu_ctx* ctx, const void* w_oihw_dev, int Cout, int Cin, int ksize, mgu_conv_weights** out, void* hip_stream);
+void mgu_conv2d_release(mgu_ctx* ctx, mgu_conv_weights* w);
+int mgu_conv2d_prepared_nhwc(mgu_ctx* ctx, const mgu_conv_weights* w, const void* in_dev, int B, int H, int W, const void* bias_dev,
+                             const void* scale_dev, const void* shift_dev, int relu, void* out_dev, int ld_out, int c_off,
+                             void* hip_stream);
 /* ConvTranspose2d(Cin, Cout, kernel_size=2, stride=2) + bias (unet_decoder.py:25,36); weight (Cin,Cout,2,2).
  * in (B,H,W,Cin) NHWC -> out (B,2H,2W,*) NHWC with pixel pitch ld_out, channels [c_off, c_off+Cout). */
 int mgu_conv_transpose2x2_nhwc(mgu_ctx* ctx, const void* in_dev, int B, int H, int W, int Cin, const void* w_iohw_dev,
@@ -108,12 +120,18 @@ int mgu_argmax_classes(mgu_ctx* ctx, const void* logits_dev, int64_t npix, int n
  * Offset (elements) of a parameter in the flat parameter/gradient vector; the order is the reference's
  * named_parameters() order.  name = state_dict key of a weight/bias; -1 if unknown. */
 int64_t mgu_unet_param_offset(mgu_ctx* ctx, const char* name);
-/* nn.CrossEntropyLoss() (mean reduction) forward + gradient (train_segmentation.py:91,127):
- * logits_dev (npix, C) NHWC fp32, labels_dev int64 (npix).  Writes *loss_dev = mean_i -log softmax(l_i)[y_i]
- * and dlogits_dev (npix, 4*ceil(C/4)) = grad_scale * (softmax - onehot), pad columns zero.
- * grad_scale = 1/npix reproduces loss.backward() of the mean loss. */
+/* nn.CrossEntropyLoss() (mean reduction, ignore_index = -100: torch's defaults) forward + gradient
+ * (train_segmentation.py:91,127): logits_dev (npix, C) NHWC fp32, labels_dev int64 (npix).
+ * Writes *loss_dev = mean over the counted pixels of -log softmax(l_i)[y_i] and dlogits_dev (npix, 4*ceil(C/4)) =
+ * grad_scale * npix/count * (softmax - onehot), pad columns zero: grad_scale = 1/npix reproduces loss.backward() of the
+ * mean loss.  A pixel labelled -100 is not counted and gets a zero gradient (torch semantics).  Any other label outside
+ * [0, C) is invalid DATA, which the host cannot see without a synchronisation: the label is never used as an index, the
+ * loss comes out NaN, and the NEXT mgu_cross_entropy / mgu_unet_backward / mgu_sync_check on this ctx that runs after the
+ * kernel has executed returns MGU_ERR_INVALID (torch raises IndexError / device-asserts at the same point). */
 int mgu_cross_entropy(mgu_ctx* ctx, const void* logits_dev, const int64_t* labels_dev, int64_t npix, int num_classes,
                       float grad_scale, void* dlogits_dev, float* loss_dev, void* hip_stream);
+/* Synchronise hip_stream and report invalid data met by kernels of this ctx since the last check (MGU_ERR_INVALID). */
+int mgu_sync_check(mgu_ctx* ctx, void* hip_stream);
 /* loss.backward() (train_segmentation.py:133) for the last mgu_unet_forward(training=1): dlogits_dev as
  * produced by mgu_cross_entropy; every element of flat_grad_dev (mgu_unet_param_count floats) is written. */
 int mgu_unet_backward(mgu_ctx* ctx, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream);
@@ -195,6 +213,9 @@ int mgu_channel_affine_nhwc(mgu_ctx* ctx, const float* x_dev, int ldx, int64_t M
                             const float* shift_dev, int act, float* y_dev, int ldy, void* hip_stream);
 /* out[c] = sum over the M rows of x[m][c]: AdaptiveAvgPool2d((1,1)) (:39) per image is this sum / (H W). 4 <= C <= 1024. */
 int mgu_channel_sum_nhwc(mgu_ctx* ctx, const float* x_dev, int ldx, int64_t M, int C, float* out_dev, void* hip_stream);
+
+/* out (B, C)[b] = column sums of image b of x (B, M, C) (row pitch ldx): AdaptiveAvgPool2d over a batch in one call. */
+int mgu_channel_sum_images_nhwc(mgu_ctx* ctx, const float* x_dev, int ldx, int B, int64_t M, int C, float* out_dev, void* hip_stream);
 
 /* ---- introspection for bench.py / profiles ------------------------------------------------------ */
 /* FLOPs (2*MAC, convolutions only) of one U-Net forward over B images: SURVEY 8d table. */

@@ -77,4 +77,17 @@ int mgu_channel_sum_nhwc(mgu_ctx* c, const float* x_dev, int ldx, int64_t M, int
   return MGU_OK;
 }
 
+// One sum per image: x (B, M, C) with row pitch ldx, out (B, C).  Each image's reduction fills the chip on its own (a 512^2
+// map is 2^18 rows), so the images are B back-to-back launches inside the library instead of B trips through the binding.
+int mgu_channel_sum_images_nhwc(mgu_ctx* c, const float* x_dev, int ldx, int B, int64_t M, int C, float* out_dev, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (B < 1) return fail(c, MGU_ERR_INVALID, "mgu_channel_sum_images_nhwc: B must be >= 1");
+  for (int b = 0; b < B; ++b) {
+    int rc = mgu_channel_sum_nhwc(c, x_dev ? x_dev + (size_t)b * M * ldx : nullptr, ldx, M, C, out_dev ? out_dev + (size_t)b * C : nullptr,
+                                  hip_stream);
+    if (rc) return rc;
+  }
+  return MGU_OK;
+}
+
 }  // extern "C"

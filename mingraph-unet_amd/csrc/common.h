@@ -15,7 +15,30 @@ namespace mgu {
 //             m = (img, y, x) over the INPUT grid H x W,
 //             -> out[((img*Hout + 2y+dy)*Wout + 2x+dx)*ldout + coff + co]
 // ---------------------------------------------------------------------------------------------
+// Kernel-selection switches of ONE context (mgu_ctx::tn, filled from the MGU_* environment in mgu_create).  They ride in
+// the launch descriptors, so two contexts of a process never see each other's settings.
+struct Tuning {
+  bool use_halo = true;     // MGU_NO_HALO=1: generic gather kernel instead of the LDS-halo conv kernel (A/B)
+  bool halo_tps3 = true;    // MGU_HALO_TPS1=1: one tap per barrier on the N <= 32 halo tile too (A/B)
+  int halo_max_ppb = 16;    // MGU_HALO_PPB=n: patches a halo workgroup walks (1 = no persistence)
+  bool use_wino = true;     // MGU_NO_WINOGRAD=1: direct kernels for the fp32 3x3 layers
+  int wino_mode = -1;       // MGU_WINO_MODE=1: force the 32-channel work split on every layer (A/B)
+  int wino_prec = 1;        // MGU_WINO_PREC: 1 = three exact bf16 pieces per fp32 operand on the bf16 MFMA (default),
+                            //                0 = fp32 MFMA operands
+  int wino_rounds = 1;      // MGU_WINO_ROUNDS / MGU_WINO_PPB_CAP: persistence of the Winograd workgroups
+  int wino_ppb_cap = 32;
+  bool wgrad_halo = true;   // MGU_NO_WGRAD_HALO=1
+  bool wino_wgrad = true;   // MGU_NO_WINO_WGRAD=1
+  bool wgrad_thin = true;   // MGU_NO_THIN_WGRAD=1
+  bool wino_dgrad = true;   // MGU_NO_WINO_DGRAD=1
+  bool gat_fused = true;    // MGU_NO_GAT_FUSED=1
+};
+const Tuning& default_tuning();
+// The >64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: set it once per (kernel, device).
+hipError_t ensure_dyn_lds(const void* func, size_t bytes, bool (&done)[64]);
+
 struct IgemmDesc {
+  const Tuning* tn;    // nullptr = default_tuning()
   const float* in;
   const float* w;
   const float* wu;     // optional: Winograd-transformed 3x3 weights (launch_pack_wino_w); enables wino_f32.hip
@@ -48,6 +71,7 @@ struct IgemmDesc {
   int ld2;
 };
 
+inline const Tuning& tun(const IgemmDesc& d) { return d.tn ? *d.tn : default_tuning(); }
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
 bool halo_pool_fusable(const IgemmDesc& d, int dtype);   // the halo conv kernel will run: MaxPool2d(2) can ride in its epilogue
 hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s);  // in / w / out point to bf16, sizes in elements
@@ -58,22 +82,13 @@ hipError_t launch_first_conv(int dtype, const void* in, const float* wf, const f
                              int Cin, int Cout, int ldout, int coff, int relu, hipStream_t s);
 // wino_f32.hip: Winograd F(2x2,3x3) for fp32 3x3 layers with Cp % 16 == 0
 size_t wino_u_floats(int Cout, int Cp);
-hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int Cp, int dgrad, hipStream_t s);
+hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int Cp, int dgrad, int prec, hipStream_t s);
 bool wino_applicable(const IgemmDesc& d);
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s);
-void set_use_wino(bool on);
-void set_wino_mode(int v);
-void set_wino_prec(int v);   // 0: fp32 MFMA operands, 1: three exact bf16 pieces per operand on the bf16 MFMA
-int wino_prec();
-bool wino_x3_applicable(const IgemmDesc& d);
-hipError_t launch_wino_x3(const IgemmDesc& d, hipStream_t s);   // wino_x3.hip: the four-wavefront three-piece kernel (prec 2)
-bool use_wino();
-void set_use_halo(bool on);
-void set_halo_max_ppb(int n);
-void set_halo_tps3(bool on);
 
 // wgrad_f32.hip:  Dw[n][k] += sum_m Z[m][n] * A(m,k)   (A = the forward kernels' im2col gather)
 struct WgradDesc {
+  const Tuning* tn;  // nullptr = default_tuning()
   const float* z;   // Z[m][n] at z[m*ldz + zoff + n]
   int ldz, zoff;
   const float* in;  // gather source (NHWC), channels [inoff, inoff+Cp) of a pixel with pitch ldin
@@ -89,16 +104,14 @@ struct WgradDesc {
   int groups;          // set by the launcher
   int rows_per_split;  // set by the launcher
 };
+inline const Tuning& tun(const WgradDesc& d) { return d.tn ? *d.tn : default_tuning(); }
 hipError_t launch_wgrad_f32(WgradDesc& d, hipStream_t s);
-void set_wgrad_halo(bool on);
 // wino_wgrad_f32.hip: Winograd F(3x3,2x2) weight gradient (Cp % 64 == 0, N % 64 == 0); same partial-panel output as the halo kernel
 bool wino_wgrad_applicable(const WgradDesc& d);
 hipError_t launch_wino_wgrad_f32(WgradDesc& d, hipStream_t s);
-void set_wino_wgrad(bool on);
 // wgrad_thin.hip: the first 3x3 conv (Cin 3) and the 1x1 head: HBM-bound streaming kernels, same partial-panel output
 bool wgrad_thin_applicable(const WgradDesc& d);
 hipError_t launch_wgrad_thin(WgradDesc& d, hipStream_t s);
-void set_wgrad_thin(bool on);
 
 // train_kernels.hip
 size_t chan_reduce_work_bytes(int Cmax);
@@ -121,8 +134,8 @@ hipError_t launch_colsum(const float* z, int ldz, int64_t M, int C, double* work
 hipError_t launch_maxpool2_bwd_add(const float* y, int ldy, const float* dpool, float* dskip, int ldd, int B, int H, int W,
                                    int C, hipStream_t s);
 hipError_t launch_zero_pad_region(float* buf, int ld, int coff, int C, int B, int H, int W, int h2, int w2, hipStream_t s);
-hipError_t launch_ce(const float* logits, const int64_t* labels, int64_t M, int C, float grad_scale, float* dlogits, int ldd,
-                     double* loss_sum, float* loss_out, hipStream_t s);
+hipError_t launch_ce(const float* logits, const int64_t* labels, int64_t M, int C, long long ignore_index, float grad_scale,
+                     float* dlogits, int ldd, double* acc, int* err_word, float* loss_out, hipStream_t s);
 hipError_t launch_pack_dgrad_w(const float* w, float* wp, int Cout, int Cin, int Cop, int KS, int Kp, hipStream_t s);
 hipError_t launch_pack_convt_dgrad_w(const float* w, float* wp, int Cin, int Cout, int Kp, hipStream_t s);
 hipError_t launch_unpack_conv_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cout, int Cin, int Cp, int KS,

@@ -43,9 +43,12 @@ struct Layer {
 
 struct mgu_ctx {
   int device = 0;
+  mgu::Tuning tn;           // kernel-selection switches of THIS context (MGU_* environment at mgu_create)
   std::string err;
   bool configured = false, loaded = false;
   bool fold_dirty = false;  // BN running stats / affine changed since the eval scale/shift were folded
+  int* err_word = nullptr;  // host-mapped word a kernel sets when it meets invalid DATA (e.g. a label out of range): read by
+                            // mgu_sync_check and, without a sync, at the entry of the next training call
   void* redws = nullptr;    // per-channel reduction slots (self-cleaning: zero between launches)
   size_t redws_bytes = 0;
   void* pm_out = nullptr;   // one-shot request (mgu_unet_request_patch_mean): patch means of decoder feature 0
@@ -150,6 +153,7 @@ int run_layer(mgu_ctx* c, const Layer& L, const void* in, int ldin, int B, int H
               double* stat_slots = nullptr, bool* stat_fused = nullptr);          // optional fused BatchNorm batch statistics
 
 // training path (mgunet_train.hip)
+size_t train_ws_bytes(const mgu_ctx* c, int B, int H, int W);
 int unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int64_t xs_w, int B, int H,
                        int W, float* logits, void* const* cat_dev, void* const* feat_dev, hipStream_t s);
 

@@ -20,6 +20,7 @@
 //     channel pitch/offset so encoder outputs and the pixel-shuffled ConvTranspose outputs land
 //     directly in the two halves of the decoder's concat buffer (torch.cat never materialises).
 #include "common.h"
+#include <algorithm>
 #include <type_traits>
 
 namespace mgu {
@@ -27,12 +28,22 @@ namespace mgu {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static bool g_use_halo = true;   // MGU_NO_HALO=1 forces the generic gather kernel (A/B comparisons)
-static bool g_halo_tps3 = true;   // MGU_HALO_TPS1=1: one tap per barrier on the N <= 32 tile too (A/B)
-void set_halo_tps3(bool on) { g_halo_tps3 = on; }
-static int g_halo_max_ppb = 16;  // MGU_HALO_PPB=n caps the patches a halo workgroup walks (1 = no persistence)
-void set_use_halo(bool on) { g_use_halo = on; }
-void set_halo_max_ppb(int n) { g_halo_max_ppb = n < 1 ? 1 : n; }
+const Tuning& default_tuning() {
+  static const Tuning t;
+  return t;
+}
+
+hipError_t ensure_dyn_lds(const void* func, size_t bytes, bool (&done)[64]) {
+  if (bytes <= 65536) return hipSuccess;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (done[dev]) return hipSuccess;
+  e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done[dev] = true;
+  return e;
+}
 
 // ---- element traits: the kernels are written once for fp32 (exact v_mfma_f32_32x32x2_f32) and bf16 storage with
 // fp32 accumulation (v_mfma_f32_32x32x16_bf16).  All staging moves raw 16-byte chunks (4 floats or 8 bf16); an LDS
@@ -539,15 +550,12 @@ static hipError_t launch_halo(const IgemmDesc& d, hipStream_t s) {
   // patches per workgroup: keep >= ~4 workgroups per CU in the grid (2 are resident), at most 16 patches each
   int ppb = (int)(((long)total * ntn) / (256 * 4));
   if (ppb < 1) ppb = 1;
-  if (ppb > g_halo_max_ppb) ppb = g_halo_max_ppb;
+  if (ppb > tun(d).halo_max_ppb) ppb = std::max(1, tun(d).halo_max_ppb);
   dim3 grid((total + ppb - 1) / ppb, ntn);
   const size_t lds = (size_t)(HP + 2 * TPS * BN) * (NP * 16 + 16);
-  static bool attr_set = false;
-  if (!attr_set && lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, NP, TH, WAVES_M, WAVES_N, WMT, WNT, TPS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static bool attr_done[64] = {};
+  hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, NP, TH, WAVES_M, WAVES_N, WMT, WNT, TPS>), lds, attr_done);
+  if (ae != hipSuccess) return ae;
   hipLaunchKernelGGL((conv3x3_halo_kernel<T, NP, TH, WAVES_M, WAVES_N, WMT, WNT, TPS>), grid, dim3(256), lds, s, d, tiles_x,
                      tiles_y, total, ppb);
   return hipGetLastError();
@@ -557,7 +565,7 @@ template <typename T>
 static int halo_np(const IgemmDesc& d) {   // 16-byte pieces per pixel chunk the halo kernel can use, 0 = not applicable
   constexpr int VEC = Elem<T>::VEC;
   if (!(d.KS == 3 && d.out_mode == 0 && d.K == 9 * d.Cp && d.ldin == d.Cp && (long)d.H * d.W * d.ldin < (1l << 31) &&
-        (long)d.H * d.W * d.ldout < (1l << 31) && g_use_halo))
+        (long)d.H * d.W * d.ldout < (1l << 31) && tun(d).use_halo))
     return 0;
   if (d.Cp % (8 * VEC) == 0) return 8;
   if (sizeof(T) == 2 && d.Cp % (4 * VEC) == 0) return 4;   // bf16 layers with 32 input channels
@@ -585,7 +593,7 @@ template <typename T, int NP>
 static hipError_t launch_halo_tiles(const IgemmDesc& d, hipStream_t s) {
   if (d.N > 64) return launch_halo<T, NP, 8, 2, 2, 2, 2, 1>(d, s);     // 8x16 px  x 128 ch, wave 64x64
   if (d.N > 32) return launch_halo<T, NP, 16, 4, 1, 2, 2, 1>(d, s);    // 16x16 px x 64 ch,  wave 64x64
-  if (g_halo_tps3) return launch_halo<T, NP, 16, 4, 1, 2, 1, 3>(d, s);  // 16x16 px x 32 ch, wave 64x32, 3 taps per barrier
+  if (tun(d).halo_tps3) return launch_halo<T, NP, 16, 4, 1, 2, 1, 3>(d, s);  // 16x16 px x 32 ch, wave 64x32, 3 taps per barrier
   return launch_halo<T, NP, 16, 4, 1, 2, 1, 1>(d, s);
 }
 

@@ -3,6 +3,8 @@
 // elementwise.hip or gat.hip.  No CPU fallback exists: without a HIP device every call fails.
 #include "ctx.h"
 
+#include <algorithm>
+
 using namespace mgu;
 using namespace mgud;
 
@@ -59,24 +61,23 @@ int mgu_create(int device_id, mgu_ctx** out) {
   if (e != hipSuccess) return fail(nullptr, MGU_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
   mgu_ctx* c = new mgu_ctx();
   c->device = device_id;
-  const char* nh = getenv("MGU_NO_HALO");
-  set_use_halo(!(nh && nh[0] == '1'));
-  const char* nw = getenv("MGU_NO_WGRAD_HALO");
-  set_wgrad_halo(!(nw && nw[0] == '1'));
-  const char* nwi = getenv("MGU_NO_WINOGRAD");
-  set_use_wino(!(nwi && nwi[0] == '1'));
-  const char* wmo = getenv("MGU_WINO_MODE");
-  set_wino_mode(wmo ? atoi(wmo) : -1);
-  const char* wpr = getenv("MGU_WINO_PREC");
-  set_wino_prec(wpr ? atoi(wpr) : 0);
-  const char* nww = getenv("MGU_NO_WINO_WGRAD");
-  set_wino_wgrad(!(nww && nww[0] == '1'));
-  const char* ntw = getenv("MGU_NO_THIN_WGRAD");
-  set_wgrad_thin(!(ntw && ntw[0] == '1'));
-  const char* t1 = getenv("MGU_HALO_TPS1");
-  set_halo_tps3(!(t1 && t1[0] == '1'));
-  const char* pp = getenv("MGU_HALO_PPB");
-  if (pp && atoi(pp) > 0) set_halo_max_ppb(atoi(pp));
+  // kernel-selection switches live in the context (no process globals: two contexts never see each other's settings)
+  auto flag = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
+  auto num = [](const char* name, int dflt) { const char* v = getenv(name); return v && v[0] ? atoi(v) : dflt; };
+  Tuning& t = c->tn;
+  t.use_halo = !flag("MGU_NO_HALO");
+  t.halo_tps3 = !flag("MGU_HALO_TPS1");
+  t.halo_max_ppb = std::max(1, num("MGU_HALO_PPB", t.halo_max_ppb));
+  t.use_wino = !flag("MGU_NO_WINOGRAD");
+  t.wino_mode = num("MGU_WINO_MODE", -1);
+  t.wino_prec = num("MGU_WINO_PREC", t.wino_prec) ? 1 : 0;
+  t.wino_rounds = std::max(1, num("MGU_WINO_ROUNDS", 1));
+  t.wino_ppb_cap = std::max(1, num("MGU_WINO_PPB_CAP", 32));
+  t.wgrad_halo = !flag("MGU_NO_WGRAD_HALO");
+  t.wino_wgrad = !flag("MGU_NO_WINO_WGRAD");
+  t.wgrad_thin = !flag("MGU_NO_THIN_WGRAD");
+  t.wino_dgrad = !flag("MGU_NO_WINO_DGRAD");
+  t.gat_fused = !flag("MGU_NO_GAT_FUSED");
   *out = c;
   return MGU_OK;
 }
@@ -92,6 +93,7 @@ void mgu_destroy(mgu_ctx* c) {
   if (c->redws) (void)hipFree(c->redws);
   if (c->wuws) (void)hipFree(c->wuws);
   if (c->ncws) (void)hipFree(c->ncws);
+  if (c->err_word) (void)hipHostFree(c->err_word);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   for (auto e : c->ev_total)
     if (e) (void)hipEventDestroy(e);
@@ -278,7 +280,7 @@ int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void*
       // a layer that runs as Winograd / first-conv reads wu / wf; its direct panel is packed lazily, only if a launch
       // ever falls back to the implicit-GEMM kernel (run_layer)
       L.wp_dirty = true;
-      if (L.wu) HIPCHK(c, launch_pack_wino_w(w, L.wu, L.Cout, L.Cin, L.Cp, 0, s));
+      if (L.wu) HIPCHK(c, launch_pack_wino_w(w, L.wu, L.Cout, L.Cin, L.Cp, 0, c->tn.wino_prec, s));
       if (!L.wu && !L.first) {
         HIPCHK(c, launch_pack_conv_w(w, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
         L.wp_dirty = false;
@@ -305,8 +307,9 @@ int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void*
 int mgu_unet_workspace_bytes(mgu_ctx* c, int B, int H, int W, int training, size_t* out) {
   if (!c || !out) return MGU_ERR_INVALID;
   if (!c->configured) return fail(c, MGU_ERR_STATE, "not configured");
-  (void)training;
-  *out = plan_ws(c, B, H, W).total;
+  // eval: packed input, one conv1 temp, pooled tensors, bottleneck; training: every layer's z / y kept for backward,
+  // gradient temporaries and the weight-gradient partial panels (mgunet_train.hip)
+  *out = training ? train_ws_bytes(c, B, H, W) : plan_ws(c, B, H, W).total;
   return MGU_OK;
 }
 
@@ -315,7 +318,7 @@ int mgu_unet_reserve(mgu_ctx* c, int B, int H, int W, int training) {
   int rc = mgu_unet_workspace_bytes(c, B, H, W, training, &need);
   if (rc) return rc;
   HIPCHK(c, hipSetDevice(c->device));
-  return ensure(c, &c->ws, &c->ws_bytes, need);
+  return training ? ensure(c, &c->tws, &c->tws_bytes, need) : ensure(c, &c->ws, &c->ws_bytes, need);
 }
 
 }  // extern "C"
@@ -325,6 +328,7 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
                     void* pool, int ldpool, bool* pool_fused, double* stat_slots, bool* stat_fused) {
   IgemmDesc d;
   memset(&d, 0, sizeof d);
+  d.tn = &c->tn;
   d.in = (const float*)in_v;   // element type follows c->dtype; the descriptor carries raw pointers
   d.w = L.wp;
   d.wu = L.wu;
@@ -521,6 +525,82 @@ static int block_scratch(mgu_ctx* c, int Np, int Kp, float** wp, float** scale, 
   return MGU_OK;
 }
 
+// Packed forms of one Conv2d weight (direct panel and, for fp32 3x3 layers with Cin % 16 == 0, the Winograd U), owned by the
+// library: built once by mgu_conv2d_prepare and reused by every mgu_conv2d_prepared_nhwc call until the weight changes.
+struct mgu_conv_weights {
+  int Cout = 0, Cin = 0, ksize = 0, K = 0, Kp = 0, Np = 0;
+  float *wp = nullptr, *wu = nullptr, *shift = nullptr;   // one allocation: [panel | bias-as-shift | U]
+};
+
+int mgu_conv2d_prepare(mgu_ctx* c, const void* w_dev, int Cout, int Cin, int ksize, mgu_conv_weights** out, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!w_dev || !out || Cout < 1 || (ksize != 1 && ksize != 3)) return fail(c, MGU_ERR_INVALID, "bad conv2d_prepare args (ksize must be 1 or 3)");
+  if (Cin < 4 || (Cin & 3)) return fail(c, MGU_ERR_INVALID, "conv2d needs Cin %% 4 == 0 (got %d)", Cin);
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  mgu_conv_weights* p = new mgu_conv_weights();
+  p->Cout = Cout, p->Cin = Cin, p->ksize = ksize;
+  p->K = ksize * ksize * Cin, p->Kp = rup(p->K, 32), p->Np = rup(Cout, 128);
+  const bool wino = ksize == 3 && Cin % 16 == 0 && c->tn.use_wino;
+  const size_t panel = (size_t)p->Np * p->Kp, total = panel + p->Np + (wino ? wino_u_floats(Cout, Cin) : 0);
+  hipError_t e = hipMalloc((void**)&p->wp, total * sizeof(float));
+  if (e != hipSuccess) {
+    delete p;
+    return fail(c, MGU_ERR_NOMEM, "hipMalloc(%zu) failed: %s", total * sizeof(float), hipGetErrorString(e));
+  }
+  p->shift = p->wp + panel;
+  e = hipMemsetAsync(p->wp, 0, (panel + p->Np) * sizeof(float), s);
+  if (e == hipSuccess) e = launch_pack_conv_w((const float*)w_dev, p->wp, 0, Cout, Cin, Cin, ksize, p->Kp, s);
+  if (e == hipSuccess && wino) {
+    p->wu = p->shift + p->Np;
+    e = launch_pack_wino_w((const float*)w_dev, p->wu, Cout, Cin, Cin, 0, c->tn.wino_prec, s);
+  }
+  if (e != hipSuccess) {
+    (void)hipFree(p->wp);
+    delete p;
+    return fail(c, MGU_ERR_HIP, "conv2d_prepare: %s", hipGetErrorString(e));
+  }
+  *out = p;
+  return MGU_OK;
+}
+
+void mgu_conv2d_release(mgu_ctx* c, mgu_conv_weights* p) {
+  if (!p) return;
+  if (c) (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();   // launches that read the panels may still be in flight
+  if (p->wp) (void)hipFree(p->wp);
+  delete p;
+}
+
+int mgu_conv2d_prepared_nhwc(mgu_ctx* c, const mgu_conv_weights* p, const void* in_dev, int B, int H, int W, const void* bias_dev,
+                             const void* scale_dev, const void* shift_dev, int relu, void* out_dev, int ld_out, int c_off,
+                             void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!p || !in_dev || !out_dev || B < 1 || H < 1 || W < 1) return fail(c, MGU_ERR_INVALID, "bad conv2d args");
+  if (ld_out < c_off + p->Cout) return fail(c, MGU_ERR_INVALID, "ld_out %d < c_off %d + Cout %d", ld_out, c_off, p->Cout);
+  if ((int64_t)B * H * W >= (1ll << 31)) return fail(c, MGU_ERR_INVALID, "B*H*W must be < 2^31");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  IgemmDesc d;
+  memset(&d, 0, sizeof d);
+  d.tn = &c->tn;
+  d.in = (const float*)in_dev, d.w = p->wp, d.wu = p->wu, d.out = (float*)out_dev;
+  d.M = B * H * W, d.H = H, d.W = W, d.Cp = p->Cin, d.ldin = p->Cin, d.KS = p->ksize, d.K = p->K, d.Kp = p->Kp;
+  d.N = p->Cout, d.ldout = ld_out, d.coff = c_off, d.relu = relu;
+  if (scale_dev && shift_dev) {  // y = scale*(conv) + shift, bias folded by the caller into shift
+    d.scale = (const float*)scale_dev;
+    d.shift = (const float*)shift_dev;
+  } else if (bias_dev) {
+    HIPCHK(c, launch_bias_tile((const float*)bias_dev, p->shift, p->Cout, 1, s));
+    d.shift = p->shift;
+  }
+  ProfScope ps(c, s);
+  HIPCHK(c, launch_igemm_f32(d, s));
+  return MGU_OK;
+}
+
+// One-shot form: packs the weight on EVERY call (parity tests, weights that change between calls); steady-state callers
+// use mgu_conv2d_prepare + mgu_conv2d_prepared_nhwc.
 int mgu_conv2d_nhwc(mgu_ctx* c, const void* in_dev, int B, int H, int W, int Cin, const void* w_dev, const void* bias_dev,
                     const void* scale_dev, const void* shift_dev, int Cout, int ksize, int relu, void* out_dev,
                     int ld_out, int c_off, void* hip_stream) {
@@ -539,13 +619,14 @@ int mgu_conv2d_nhwc(mgu_ctx* c, const void* in_dev, int B, int H, int W, int Cin
   int rc = block_scratch(c, L.Np, L.Kp, &L.wp, &sc, &sh, s);
   if (rc) return rc;
   HIPCHK(c, launch_pack_conv_w((const float*)w_dev, L.wp, 0, Cout, Cin, Cin, ksize, L.Kp, s));
-  if (ksize == 3 && Cin % 16 == 0 && use_wino()) {   // same routing as the model's layers: Winograd F(2x2,3x3)
+  if (ksize == 3 && Cin % 16 == 0 && c->tn.use_wino) {   // same routing as the model's layers: Winograd F(2x2,3x3)
     if ((rc = ensure(c, &c->wuws, &c->wuws_bytes, wino_u_floats(Cout, Cin) * sizeof(float)))) return rc;
     L.wu = (float*)c->wuws;
-    HIPCHK(c, launch_pack_wino_w((const float*)w_dev, L.wu, Cout, Cin, Cin, 0, s));
+    HIPCHK(c, launch_pack_wino_w((const float*)w_dev, L.wu, Cout, Cin, Cin, 0, c->tn.wino_prec, s));
   }
   IgemmDesc d;
   memset(&d, 0, sizeof d);
+  d.tn = &c->tn;
   d.in = (const float*)in_dev, d.w = L.wp, d.wu = L.wu, d.out = (float*)out_dev;
   d.M = B * H * W, d.H = H, d.W = W, d.Cp = Cin, d.ldin = Cin, d.KS = ksize, d.K = L.K, d.Kp = L.Kp;
   d.N = Cout, d.ldout = ld_out, d.coff = c_off, d.relu = relu;
@@ -577,6 +658,7 @@ int mgu_conv_transpose2x2_nhwc(mgu_ctx* c, const void* in_dev, int B, int H, int
   HIPCHK(c, launch_pack_convt_w((const float*)w_dev, wp, 0, Cin, Cout, Kp, s));
   IgemmDesc d;
   memset(&d, 0, sizeof d);
+  d.tn = &c->tn;
   d.in = (const float*)in_dev, d.w = wp, d.out = (float*)out_dev;
   d.M = B * H * W, d.H = H, d.W = W, d.Cp = Cin, d.ldin = Cin, d.KS = 1, d.K = Cin, d.Kp = Kp;
   d.N = N, d.ldout = ld_out, d.coff = c_off, d.out_mode = 1, d.ct_cout = Cout, d.Hout = 2 * H, d.Wout = 2 * W;
@@ -635,8 +717,7 @@ int mgu_gat_layer_forward(mgu_ctx* c, const void* X_dev, int N, int Fin, const i
   if (num_graphs < 1) num_graphs = 1;
   HIPCHK(c, hipSetDevice(c->device));
   hipStream_t s = (hipStream_t)hip_stream;
-  static const bool no_fused = getenv("MGU_NO_GAT_FUSED") != nullptr;   // A/B switch
-  if (!no_fused && gat_fused_applicable(Fin, heads, Fout_head, E)) {
+  if (c->tn.gat_fused && gat_fused_applicable(Fin, heads, Fout_head, E)) {
     // aggregate-first path (gat_fused.hip): no (N, heads*F') node table, the gather moves Fin floats per edge
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -689,6 +770,7 @@ int mgu_gat_layer_forward(mgu_ctx* c, const void* X_dev, int N, int Fin, const i
   HIPCHK(c, launch_gat_wa_rows((const float*)W_dev, (const float*)a_dev, wp, HF, heads, Fout_head, Fin, Kp, s));
   IgemmDesc d;
   memset(&d, 0, sizeof d);
+  d.tn = &c->tn;
   d.in = (const float*)X_dev;
   d.w = wp;
   d.out = Whp;
@@ -740,7 +822,7 @@ double mgu_unet_mfma_flops(mgu_ctx* c, int B, int H, int W) {
   std::vector<int> hs, wsz;
   level_dims(H, W, c->depth, hs, wsz);
   auto conv = [&](const Layer& L, int h, int w) {
-    if (L.wu && use_wino()) return 2.0 * ((h + 1) / 2) * ((w + 1) / 2) * 16.0 * L.Cp * L.Cout;   // per 2x2 tile: 16 products
+    if (L.wu && c->tn.use_wino) return 2.0 * ((h + 1) / 2) * ((w + 1) / 2) * 16.0 * L.Cp * L.Cout;   // per 2x2 tile: 16 products
     return 2.0 * h * w * 9.0 * L.Cin * L.Cout;
   };
   double fl = 0;

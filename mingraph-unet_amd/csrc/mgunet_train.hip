@@ -116,6 +116,7 @@ int conv_wgrad(Bwd& w, const Layer& L, const float* dz) {
   mgu_ctx* c = w.c;
   WgradDesc d;
   memset(&d, 0, sizeof d);
+  d.tn = &c->tn;
   d.z = dz, d.ldz = L.Cout, d.zoff = 0;
   d.in = L.t_in, d.ldin = L.t_ldin, d.inoff = 0, d.Cp = L.Cp;
   d.KS = L.KS;
@@ -138,16 +139,16 @@ int conv_dgrad(Bwd& w, const Layer& L, const float* dz, float* out, int ldout) {
   const int Kd = L.KS * L.KS * Cop, Kpd = rup(Kd, 32);
   IgemmDesc d;
   memset(&d, 0, sizeof d);
+  d.tn = &c->tn;
   d.in = dz, d.w = w.dgp, d.out = out;
   d.M = L.t_B * L.t_H * L.t_W, d.H = L.t_H, d.W = L.t_W;
   d.Cp = Cop, d.ldin = L.Cout == Cop ? L.Cout : Cop, d.KS = L.KS, d.K = Kd, d.Kp = Kpd;
   d.N = L.Cin, d.ldout = ldout;
-  static const bool no_wd = getenv("MGU_NO_WINO_DGRAD") != nullptr;   // A/B switch
-  if (!no_wd && L.wino && L.KS == 3 && Cop % 16 == 0 && use_wino()) {   // same Winograd kernel, weights flipped + transposed
+  if (c->tn.wino_dgrad && L.wino && L.KS == 3 && Cop % 16 == 0 && c->tn.use_wino) {   // same Winograd kernel, weights flipped + transposed
     d.wu = w.wug;
   }
   // only the weight form the chosen kernel reads is built: Winograd U or the direct flipped/transposed panel
-  if (wino_applicable(d)) HIPCHK(c, launch_pack_wino_w(L.w_src, w.wug, L.Cin, L.Cout, Cop, 1, w.s));
+  if (wino_applicable(d)) HIPCHK(c, launch_pack_wino_w(L.w_src, w.wug, L.Cin, L.Cout, Cop, 1, c->tn.wino_prec, w.s));
   else HIPCHK(c, launch_pack_dgrad_w(L.w_src, w.dgp, L.Cout, L.Cin, Cop, L.KS, Kpd, w.s));
   ProfScope ps(c, w.s);
   HIPCHK(c, launch_igemm_f32(d, w.s));
@@ -180,6 +181,8 @@ int block_backward(Bwd& w, const Layer& L1, const Layer& L2, const float* dy, in
 }
 
 }  // namespace
+
+size_t mgud::train_ws_bytes(const mgu_ctx* c, int B, int H, int W) { return plan_train(c, B, H, W).total; }
 
 int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int64_t xs_w, int B,
                              int H, int W, float* logits, void* const* cat_dev, void* const* feat_dev, hipStream_t s) {
@@ -252,18 +255,41 @@ int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t x
 
 extern "C" {
 
+// invalid data seen by an EARLIER kernel of this context (the word is host-mapped: no synchronisation needed to read it)
+static int pending_data_error(mgu_ctx* c) {
+  if (c->err_word && *(volatile int*)c->err_word) {
+    *(volatile int*)c->err_word = 0;
+    return fail(c, MGU_ERR_INVALID, "a label outside [0, num_classes) (and != ignore_index -100) reached mgu_cross_entropy");
+  }
+  return MGU_OK;
+}
+
 int mgu_cross_entropy(mgu_ctx* c, const void* logits_dev, const int64_t* labels_dev, int64_t npix, int num_classes,
                       float grad_scale, void* dlogits_dev, float* loss_dev, void* hip_stream) {
   if (!c) return MGU_ERR_INVALID;
   if (!logits_dev || !labels_dev || !dlogits_dev || !loss_dev || npix < 1 || num_classes < 1)
     return fail(c, MGU_ERR_INVALID, "bad cross_entropy args");
   HIPCHK(c, hipSetDevice(c->device));
-  hipStream_t s = (hipStream_t)hip_stream;
-  int rc = ensure(c, &c->gws, &c->gws_bytes, 256);
+  int rc = pending_data_error(c);
   if (rc) return rc;
-  HIPCHK(c, launch_ce((const float*)logits_dev, labels_dev, npix, num_classes, grad_scale, (float*)dlogits_dev,
-                      rup(num_classes, 4), (double*)c->gws, loss_dev, s));
+  hipStream_t s = (hipStream_t)hip_stream;
+  if ((rc = ensure(c, &c->gws, &c->gws_bytes, 256))) return rc;
+  if (!c->err_word) {
+    HIPCHK(c, hipHostMalloc((void**)&c->err_word, sizeof(int), hipHostMallocMapped));
+    *c->err_word = 0;
+  }
+  int* err_dev = nullptr;
+  HIPCHK(c, hipHostGetDevicePointer((void**)&err_dev, c->err_word, 0));
+  HIPCHK(c, launch_ce((const float*)logits_dev, labels_dev, npix, num_classes, -100 /* nn.CrossEntropyLoss default */, grad_scale,
+                      (float*)dlogits_dev, rup(num_classes, 4), (double*)c->gws, err_dev, loss_dev, s));
   return MGU_OK;
+}
+
+int mgu_sync_check(mgu_ctx* c, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize((hipStream_t)hip_stream));
+  return pending_data_error(c);
 }
 
 int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream) {
@@ -271,6 +297,10 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
   if (!c->have_train_fwd) return fail(c, MGU_ERR_STATE, "mgu_unet_backward needs a preceding mgu_unet_forward(training=1)");
   if (!dlogits_dev || !flat_grad_dev) return fail(c, MGU_ERR_INVALID, "NULL buffer");
   HIPCHK(c, hipSetDevice(c->device));
+  {
+    int prc = pending_data_error(c);
+    if (prc) return prc;
+  }
   hipStream_t s = (hipStream_t)hip_stream;
   const int d = c->depth, B = c->tB, H = c->tH, W = c->tW;
   const TPlan p = plan_train(c, B, H, W);
@@ -298,6 +328,7 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
   {
     WgradDesc g;
     memset(&g, 0, sizeof g);
+    g.tn = &c->tn;
     g.z = dlog, g.ldz = ldd, g.in = F.t_in, g.ldin = F.t_ldin, g.Cp = C0, g.KS = 1;
     g.M = (int)M0, g.H = H, g.W = W, g.N = ldd, g.K = C0, g.Kp = F.Kp, g.dw = w.dwp, g.dw_capacity = w.dwp_floats;
     HIPCHK(c, launch_wgrad_f32(g, s));
@@ -306,6 +337,7 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
     HIPCHK(c, launch_pack_dgrad_w(F.w_src, w.dgp, c->ncls, C0, ldd, 1, Kpd, s));
     IgemmDesc q;
     memset(&q, 0, sizeof q);
+    q.tn = &c->tn;
     q.in = dlog, q.w = w.dgp, q.out = tc, q.M = (int)M0, q.H = H, q.W = W, q.Cp = ldd, q.ldin = ldd, q.KS = 1, q.K = ldd,
     q.Kp = Kpd, q.N = C0, q.ldout = C0;
     HIPCHK(c, launch_igemm_f32(q, s));
@@ -328,6 +360,7 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
     {
       WgradDesc g;
       memset(&g, 0, sizeof g);
+    g.tn = &c->tn;
       g.z = U.t_in, g.ldz = U.t_ldin, g.in = dcat, g.ldin = 2 * C, g.inoff = C, g.Cp = C, g.KS = 2;
       g.M = U.t_B * U.t_H * U.t_W, g.H = U.t_H, g.W = U.t_W, g.Hs = hs[i], g.Ws = ws[i];
       g.N = U.Cin, g.K = Kt, g.Kp = Kpt, g.dw = w.dwp, g.dw_capacity = w.dwp_floats;
@@ -337,6 +370,7 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
     HIPCHK(c, launch_pack_convt_dgrad_w(U.w_src, w.dgp, U.Cin, C, Kpt, s));
     IgemmDesc q;
     memset(&q, 0, sizeof q);
+    q.tn = &c->tn;
     q.in = dcat + C, q.w = w.dgp, q.out = tc, q.M = U.t_B * U.t_H * U.t_W, q.H = U.t_H, q.W = U.t_W, q.Cp = C, q.ldin = 2 * C;
     q.KS = 2, q.K = Kt, q.Kp = Kpt, q.N = U.Cin, q.ldout = U.Cin, q.Hout = hs[i], q.Wout = ws[i];
     HIPCHK(c, launch_igemm_f32(q, s));

@@ -330,27 +330,56 @@ hipError_t launch_zero_pad_region(float* buf, int ld, int coff, int C, int B, in
   return hipGetLastError();
 }
 
-// ---- nn.CrossEntropyLoss (mean) forward + gradient w.r.t. logits (train_segmentation.py:91,127) --------
-// logits NHWC (M, C); labels int64 (M); dlogits written with pitch ldd >= C (pad columns zeroed),
-// scaled by grad_scale (= 1/M for the mean reduction); loss_sum accumulates sum_i -log p_i[y_i] in double.
+// ---- nn.CrossEntropyLoss (mean, ignore_index = -100) forward + gradient w.r.t. logits (train_segmentation.py:91,127) ----
+// logits NHWC (M, C); labels int64 (M); dlogits written with pitch ldd >= C (pad columns zeroed).
+// torch semantics: a pixel whose label is ignore_index contributes nothing to the loss, gets a zero gradient and is left
+// out of the mean's denominator; any other label outside [0, C) is an error (torch raises / device-asserts): here it is
+// never used as an index, the pixel gets a zero gradient, the loss becomes NaN and *err_word (host-visible) is set.
+//   acc[0] = sum_i -log p_i[y_i] (double), acc[1] = number of counted pixels (double)
+__global__ __launch_bounds__(256) void ce_count_kernel(const int64_t* __restrict__ labels, int64_t M, int C, long long ignore_index,
+                                                       double* __restrict__ acc, int* __restrict__ err_word) {
+  __shared__ int red[256];
+  int local = 0, bad = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    const long long y = labels[i];
+    if (y == ignore_index) continue;
+    if (y < 0 || y >= C) bad = 1;
+    else ++local;
+  }
+  if (bad && err_word) atomicOr(err_word, 1);
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && red[0]) atomicAdd(acc + 1, (double)red[0]);
+}
+
 __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                         int64_t M, int C, float grad_scale, float* __restrict__ dlogits,
-                                                         int ldd, double* __restrict__ loss_sum) {
+                                                         int64_t M, int C, long long ignore_index, float grad_scale,
+                                                         float* __restrict__ dlogits, int ldd, double* __restrict__ acc) {
   __shared__ double red[256];
   double local = 0.0;
+  // grad_scale = 1/M reproduces loss.backward() of the mean loss: with ignored pixels the mean runs over `count`
+  const double count = acc[1];
+  const float gs = count > 0.0 ? (float)((double)grad_scale * (double)M / count) : 0.f;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     const float* p = logits + i * C;
+    const long long yl = labels[i];
+    const bool counted = yl >= 0 && yl < C;        // ignore_index and invalid labels: zero gradient
+    const int y = counted ? (int)yl : 0;
     float mx = p[0];
     for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += expf(p[c] - mx);
     const float lse = mx + logf(se);
-    const int y = (int)labels[i];
-    local += (double)(lse - p[y]);
+    if (counted) local += (double)(lse - p[y]);
+    else if (yl != ignore_index) local += (double)__builtin_nanf("");   // out-of-range label: the loss says so
     const float inv = 1.f / se;
     for (int c = 0; c < ldd; ++c) {
       float g = 0.f;
-      if (c < C) g = (expf(p[c] - mx) * inv - (c == y ? 1.f : 0.f)) * grad_scale;
+      if (c < C && counted) g = (expf(p[c] - mx) * inv - (c == y ? 1.f : 0.f)) * gs;
       dlogits[i * ldd + c] = g;
     }
   }
@@ -360,18 +389,20 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
     if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(loss_sum, red[0]);
+  if (threadIdx.x == 0) atomicAdd(acc, red[0]);
 }
 
-__global__ void ce_finalize_kernel(const double* loss_sum, double M, float* loss_out) { *loss_out = (float)(*loss_sum / M); }
+// mean over the counted pixels; 0 counted pixels -> NaN, as torch's 0/0
+__global__ void ce_finalize_kernel(const double* acc, float* loss_out) { *loss_out = (float)(acc[0] / acc[1]); }
 
-hipError_t launch_ce(const float* logits, const int64_t* labels, int64_t M, int C, float grad_scale, float* dlogits, int ldd,
-                     double* loss_sum, float* loss_out, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
+hipError_t launch_ce(const float* logits, const int64_t* labels, int64_t M, int C, long long ignore_index, float grad_scale,
+                     float* dlogits, int ldd, double* acc, int* err_word, float* loss_out, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(nblk(M, 256, 2048)), dim3(256), 0, s, logits, labels, M, C, grad_scale, dlogits,
-                     ldd, loss_sum);
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, s, loss_sum, (double)M, loss_out);
+  hipLaunchKernelGGL(ce_count_kernel, dim3(nblk(M, 256, 1024)), dim3(256), 0, s, labels, M, C, ignore_index, acc, err_word);
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(nblk(M, 256, 2048)), dim3(256), 0, s, logits, labels, M, C, ignore_index, grad_scale,
+                     dlogits, ldd, acc);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, s, acc, loss_out);
   return hipGetLastError();
 }
 

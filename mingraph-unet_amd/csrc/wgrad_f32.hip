@@ -346,8 +346,6 @@ static hipError_t launch_wg_halo(WgradDesc& d, hipStream_t s) {
   return hipGetLastError();
 }
 
-static bool g_wgrad_halo = true;   // MGU_NO_WGRAD_HALO=1: always use the generic kernel (A/B)
-void set_wgrad_halo(bool on) { g_wgrad_halo = on; }
 
 hipError_t launch_wgrad_f32(WgradDesc& d, hipStream_t s) {
   d.groups = 1;   // atomic paths accumulate into ONE panel, which the caller must have zeroed
@@ -356,7 +354,7 @@ hipError_t launch_wgrad_f32(WgradDesc& d, hipStream_t s) {
     return hipErrorInvalidValue;
   if (wgrad_thin_applicable(d)) return launch_wgrad_thin(d, s);       // first conv / 1x1 head: streaming kernels (wgrad_thin.hip)
   if (wino_wgrad_applicable(d)) return launch_wino_wgrad_f32(d, s);   // F(3x3,2x2): 2.25x fewer multiplies (wino_wgrad_f32.hip)
-  if (g_wgrad_halo && d.KS == 3 && d.Cp % 32 == 0 && d.N % 32 == 0 && d.K == 9 * d.Cp &&
+  if (tun(d).wgrad_halo && d.KS == 3 && d.Cp % 32 == 0 && d.N % 32 == 0 && d.K == 9 * d.Cp &&
       (long)d.H * d.W * d.ldin < (1l << 31) && (long)d.H * d.W * d.ldz < (1l << 31) &&
       d.dw_capacity >= (size_t)d.N * d.Kp) {
     if (d.N % 64 == 0) return launch_wg_halo<2>(d, s);

@@ -121,11 +121,9 @@ __global__ __launch_bounds__(256) void wgrad_first_kernel(const float* __restric
   }
 }
 
-static bool g_wgrad_thin = true;   // MGU_NO_THIN_WGRAD=1: generic MFMA tile kernel for these two layers (A/B)
-void set_wgrad_thin(bool on) { g_wgrad_thin = on; }
 
 bool wgrad_thin_applicable(const WgradDesc& d) {
-  if (!g_wgrad_thin || d.M < 4096 || (d.ldz & 3) || (d.zoff & 3) || (d.ldin & 3) || (d.inoff & 3)) return false;
+  if (!tun(d).wgrad_thin || d.M < 4096 || (d.ldz & 3) || (d.zoff & 3) || (d.ldin & 3) || (d.inoff & 3)) return false;
   if (d.KS == 1 && d.N == 4 && (d.Cp == 32 || d.Cp == 64) && d.K == d.Cp) return true;
   if (d.KS == 3 && d.N == 32 && d.Cp == 4 && d.K == 36 && d.M == (d.M / (d.H * d.W)) * d.H * d.W) return true;
   return false;

@@ -25,6 +25,7 @@
 //   * inverse transform: each wave folds its own row (M[i][.] A) in registers, the four row waves meet through a
 //     small LDS exchange, and lanes store one channel each (32 lanes = one 128-byte line of a pixel).
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -63,10 +64,6 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const 
 // needs; the "memory" clobber keeps the compiler from moving LDS accesses across it.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-static bool g_use_wino = true;   // MGU_NO_WINOGRAD=1: direct (halo implicit-GEMM) kernels only
-void set_use_wino(bool on) { g_use_wino = on; }
-bool use_wino() { return g_use_wino; }
-
 // Operand precision of the 16 GEMMs (PREC):
 //   0: v_mfma_f32_32x32x2_f32 on the fp32 operands;
 //   1: every fp32 operand is split EXACTLY into three bf16 pieces (8 + 8 + 8 mantissa bits, by truncation:
@@ -77,9 +74,7 @@ bool use_wino() { return g_use_wino; }
 //      K = 16 (6 x 32 cycles) against 8 fp32 MFMAs of K = 2 (8 x 64 cycles) -- and, measured (tools/ubench/
 //      mfma_valu.hip), the fp32 MFMA blocks the VALU while it runs whereas the bf16 MFMA does not, so the input
 //      transform hides under the matrix pipe here.
-static int g_wino_prec = 0;
-void set_wino_prec(int v) { g_wino_prec = v; }
-int wino_prec() { return g_wino_prec; }
+// (Tuning::wino_prec; the packed U layout follows it, so launch_pack_wino_w takes the same value.)
 
 // U[ntile][cin/8][i*4+j][lane (h = lane>>5, r = lane&31)][t]  =  (G g G^T)[i][j]  of  cout = 32*ntile + r,
 // cin = 8*(cin/8) + 4*h + t.   dgrad = 1: the data-gradient conv, g'[u][v] = w[c][n][2-u][2-v] (roles swapped).
@@ -149,12 +144,12 @@ __global__ void pack_wino_w_kernel(const float* __restrict__ w, float* __restric
 // n tiles padded to pairs; 6 bytes per value in the three-piece layout (sized for either)
 size_t wino_u_floats(int Cout, int Cp) { return (size_t)((Cout + 63) / 64 * 64) * Cp * 24; }
 
-hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int Cp, int dgrad, hipStream_t s) {
-  if (Cp & (g_wino_prec ? 15 : 7)) return hipErrorInvalidValue;
+hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int Cp, int dgrad, int prec, hipStream_t s) {
+  if (Cp & (prec ? 15 : 7)) return hipErrorInvalidValue;
   const int Np = (Cout + 63) / 64 * 64;
   int64_t blocks = ((int64_t)Np * Cp + 255) / 256;
   if (blocks > 65535) blocks = 65535;
-  hipLaunchKernelGGL(pack_wino_w_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, U, Cout, Cin, Cp, Np, dgrad, g_wino_prec);
+  hipLaunchKernelGGL(pack_wino_w_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w, U, Cout, Cin, Cp, Np, dgrad, prec);
   return hipGetLastError();
 }
 
@@ -644,9 +639,6 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   }
 }
 
-static int g_wino_mode = -1;   // MGU_WINO_MODE=1: force work split 1 on every layer (A/B); default: 0 for N > 32
-void set_wino_mode(int v) { g_wino_mode = v; }
-
 template <int MODE, int PREC>
 static hipError_t launch_wino_mode(const IgemmDesc& d, hipStream_t s) {
   constexpr int NTB = MODE == 0 ? 2 : 1, NWAVES = 8;
@@ -655,8 +647,7 @@ static hipError_t launch_wino_mode(const IgemmDesc& d, hipStream_t s) {
   const int total = tiles_x * tiles_y * B, nblk = (d.N + 32 * NTB - 1) / (32 * NTB);
   // one workgroup per CU is resident: ONE round of them, each walking up to 32 patches (measured against 2-4 rounds of
   // shorter walks: fewer pipeline prologues and no second-round tail, 0.7 % of the headline step)
-  static const int rounds = getenv("MGU_WINO_ROUNDS") ? atoi(getenv("MGU_WINO_ROUNDS")) : 1;
-  static const int cap = getenv("MGU_WINO_PPB_CAP") ? atoi(getenv("MGU_WINO_PPB_CAP")) : 32;
+  const int rounds = std::max(1, tun(d).wino_rounds), cap = std::max(1, tun(d).wino_ppb_cap);
   int ppb = (int)(((long)total * nblk) / (256 * rounds));
   if (ppb < 1) ppb = 1;
   if (ppb > cap) ppb = cap;
@@ -666,26 +657,22 @@ static hipError_t launch_wino_mode(const IgemmDesc& d, hipStream_t s) {
   constexpr int HSTRIDE = NWAVES * 16, HR = (340 + HSTRIDE - 1) / HSTRIDE;
   constexpr int RAWF = HR * HSTRIDE / 34 * 34 * 20 + 34 * 20;   // must match the kernel
   const size_t lds = (size_t)(2 * RAWF + 4 * 64 * (32 * NTB + 8)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino3x3_f32_kernel<MODE, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
+  static bool attr_done[64] = {};
+  hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&wino3x3_f32_kernel<MODE, PREC>), lds, attr_done);
+  if (ae != hipSuccess) return ae;
   hipLaunchKernelGGL((wino3x3_f32_kernel<MODE, PREC>), grid, dim3(64 * NWAVES), lds, s, d, tiles_x, tiles_y, total, ppb, ngroups,
                      ngroups * nblk, per_xcd);
   return hipGetLastError();
 }
 
 bool wino_applicable(const IgemmDesc& d) {
-  return g_use_wino && d.wu && d.KS == 3 && d.out_mode == 0 && d.split_n == 0 && (d.Cp % 16) == 0 && d.K == 9 * d.Cp &&
+  return tun(d).use_wino && d.wu && d.KS == 3 && d.out_mode == 0 && d.split_n == 0 && (d.Cp % 16) == 0 && d.K == 9 * d.Cp &&
          (d.ldin & 3) == 0 && (long)d.H * d.W * d.ldin < (1l << 31) && (long)d.H * d.W * d.ldout < (1l << 31);
 }
 
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
-  const bool wide = d.N > 32 && g_wino_mode != 1;
-  if (g_wino_prec == 2 && wino_x3_applicable(d)) return launch_wino_x3(d, s);
-  if (g_wino_prec) return wide ? launch_wino_mode<0, 1>(d, s) : launch_wino_mode<1, 1>(d, s);
+  const bool wide = d.N > 32 && tun(d).wino_mode != 1;
+  if (tun(d).wino_prec) return wide ? launch_wino_mode<0, 1>(d, s) : launch_wino_mode<1, 1>(d, s);
   return wide ? launch_wino_mode<0, 0>(d, s) : launch_wino_mode<1, 0>(d, s);
 }
 

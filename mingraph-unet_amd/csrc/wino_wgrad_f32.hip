@@ -31,8 +31,6 @@ namespace mgu {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static bool g_wino_wgrad = true;   // MGU_NO_WINO_WGRAD=1: direct weight-gradient kernels only (A/B)
-void set_wino_wgrad(bool on) { g_wino_wgrad = on; }
 
 __device__ __forceinline__ void ww_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -189,7 +187,7 @@ __global__ __launch_bounds__(256 * CI_T) void wino_wgrad_f32_kernel(const WgradD
 }
 
 bool wino_wgrad_applicable(const WgradDesc& d) {
-  return g_wino_wgrad && d.KS == 3 && d.Cp % 32 == 0 && d.N % 32 == 0 && d.K == 9 * d.Cp && (d.ldin & 3) == 0 && (d.ldz & 3) == 0 &&
+  return tun(d).wino_wgrad && d.KS == 3 && d.Cp % 32 == 0 && d.N % 32 == 0 && d.K == 9 * d.Cp && (d.ldin & 3) == 0 && (d.ldz & 3) == 0 &&
          (d.inoff & 3) == 0 && (d.zoff & 3) == 0 && (long)d.H * d.W * d.ldin < (1l << 31) && (long)d.H * d.W * d.ldz < (1l << 31) &&
          d.dw_capacity >= (size_t)d.N * d.Kp;
 }
@@ -210,12 +208,9 @@ static hipError_t launch_ww(WgradDesc& d, hipStream_t s) {
   groups = (total + ppb - 1) / ppb;   // every group has >= 1 patch: every partial panel is fully written
   d.groups = groups;
   const size_t lds = (size_t)((8 + 2) * 18 * (32 * CI_T + 16) + 8 * 16 * (32 * CO_T + 16)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_f32_kernel<CO_T, CI_T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
+  static bool attr_done[64] = {};
+  hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&wino_wgrad_f32_kernel<CO_T, CI_T>), lds, attr_done);
+  if (ae != hipSuccess) return ae;
   hipLaunchKernelGGL((wino_wgrad_f32_kernel<CO_T, CI_T>), dim3(groups, nci * nco), dim3(256 * CI_T), lds, s, d, tiles_x, tiles_y, total,
                      ppb, nci);
   return hipGetLastError();

@@ -36,6 +36,68 @@ class DetectionHead(nn.Module):
         if num_classes > 1:
             self.fc_class_scores = nn.Linear(fc_hidden_dim // 2, num_classes)  # :65-66
 
+    # ---- packed weights: built once per (device, parameter versions), not per forward ------------------------------------
+    def _prepared(self, ctx, dev):
+        """Everything the forward derives from the parameters alone: the two convolutions' packed panels / Winograd
+        transforms (mgu_conv2d_prepare), the BatchNorm affines, the stacked output heads.  Rebuilt only when a parameter or
+        buffer has been modified (tensor._version) or the module moved to another device."""
+        tensors = list(self.parameters()) + list(self.buffers())
+        key = (str(dev), tuple((t.data_ptr(), t._version) for t in tensors))
+        cache = self.__dict__.get("_mgu_prepared")
+        if cache is not None and cache["key"] == key:
+            return cache
+        if cache is not None:
+            for h in cache["handles"]:
+                _lib.lib().mgu_conv2d_release(cache["ctx"].handle, h)
+        L = _lib.lib()
+        stream = _lib.current_stream_ptr(dev)
+        out = {"key": key, "ctx": ctx, "handles": []}
+
+        def prep(conv):
+            import ctypes as C
+            w = conv.weight.detach().contiguous()
+            h = C.c_void_p()
+            _lib.check(L.mgu_conv2d_prepare(ctx.handle, w.data_ptr(), w.shape[0], w.shape[1], w.shape[2], C.byref(h), stream), ctx.handle)
+            out["handles"].append(h)
+            return h, conv.bias.detach().contiguous(), w.shape[0]
+
+        if not self.input_is_flat:
+            cb = self.conv_block
+            out["conv1"], out["conv2"] = prep(cb[0]), prep(cb[3])
+            out["bn1"], out["bn2"] = self._bn_affine(cb[2]), self._bn_affine(cb[5])
+        ws, bs = [self.fc_bbox.weight, self.fc_confidence.weight], [self.fc_bbox.bias, self.fc_confidence.bias]
+        if self.num_classes > 1:
+            ws.append(self.fc_class_scores.weight)
+            bs.append(self.fc_class_scores.bias)
+        wo, bo = torch.cat(ws, 0).detach().contiguous(), torch.cat(bs, 0).detach().contiguous()
+        pad = (-wo.shape[0]) % 4
+        if pad:
+            wo = torch.cat([wo, torch.zeros(pad, wo.shape[1], device=dev)], 0)
+            bo = torch.cat([bo, torch.zeros(pad, device=dev)], 0)
+        out["heads"] = (wo.contiguous(), bo.contiguous())
+        self.__dict__["_mgu_prepared"] = out
+        return out
+
+    def __del__(self):
+        try:
+            cache = self.__dict__.get("_mgu_prepared")
+            if cache:
+                for h in cache["handles"]:
+                    _lib.lib().mgu_conv2d_release(cache["ctx"].handle, h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def _conv_prepared(ctx, x_nhwc, prepared, relu):
+        handle, bias, Cout = prepared
+        B, H, W, _ = x_nhwc.shape
+        ld = (Cout + 3) // 4 * 4
+        out = torch.empty((B, H, W, ld), device=x_nhwc.device, dtype=torch.float32)
+        rc = _lib.lib().mgu_conv2d_prepared_nhwc(ctx.handle, handle, x_nhwc.data_ptr(), B, H, W, bias.data_ptr(), None, None,
+                                                 1 if relu else 0, out.data_ptr(), ld, 0, _lib.current_stream_ptr(x_nhwc.device))
+        _lib.check(rc, ctx.handle)
+        return out if ld == Cout else out[..., :Cout]
+
     # ---- building blocks (all on the stream of the input's device) -------------------------------------------------
     @staticmethod
     def _conv(ctx, x_nhwc, w, b, k, relu):
@@ -79,6 +141,7 @@ class DetectionHead(nn.Module):
         ctx = _context(dev)
         w1, b1 = self.fc_layers[0].weight.detach(), self.fc_layers[0].bias.detach()
         with torch.cuda.device(dev):
+            prep = self._prepared(ctx, dev)
             if not self.input_is_flat:
                 if f_fused.dim() != 4:
                     raise ValueError("expected (B, C, H, W) fused features")
@@ -86,22 +149,22 @@ class DetectionHead(nn.Module):
                 if C % 16:
                     raise ValueError("in_features_channels must be a multiple of 16 (C/4 is a 16-byte NHWC pixel)")
                 x = f_fused.detach().permute(0, 2, 3, 1).contiguous()        # a no-op for mgunet's NHWC-stored feature maps
-                cb = self.conv_block
-                x = self._conv(ctx, x, cb[0].weight.detach().contiguous(), cb[0].bias.detach().contiguous(), 3, True)   # :33-34
-                a1, c1 = self._bn_affine(cb[2])
+                x = self._conv_prepared(ctx, x, prep["conv1"], True)                                                    # :33-34
+                a1, c1 = prep["bn1"]
                 x = self._affine(ctx, x.reshape(-1, C // 2), a1, c1, 0).reshape(B, H, W, C // 2)                      # :35
-                x = self._conv(ctx, x, cb[3].weight.detach().contiguous(), cb[3].bias.detach().contiguous(), 3, True)   # :36-37
+                x = self._conv_prepared(ctx, x, prep["conv2"], True)                                                    # :36-37
                 C4 = C // 4
                 sums = torch.empty((B, C4), device=dev, dtype=torch.float32)
-                x2 = x.reshape(B, H * W, C4)
-                for b in range(B):                                                                                       # :39
-                    rc = _lib.lib().mgu_channel_sum_nhwc(ctx.handle, x2[b].data_ptr(), C4, H * W, C4, sums[b].data_ptr(),
-                                                         _lib.current_stream_ptr(dev))
-                    _lib.check(rc, ctx.handle)
-                # BatchNorm (:38) after the mean: Linear1(a2 * mean + c2) = (W1 diag(a2 / HW)) sums + (W1 c2 + b1)
-                a2, c2 = self._bn_affine(cb[5])
-                b1 = b1 + w1 @ c2
-                w1 = w1 * (a2 / float(H * W)).unsqueeze(0)
+                rc = _lib.lib().mgu_channel_sum_images_nhwc(ctx.handle, x.data_ptr(), C4, B, H * W, C4, sums.data_ptr(),
+                                                            _lib.current_stream_ptr(dev))                               # :39
+                _lib.check(rc, ctx.handle)
+                # BatchNorm (:38) after the mean: Linear1(a2 * mean + c2) = (W1 diag(a2 / HW)) sums + (W1 c2 + b1); the
+                # fold depends on H*W, so it is cached per spatial size next to the packed weights
+                fold = prep.setdefault("fold", {})
+                if (H, W) not in fold:
+                    a2, c2 = prep["bn2"]
+                    fold[(H, W)] = ((w1 * (a2 / float(H * W)).unsqueeze(0)).contiguous(), (b1 + w1 @ c2).contiguous())
+                w1, b1 = fold[(H, W)]
                 feat = sums
             else:
                 if f_fused.dim() != 2:
@@ -112,17 +175,8 @@ class DetectionHead(nn.Module):
             h = self._linear(ctx, feat, w1.contiguous(), b1.contiguous(), True)                                           # :45-47
             h = self._linear(ctx, h.contiguous(), self.fc_layers[3].weight.detach(), self.fc_layers[3].bias.detach(), True)  # :49-51
             # the output heads in ONE GEMM: rows [0,4) boxes, [4] confidence, [5, 5+ncls) class scores (:56-66)
-            ws, bs = [self.fc_bbox.weight, self.fc_confidence.weight], [self.fc_bbox.bias, self.fc_confidence.bias]
-            if self.num_classes > 1:
-                ws.append(self.fc_class_scores.weight)
-                bs.append(self.fc_class_scores.bias)
-            wo, bo = torch.cat(ws, 0).detach().contiguous(), torch.cat(bs, 0).detach().contiguous()
-            n_out = wo.shape[0]
-            pad = (-n_out) % 4
-            if pad:
-                wo = torch.cat([wo, torch.zeros(pad, wo.shape[1], device=dev)], 0)
-                bo = torch.cat([bo, torch.zeros(pad, device=dev)], 0)
-            o = self._linear(ctx, h.contiguous(), wo.contiguous(), bo.contiguous(), False).contiguous()
+            wo, bo = prep["heads"]
+            o = self._linear(ctx, h.contiguous(), wo, bo, False).contiguous()
             sg = self._affine(ctx, o, None, None, 2)                                                                      # :101, :104
         bboxes, conf = sg[:, 0:4], sg[:, 4:5]
         if self.num_classes > 1:

@@ -156,3 +156,15 @@ def test_checkpoint_interchange_both_pth_layouts(tmp_path):
     det = mgunet.DetectionHead(96, 3)
     want = set(O.detection_head_param_shapes(96, 3).keys()) | {"conv_block.2.num_batches_tracked", "conv_block.5.num_batches_tracked"}
     assert set(det.state_dict().keys()) == want
+
+
+def test_host_routines_under_asan():
+    """an AddressSanitizer (+UBSan) build of the C-ABI's host routines driven over their edge cases
+    (exact-size buffers, empty / ragged grids, invalid ids).  CPU only -- GPU sanitizers are not available on the pool."""
+    import subprocess
+    csrc = os.path.join(ROOT, "mingraph-unet_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "asan-host"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    exe = os.path.join(ROOT, "mingraph-unet_amd", "lib", "host_abi_check_asan")
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0 and "host_abi_check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

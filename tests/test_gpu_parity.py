@@ -33,7 +33,7 @@ def maxdiff(a, b):
 
 
 def test_native_library_is_the_path(cuda):
-    assert "libmgunet.so" in open("/proc/self/maps").read() or mgunet.lib() is not None
+    mgunet.lib()
     assert "libmgunet.so" in open("/proc/self/maps").read()
 
 
