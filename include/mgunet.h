@@ -135,12 +135,64 @@ int mgu_sync_check(mgu_ctx* ctx, void* hip_stream);
 /* loss.backward() (train_segmentation.py:133) for the last mgu_unet_forward(training=1): dlogits_dev as
  * produced by mgu_cross_entropy; every element of flat_grad_dev (mgu_unet_param_count floats) is written. */
 int mgu_unet_backward(mgu_ctx* ctx, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream);
+/* ---- backward building blocks: ONE stage of loss.backward() each, through exactly the launchers mgu_unet_backward uses,
+ *      on caller-provided NHWC fp32 tensors (kernel-level parity tests against float64; also usable on their own) ------
+ * Weight gradient of Conv2d(k=1|3, pad=k/2) (unet_encoder.py:7-8): dw[co][ci][r][s] = sum_{b,y,x} dz[b,y,x,co] *
+ * in[b, y+r-k/2, x+s-k/2, ci].  in: (B,H,W,ld_in), ld_in % 4 == 0, channels [Cin, ld_in) zero; dz: (B,H,W,ceil4(Cout)) with
+ * zero pad columns; dw_oihw_dev: (Cout,Cin,k,k), every element written. */
+int mgu_conv2d_wgrad_nhwc(mgu_ctx* ctx, const void* in_dev, int ld_in, const void* dz_dev, int B, int H, int W, int Cin, int Cout,
+                          int ksize, void* dw_oihw_dev, void* hip_stream);
+/* Data gradient of the same layer: din[b,y,x,ci] = sum dz[b, y-r+k/2, x-s+k/2, co] * w[co][ci][r][s];
+ * dz as above, din_dev: (B,H,W,ld_out >= Cin). */
+int mgu_conv2d_dgrad_nhwc(mgu_ctx* ctx, const void* dz_dev, const void* w_oihw_dev, int B, int H, int W, int Cin, int Cout, int ksize,
+                          void* din_dev, int ld_out, void* hip_stream);
+/* ConvTranspose2d(Cin, Cout, 2, stride 2) (unet_decoder.py:25,36): in (B,H,W,Cin); dout = channels [c_off, c_off+Cout) of a
+ * (B,2H,2W,ld_d) tensor; dw_iohw_dev (Cin,Cout,2,2); dbias_dev (Cout) or NULL. */
+int mgu_conv_transpose2x2_wgrad_nhwc(mgu_ctx* ctx, const void* in_dev, const void* dout_dev, int ld_d, int c_off, int B, int H, int W,
+                                     int Cin, int Cout, void* dw_iohw_dev, void* dbias_dev, void* hip_stream);
+int mgu_conv_transpose2x2_dgrad_nhwc(mgu_ctx* ctx, const void* dout_dev, int ld_d, int c_off, const void* w_iohw_dev, int B, int H,
+                                     int W, int Cin, int Cout, void* din_dev /* (B,H,W,Cin) */, void* hip_stream);
+/* Train-mode BatchNorm2d (eps 1e-5, momentum 0.1, unet_encoder.py:12-13) + ReLU over an (M, C) view: batch mean / 1/sqrt(biased
+ * var + eps) to mean_dev / invstd_dev, running stats updated in place (unbiased var), y = relu(bn(z)) with pitch ld_y. */
+int mgu_bn_relu_train_nhwc(mgu_ctx* ctx, const void* z_dev, const void* gamma_dev, const void* beta_dev, int64_t M, int C, void* y_dev,
+                           int ld_y, void* mean_dev, void* invstd_dev, void* run_mean_dev, void* run_var_dev, void* hip_stream);
+/* ... and its backward: dy (M, ld_dy) -> dz (M, C) dense, dgamma, dbeta (C), dbias = column sums of dz (the conv bias in front
+ * of the BatchNorm: analytically 0).  The ReLU mask is recomputed from z. */
+int mgu_bn_relu_backward_nhwc(mgu_ctx* ctx, const void* dy_dev, int ld_dy, const void* z_dev, const void* gamma_dev, const void* beta_dev,
+                              const void* mean_dev, const void* invstd_dev, int64_t M, int C, void* dz_dev, void* dgamma_dev,
+                              void* dbeta_dev, void* dbias_dev, void* hip_stream);
+/* MaxPool2d(2,2) backward ACCUMULATED into dskip (the skip tensor also receives the decoder-side gradient): y (B,H,W,ld_y) the
+ * pooled tensor's input, dpool (B,H/2,W/2,C) dense, dskip (B,H,W,ld_d) += routed gradient (first maximum wins, as aten). */
+int mgu_maxpool2x2_backward_nhwc(mgu_ctx* ctx, const void* y_dev, int ld_y, const void* dpool_dev, void* dskip_dev, int ld_d, int B, int H,
+                                 int W, int C, void* hip_stream);
+
 /* torch.optim.Adam.step() with L2 weight decay folded into the gradient (train_segmentation.py:96):
  * g = grad_scale*grad + wd*p; m,v moments; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  step t >= 1.
  * grad_scale lets the caller fold the 1/world_size of an all-reduce SUM into the update. */
 int mgu_adam_step(mgu_ctx* ctx, void* flat_param_dev, const void* flat_grad_dev, void* exp_avg_dev, void* exp_avg_sq_dev,
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   float grad_scale, void* hip_stream);
+
+/* ---- gradient exchange of the data-parallel train step: RCCL over xGMI (the reference is single-process and has no
+ *      collective; BASELINE configs[4] adds exactly this one, SURVEY sections 5 / 8b / 8e) -------------------------------
+ * librccl is bound at run time inside libmgunet.so.  The host only moves 128 bytes: rank 0 calls mgu_comm_get_unique_id,
+ * hands the bytes to every rank through its launcher's store, and each rank calls mgu_comm_init_rank on its own ctx
+ * (= ncclCommInitRank on the ctx's device).  The communicator belongs to the ctx (freed by mgu_comm_destroy /
+ * mgu_destroy). */
+#define MGU_COMM_ID_BYTES 128
+int mgu_comm_get_unique_id(void* id_out /* host, MGU_COMM_ID_BYTES */);
+int mgu_comm_init_rank(mgu_ctx* ctx, const void* id /* host, MGU_COMM_ID_BYTES */, int rank, int world_size);
+int mgu_comm_destroy(mgu_ctx* ctx);
+void* mgu_comm_handle(mgu_ctx* ctx);     /* the ncclComm_t of this ctx, or NULL */
+int mgu_comm_world_size(mgu_ctx* ctx);   /* 1 without a communicator */
+/* In-place MEAN over the ranks of flat_grad_dev (n fp32, device) on hip_stream: one ncclAllReduce(ncclAvg).
+ * rccl_comm: an ncclComm_t of the caller, or NULL for the ctx's own communicator. */
+int mgu_allreduce_grads(mgu_ctx* ctx, void* flat_grad_dev, int64_t n, void* rccl_comm, void* hip_stream);
+/* mgu_unet_backward + the gradient exchange, overlapped: the flat gradient is mean-all-reduced in buckets (>= 4 MB, in
+ * the order backward finishes them: decoder first, encoder last) on the ctx's own communicator stream while the remaining
+ * layers are still being differentiated; when the call returns, work enqueued on hip_stream afterwards (mgu_adam_step)
+ * sees the averaged gradient.  Needs mgu_comm_init_rank. */
+int mgu_unet_backward_allreduce(mgu_ctx* ctx, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream);
 
 /* One-shot request: the NEXT mgu_unet_forward on this ctx also writes the per-patch means of the shallowest decoder
  * feature -- exactly what mgu_patch_mean(decoder_feats[0], ...) returns, (B*nph*npw, init_features) fp32 -- to out_dev.

@@ -73,6 +73,12 @@ struct mgu_ctx {
   int tB = 0, tH = 0, tW = 0;
   std::vector<float*> t_cat, t_feat, t_pooled;
   float* t_logits = nullptr;
+  // gradient exchange (comm.hip): RCCL communicator owned by this context, its stream and a small pool of ordering events
+  void* comm = nullptr;     // ncclComm_t
+  int comm_world = 1, comm_rank = 0;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t comm_ev[16] = {};
+  int comm_ev_next = 0;
   // profiling
   bool prof = false;
   std::vector<hipEvent_t> ev;  // pairs
@@ -151,6 +157,10 @@ int run_layer(mgu_ctx* c, const Layer& L, const void* in, int ldin, int B, int H
               int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s,
               void* pool = nullptr, int ldpool = 0, bool* pool_fused = nullptr,   // optional fused MaxPool2d(2) output
               double* stat_slots = nullptr, bool* stat_fused = nullptr);          // optional fused BatchNorm batch statistics
+
+// gradient exchange (comm.hip)
+int comm_bucket(mgu_ctx* c, float* flat, int64_t lo, int64_t hi, hipStream_t s);
+int comm_join(mgu_ctx* c, hipStream_t s);
 
 // training path (mgunet_train.hip)
 size_t train_ws_bytes(const mgu_ctx* c, int B, int H, int W);

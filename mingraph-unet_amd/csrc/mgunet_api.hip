@@ -86,6 +86,7 @@ void mgu_destroy(mgu_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  (void)mgu_comm_destroy(c);
   if (c->arena) (void)hipFree(c->arena);
   if (c->ws) (void)hipFree(c->ws);
   if (c->gws) (void)hipFree(c->gws);

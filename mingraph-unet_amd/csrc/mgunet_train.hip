@@ -292,7 +292,13 @@ int mgu_sync_check(mgu_ctx* c, void* hip_stream) {
   return pending_data_error(c);
 }
 
-int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream) {
+}  // extern "C"
+
+// exchange != 0: the gradient of every finished block is mean-all-reduced on the context's communicator stream while the
+// blocks below it are still being differentiated.  Blocks finish in reverse parameter order (final conv, decoder shallow ->
+// deep, bottleneck, encoder deep -> shallow), so the finished part of the flat vector is a suffix that grows downwards;
+// it is flushed whenever >= 4 MB are pending (xGMI collectives are latency-bound below that) and once at the end.
+static int backward_impl(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream, int exchange) {
   if (!c) return MGU_ERR_INVALID;
   if (!c->have_train_fwd) return fail(c, MGU_ERR_STATE, "mgu_unet_backward needs a preceding mgu_unet_forward(training=1)");
   if (!dlogits_dev || !flat_grad_dev) return fail(c, MGU_ERR_INVALID, "NULL buffer");
@@ -317,6 +323,14 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
   w.red = (double*)c->redws;
   float* tc = at(c, p.tc);
   int rc;
+  int64_t pend_hi = c->nparams;   // flat[pend_lo, pend_hi) is finished but not yet exchanged
+  auto block_done = [&](int64_t lo, bool last) -> int {
+    if (!exchange) return MGU_OK;
+    if (!last && (pend_hi - lo) < (1 << 20)) return MGU_OK;
+    int r = comm_bucket(c, w.flat, lo, pend_hi, s);
+    pend_hi = lo;
+    return r;
+  };
 
   // ---- final 1x1 conv (unet_decoder.py:143) ------------------------------------------------------
   const Layer& F = c->layers.back();
@@ -344,6 +358,7 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
   }
   const float* dy = tc;
   int lddy = C0;
+  if ((rc = block_done(F.off_w, false))) return rc;
 
   // ---- decoder blocks, shallow -> deep (reverse of unet_decoder.py:139-141) ------------------------
   for (int b = d - 1; b >= 0; --b) {
@@ -375,11 +390,13 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
     q.KS = 2, q.K = Kt, q.Kp = Kpt, q.N = U.Cin, q.ldout = U.Cin, q.Hout = hs[i], q.Wout = ws[i];
     HIPCHK(c, launch_igemm_f32(q, s));
     dy = tc, lddy = U.Cin;
+    if ((rc = block_done(U.off_w, false))) return rc;
   }
   // ---- bottleneck -----------------------------------------------------------------------------------
   {
     const Layer& L1 = c->layers[2 * d];
     if ((rc = block_backward(w, L1, c->layers[2 * d + 1], dy, lddy, tc, L1.Cin))) return rc;
+    if ((rc = block_done(L1.off_w, false))) return rc;
   }
   // ---- encoder blocks, deep -> shallow -----------------------------------------------------------------
   for (int i = d - 1; i >= 0; --i) {
@@ -389,8 +406,22 @@ int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, 
     HIPCHK(c, launch_maxpool2_bwd_add(c->t_cat[i], 2 * C, tc, dcat, 2 * C, B, hs[i], ws[i], C, s));
     const Layer& L1 = c->layers[2 * i];
     if ((rc = block_backward(w, L1, c->layers[2 * i + 1], dcat, 2 * C, i > 0 ? tc : nullptr, L1.Cin))) return rc;
+    if ((rc = block_done(L1.off_w, i == 0))) return rc;
   }
+  if (exchange && (rc = comm_join(c, s))) return rc;   // the caller's stream continues after the last bucket
   return MGU_OK;
+}
+
+extern "C" {
+
+int mgu_unet_backward(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream) {
+  return backward_impl(c, dlogits_dev, flat_grad_dev, hip_stream, 0);
+}
+
+int mgu_unet_backward_allreduce(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!c->comm) return fail(c, MGU_ERR_STATE, "mgu_unet_backward_allreduce needs mgu_comm_init_rank on this context");
+  return backward_impl(c, dlogits_dev, flat_grad_dev, hip_stream, 1);
 }
 
 int mgu_adam_step(mgu_ctx* c, void* flat_param_dev, const void* flat_grad_dev, void* exp_avg_dev, void* exp_avg_sq_dev,

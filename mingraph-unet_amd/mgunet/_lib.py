@@ -42,6 +42,27 @@ _PROTOS = {
                                     C.c_void_p, C.c_void_p]),
     "mgu_sync_check": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgu_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgu_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "mgu_comm_init_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "mgu_comm_destroy": (C.c_int, [C.c_void_p]),
+    "mgu_comm_handle": (C.c_void_p, [C.c_void_p]),
+    "mgu_comm_world_size": (C.c_int, [C.c_void_p]),
+    "mgu_allreduce_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "mgu_unet_backward_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgu_conv2d_wgrad_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
+    "mgu_conv2d_dgrad_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_void_p]),
+    "mgu_conv_transpose2x2_wgrad_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgu_conv_transpose2x2_dgrad_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mgu_bn_relu_train_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgu_bn_relu_backward_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgu_maxpool2x2_backward_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, C.c_void_p]),
     "mgu_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "mgu_conv2d_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

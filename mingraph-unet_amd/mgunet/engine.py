@@ -172,7 +172,12 @@ class Trainer:
     a single kernel and the gradient exchange a single collective.  Each rank normalises BatchNorm over its
     own shard (DDP semantics)."""
 
-    def __init__(self, model: UNet, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+    def __init__(self, model: UNet, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None, comm="auto"):
+        """comm: "auto" -- when torch.distributed runs the "nccl" backend with more than one rank, the gradient exchange is
+        libmgunet's own RCCL communicator (mgu_comm_init_rank; torch.distributed only carries the 128-byte id) and is
+        overlapped with backward (mgu_unet_backward_allreduce); a gloo group (CPU rehearsal of the plumbing) falls back to
+        torch.distributed.all_reduce on a host copy.  "rccl": always create the communicator, also for a single process
+        (world size 1: the collective degenerates to a copy, which is what the 1-GPU test exercises).  None: no exchange."""
         params = list(model.named_parameters())
         if not params or not params[0][1].is_cuda:
             raise RuntimeError("move the model to a HIP device before building a Trainer (no CPU fallback)")
@@ -202,12 +207,42 @@ class Trainer:
         model._slots = None
         self.step_count = 0
         self._loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._rccl = False
+        if comm == "rccl" or (comm == "auto" and self._dist_backend() == "nccl" and self._dist_world() > 1):
+            self.attach_rccl()
+
+    def _dist_world(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _dist_backend(self):
+        import torch.distributed as dist
+        return dist.get_backend(self.group) if dist.is_available() and dist.is_initialized() else None
+
+    def attach_rccl(self) -> None:
+        """ncclCommInitRank inside libmgunet for this rank's context.  Rank 0 draws the ncclUniqueId; the launcher's process
+        group is used ONLY to hand its 128 bytes to the other ranks."""
+        import torch.distributed as dist
+        L, ctx = _lib.lib(), self.model._context(self.device)
+        world, rank = self._dist_world(), (dist.get_rank(self.group) if self._dist_world() > 1 else 0)
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(L.mgu_comm_get_unique_id(buf), None)
+        if world > 1:
+            box = [bytes(buf.raw)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            buf = C.create_string_buffer(box[0], 128)
+        with torch.cuda.device(self.device):
+            _lib.check(L.mgu_comm_init_rank(ctx.handle, buf, rank, world), ctx.handle)
+        self._rccl = True
 
     def set_lr(self, lr: float) -> None:  # StepLR etc. live on the host (train_segmentation.py:105,143)
         self.lr = lr
 
-    def forward_backward(self, images: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
-        """Fills self.grad with d(mean CE)/d(params) of this rank's shard; returns the loss (device scalar)."""
+    def forward_backward(self, images: torch.Tensor, masks: torch.Tensor, exchange: bool = False) -> torch.Tensor:
+        """Fills self.grad with d(mean CE)/d(params) of this rank's shard; returns the loss (device scalar).
+        exchange=True (needs attach_rccl): the gradient comes back already averaged over the ranks, the all-reduce having run
+        bucket by bucket behind the layers still being differentiated."""
         model, dev = self.model, self.device
         if masks.dtype != torch.int64 or not masks.is_cuda:
             raise TypeError("masks must be an int64 tensor on the HIP device")
@@ -227,8 +262,16 @@ class Trainer:
         with torch.cuda.device(dev):
             _lib.check(L.mgu_cross_entropy(ctx.handle, nhwc.data_ptr(), masks.data_ptr(), npix, Cc, 1.0 / npix,
                                            dlogits.data_ptr(), self._loss.data_ptr(), stream), ctx.handle)
-            _lib.check(L.mgu_unet_backward(ctx.handle, dlogits.data_ptr(), self.grad.data_ptr(), stream), ctx.handle)
+            bwd = L.mgu_unet_backward_allreduce if exchange else L.mgu_unet_backward
+            _lib.check(bwd(ctx.handle, dlogits.data_ptr(), self.grad.data_ptr(), stream), ctx.handle)
         return self._loss
+
+    def check(self) -> None:
+        """Synchronise and raise ValueError if a kernel of this trainer met invalid data (a label outside [0, C) other than
+        the ignore_index -100) -- the place torch would have raised; train_step itself never blocks the host."""
+        ctx = self.model._context(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgu_sync_check(ctx.handle, _lib.current_stream_ptr(self.device)), ctx.handle)
 
     def optimizer_step(self, grad_scale: float = 1.0) -> None:
         model, dev = self.model, self.device
@@ -242,7 +285,11 @@ class Trainer:
         model.mark_parameters_changed()
 
     def train_step(self, images: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
+        if self._rccl:   # the only data-path collective of the build, issued from inside backward
+            loss = self.forward_backward(images, masks, exchange=True)
+            self.optimizer_step(1.0)
+            return loss
         loss = self.forward_backward(images, masks)
-        scale = allreduce_mean_(self.grad, self.group)   # the only data-path collective of the build
+        scale = allreduce_mean_(self.grad, self.group)   # gloo rehearsal / single process
         self.optimizer_step(scale)
         return loss
