@@ -1,0 +1,69 @@
+"""The gradient exchange on REAL RCCL with a one-rank communicator (all a one-GPU box can hold): librccl binds inside
+libmgunet.so, ncclCommInitRank works from a host-passed id, the collective runs on the caller's stream in order, the
+bucketed exchange issued from inside backward leaves the same gradient as backward alone (mean over 1 rank = identity), and a
+train step through it equals the step without it.  The two-rank logic (shard + mean) is covered on CPU by test_dist_gloo.py.
+BASELINE configs[4]; SURVEY 8b mgu_allreduce_grads, 8e."""
+import ctypes as C
+
+import pytest
+import torch
+
+import mgunet
+import mgunet_oracle as O
+from mgunet import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def make_trainer(cuda, comm):
+    cfg = (3, 2, 8, 2)
+    m = mgunet.UNet(*cfg)
+    m.load_state_dict(O.make_unet_params(*cfg, seed=9))
+    return mgunet.Trainer(m.to(cuda), lr=1e-3, weight_decay=1e-4, comm=comm)
+
+
+def test_allreduce_grads_one_rank_stream_order(cuda):
+    L = _lib.lib()
+    ctx = _lib.Context(0)
+    uid = C.create_string_buffer(128)
+    _lib.check(L.mgu_comm_get_unique_id(uid), None)
+    assert any(uid.raw)
+    _lib.check(L.mgu_comm_init_rank(ctx.handle, uid, 0, 1), ctx.handle)
+    assert L.mgu_comm_world_size(ctx.handle) == 1 and L.mgu_comm_handle(ctx.handle)
+    with pytest.raises(RuntimeError):                     # one communicator per context
+        _lib.check(L.mgu_comm_init_rank(ctx.handle, uid, 0, 1), ctx.handle)
+    n = 7_766_018                                         # the U-Net's flat gradient
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        g = torch.zeros(n, device=cuda)
+        for k in range(4):                                # producer kernels -> collective -> consumer, all on one stream
+            g.add_(1.0)
+            _lib.check(L.mgu_allreduce_grads(ctx.handle, g.data_ptr(), n, None, side.cuda_stream), ctx.handle)
+            g.mul_(2.0)
+        want = 0.0
+        for k in range(4):
+            want = (want + 1.0) * 2.0
+    side.synchronize()
+    assert float(g.min()) == want and float(g.max()) == want
+    # an explicit ncclComm_t is honoured too
+    _lib.check(L.mgu_allreduce_grads(ctx.handle, g.data_ptr(), 1000, L.mgu_comm_handle(ctx.handle), _lib.current_stream_ptr(cuda)), ctx.handle)
+    torch.cuda.synchronize()
+    _lib.check(L.mgu_comm_destroy(ctx.handle), ctx.handle)
+    assert L.mgu_comm_world_size(ctx.handle) == 1 and not L.mgu_comm_handle(ctx.handle)
+    with pytest.raises(RuntimeError):
+        _lib.check(L.mgu_allreduce_grads(ctx.handle, g.data_ptr(), n, None, _lib.current_stream_ptr(cuda)), ctx.handle)
+
+
+def test_backward_with_bucketed_exchange_equals_backward(cuda):
+    x = torch.from_numpy(O.formula_normal("rccl/x", (2, 3, 64, 48), seed=1)).to(cuda)
+    y = torch.from_numpy(O.formula_labels("rccl/y", (2, 64, 48), 2, seed=2)).to(cuda)
+    plain, rccl = make_trainer(cuda, None), make_trainer(cuda, "rccl")
+    assert rccl._rccl and not plain._rccl
+    for step in range(3):
+        l0 = plain.train_step(x, y)
+        l1 = rccl.train_step(x, y)                         # backward + overlapped buckets + Adam behind the join
+        torch.cuda.synchronize()
+        assert float(l0) == float(l1)
+        assert torch.equal(plain.grad, rccl.grad)          # mean over one rank: bit-identical
+        assert torch.equal(plain.flat, rccl.flat)
+    rccl.check()
