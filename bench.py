@@ -11,11 +11,21 @@ its own 8 images (weak scaling, = configs[2]'s 8 images/GPU at N=8) and there is
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+The JSON line's `roofline` describes ONE kernel -- the one the step spends most of its time in -- measured live with HIP
+events the library records on the launch stream right around every launch (mgu_profile_read_kernels), in a separate pass of
+the same steps (events off during the timed region so they cannot perturb `value`):
+    achieved = FLOPs the kernel ISSUES on its matrix pipe per launch / its average launch duration,  frac = achieved / peak.
+The fp32 3x3 layers run as Winograd F(2x2,3x3) (16 multiplies per 2x2 tile and channel pair instead of 36) with every fp32
+operand split exactly into three bf16 pieces (six bf16 MFMA products per fp32 product, fp32 accumulate): `frac` is against
+the bf16 MFMA peak that pipe has; the algorithmic (direct-convolution) rate and the fp32-equivalent rate are reported next
+to it and never as `frac`.  `gat` is the graph kernel's record (HBM bound), at the headline batch and at 64 graphs.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,6 +38,8 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: bf16 MFMA dense (never the 2:1-sparse figure)
+PEAK_HBM_TBS = 8.0              # same guide: HBM3E spec peak (6.3 TB/s achievable by a streaming copy)
+PIPE = {0: ("fp32 MFMA (v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS), 1: ("bf16 MFMA (v_mfma_f32_32x32x16_bf16)", PEAK_BF16_MFMA_TFLOPS)}
 
 
 def host_cores():
@@ -42,12 +54,15 @@ def host_cores():
     return max(1, n)
 
 
+def cpu_threads():
+    return min(host_cores(), int(os.environ.get("MGU_CPU_THREADS", "16")))  # the 1-GPU box's CPU share is 16
+
+
 def cpu_baseline(batch, H, W, iters):
     """The oracle (CPU restatement of the reference path, same aten/oneDNN kernels the reference's
     modules dispatch to) timed on this box's host cores on a bounded sample of the same workload."""
     import mgunet_oracle as O
-    threads = min(host_cores(), int(os.environ.get("MGU_CPU_THREADS", "16")))  # the 1-GPU box's CPU share is 16
-    torch.set_num_threads(threads)
+    torch.set_num_threads(cpu_threads())
     p = O.make_unet_params(3, 2, 32, 4, seed=0)
     gp = O.make_gat_params(32, 128, 64, 4, 1, seed=0)
     ei = torch.from_numpy(O.patch_graph_edges(H, W, 16))
@@ -70,6 +85,24 @@ def cpu_baseline(batch, H, W, iters):
                       f"({dt:.2f} s/iter), torch {torch.__version__} CPU"}
 
 
+def cpu_baseline_train(H, W, iters):
+    """The oracle's train step (train-mode forward, CrossEntropy, torch autograd backward, Adam with L2) on ONE image of the
+    same workload on the host cores."""
+    import mgunet_oracle as O
+    torch.set_num_threads(cpu_threads())
+    p = O.make_unet_params(3, 2, 32, 4, seed=0)
+    x = torch.from_numpy(O.formula_normal("bench/cpu/tx", (1, 3, H, W), seed=1))
+    y = torch.from_numpy(O.formula_labels("bench/cpu/ty", (1, H, W), 2, seed=2))
+    O.train_step(p, x, y, 4)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        O.train_step(p, x, y, 4)
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(H * W / dt / 1e6, 4), "unit": "Mpix/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 image 3x{H}x{W} fp32, the oracle's train step (train-mode forward + CE + autograd backward + Adam), "
+                      f"1 warm-up + {iters} timed iterations ({dt:.2f} s/iter), torch {torch.__version__} CPU"}
+
+
 def max_over_ranks(dt, dist, dev):
     if dist is None:
         return dt
@@ -78,17 +111,158 @@ def max_over_ranks(dt, dist, dev):
     return float(t.item())
 
 
+def merge_stats(*lists):
+    out = {}
+    for lst in lists:
+        for k in lst:
+            e = out.setdefault(k["name"], {"name": k["name"], "ms": 0.0, "flops_alg": 0.0, "flops_mfma": 0.0, "launches": 0, "pipe": k["pipe"]})
+            for f in ("ms", "flops_alg", "flops_mfma", "launches"):
+                e[f] += k[f]
+    return sorted(out.values(), key=lambda e: -e["ms"])
+
+
+def roofline_from(stats, nprof, arithmetic, traffic=None):
+    """The dominant kernel's record + the per-family table.  stats: merged mgu_profile_read_kernels over nprof steps."""
+    mf = [k for k in stats if k["pipe"] >= 0 and k["flops_mfma"] > 0]
+    if not mf:
+        return None
+    dom = mf[0]
+    pipe_name, peak = PIPE[dom["pipe"]]
+    t = dom["ms"] * 1e-3
+    ach = dom["flops_mfma"] / t / 1e12
+    fp32_equiv = dom["flops_mfma"] / (6.0 if ("wino" in dom["name"] and dom["pipe"] == 1) else 1.0)
+    table = [{"kernel": k["name"], "launches_per_step": round(k["launches"] / nprof, 2), "ms_per_step": round(k["ms"] / nprof, 4),
+              "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2),
+              "issued_tflops": round(k["flops_mfma"] / (k["ms"] * 1e-3) / 1e12, 2) if k["flops_mfma"] else None,
+              "algorithmic_tflops": round(k["flops_alg"] / (k["ms"] * 1e-3) / 1e12, 2) if k["flops_alg"] else None,
+              "pipe": {0: "f32", 1: "bf16", -1: "valu/hbm"}[k["pipe"]]} for k in stats]
+    conv = [k for k in stats if k["flops_alg"] > 0]
+    conv_ms = sum(k["ms"] for k in conv)
+    return {"bound": "mfma", "kernel": dom["name"], "launches_per_step": round(dom["launches"] / nprof, 2),
+            "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "pipe": pipe_name, "arithmetic": arithmetic,
+            "issued_flop_per_launch": round(dom["flops_mfma"] / dom["launches"]),
+            "algorithmic_flop_per_launch": round(dom["flops_alg"] / dom["launches"]),
+            "algorithmic_tflops": round(dom["flops_alg"] / t / 1e12, 2),
+            "fp32_equivalent_tflops": round(fp32_equiv / t / 1e12, 2),
+            "fp32_equivalent_frac_of_fp32_mfma_peak": round(fp32_equiv / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            "traffic": traffic[0] if traffic else None, "traffic_unit": "HBM bytes per launch of this kernel (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic_source": traffic[1] if traffic else None,
+            "all_conv_kernels": {"ms_per_step": round(conv_ms / nprof, 4), "launches_per_step": round(sum(k["launches"] for k in conv) / nprof, 2),
+                                 "algorithmic_tflops": round(sum(k["flops_alg"] for k in conv) / (conv_ms * 1e-3) / 1e12, 2),
+                                 "gflop_per_step_algorithmic": round(sum(k["flops_alg"] for k in conv) / nprof / 1e9, 2)},
+            "kernels": table,
+            "note": ("achieved = FLOPs ISSUED on the kernel's matrix pipe per launch / average launch duration (HIP events on the launch "
+                     "stream, instrumented pass); frac = achieved / that pipe's dense peak.  algorithmic_* count the direct-convolution "
+                     "2*MAC of the operator (Winograd executes 16/36 of them); fp32_equivalent_* count the Winograd multiplies once "
+                     "(not x6 for the three bf16 pieces) against the fp32 MFMA peak -- neither is `frac`.")}
+
+
+def load_traffic(kernel, dtype):
+    """HBM bytes per launch of `kernel` from this round's committed PMC passes (rocprofv3 cannot run inside this process)."""
+    tj = os.path.join(ROOT, "profiles", f"r02_traffic_{dtype}.json")
+    if not os.path.exists(tj):
+        return None
+    t = json.load(open(tj))
+    for k, v in t.get("kernels", {}).items():
+        if kernel.split("<")[0] in k and (("<" not in kernel) or kernel.split("<")[1].rstrip(">").replace(" ", "") in k.replace(" ", "")):
+            return round(v["hbm_bytes_per_launch"]), f"profiles/r02_traffic_{dtype}.json ({t.get('correction', '')})"
+    return None
+
+
+def gat_record(dev, L, _lib):
+    """The graph kernel at the north-star point (64 graphs of the 512^2 / patch-16 grid = 65 536 nodes, 253 952 edges) on
+    synthetic node features, both schedules: aggregate-first (the patch GAT's, Fin 32 <= F' 64) and the Wh-row gather
+    (layers with Fin > F'; forced here with MGU_NO_GAT_FUSED=1 in a context of its own so that the same layer is measured)."""
+    import mgunet
+    import mgunet_oracle as O
+    from mgunet.engine import gat_forward_csr
+    out = {}
+    graph = mgunet.PatchGraphConstructor(16)
+    Fin, heads, Fh = 32, 4, 64
+    for G in (8, 64):
+        rowptr, col, gp, N, E = graph.batched_csr(512, 512, G, dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(7)
+        X = torch.randn((N, Fin), device=dev, generator=gen)
+        rec = {"graphs": G, "nodes": N, "edges": E}
+        for sched, env in (("aggregate_first", {}), ("wh_row_gather", {"MGU_NO_GAT_FUSED": "1"})):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            ctx = _lib.Context(dev.index or 0)
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            gp_ = O.make_gat_params(32, 128, 64, 4, 1, seed=0)
+            W = torch.cat([gp_[f"gat_layers.0.heads.{h}.W.weight"] for h in range(heads)], 0).contiguous().to(dev)
+            a = torch.cat([gp_[f"gat_layers.0.heads.{h}.a.weight"] for h in range(heads)], 0).contiguous().to(dev)
+            hnd = C.c_void_p()
+            s = _lib.current_stream_ptr(dev)
+            _lib.check(L.mgu_gat_prepare(ctx.handle, W.data_ptr(), a.data_ptr(), heads, Fh, Fin, 1, C.byref(hnd), s), ctx.handle)
+            y = torch.empty((N, Fh), device=dev)
+
+            def run():
+                _lib.check(L.mgu_gat_layer_forward_prepared(ctx.handle, hnd, X.data_ptr(), N, rowptr.data_ptr(), col.data_ptr(), E,
+                                                            gp.data_ptr(), G, 0, 0.2, y.data_ptr(), s), ctx.handle)
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize(dev)
+            reps = 20
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(reps):
+                run()
+            ev1.record()
+            torch.cuda.synchronize(dev)
+            layer_us = ev0.elapsed_time(ev1) * 1e3 / reps
+            L.mgu_profile_enable(ctx.handle, 1)
+            for _ in range(reps):
+                run()
+            ks = _lib.read_kernel_stats(ctx)
+            L.mgu_profile_enable(ctx.handle, 0)
+            kern = {k["name"]: round(k["ms"] * 1e3 / reps, 2) for k in ks}
+            csr = (N + 1 + E) * 4
+            if sched == "aggregate_first":
+                # X read (stmax) + st written, node->graph written; then X, st, node->graph, CSR read again + out written
+                comp = N * Fin * 4 + csr + N * 2 * heads * 4 + N * 4 + (N * Fin * 4 + csr + N * 2 * heads * 4 + N * 4 + N * Fh * 4)
+                dom_name = "gat_fused_kernel"
+                dom_bytes = N * Fin * 4 + csr + N * 2 * heads * 4 + N * 4 + N * Fh * 4
+            else:
+                comp = None
+                dom_name = "gat_aggregate_kernel"
+                dom_bytes = N * heads * Fh * 4 + N * 2 * heads * 4 + csr + N * 4 + N * Fh * 4   # SURVEY 8d: Wh table + s,t + CSR + out
+            dom_us = kern.get(dom_name)
+            rec[sched] = {"launches": len(ks), "layer_us": round(layer_us, 2), "kernel_us": kern,
+                          "dominant_kernel": dom_name, "compulsory_bytes": dom_bytes,
+                          "achieved_TBps": round(dom_bytes / (dom_us * 1e-6) / 1e12, 3) if dom_us else None,
+                          "frac_of_hbm_peak": round(dom_bytes / (dom_us * 1e-6) / 1e12 / PEAK_HBM_TBS, 4) if dom_us else None,
+                          "logical_gather_bytes": E * (4 + (Fin if sched == "aggregate_first" else heads * Fh) * 4 + 4),
+                          "layer_compulsory_bytes": comp}
+            L.mgu_gat_release(ctx.handle, hnd)
+            del ctx
+        out[f"graphs_{G}"] = rec
+    out["note"] = ("compulsory_bytes: every array the dominant kernel must touch once (node table or input rows, attention scalars, CSR, "
+                   "node->graph ids, output); at these sizes the tables (8-67 MB) stay in the 256 MB Infinity Cache between the producer "
+                   "and the gather, so the ceiling is the cache, not HBM -- the HBM fraction the north star asks for is quoted as-is, "
+                   "against the 8 TB/s spec peak")
+    return out
+
+
 def bench_train(a, world, rank, local_rank, dev, dist):
     """BASELINE configs[4]: training step, batch 32 over 8 GPUs = 4 images/GPU (weak scaling), fwd+bwd+Adam,
     mean all-reduce of the flat fp32 gradient over RCCL (DDP semantics).  Mpix/s = images*H*W per step time."""
     import mgunet
     import mgunet_oracle as O
-    B = a.batch if a.batch != 8 else 4
+    from mgunet import _lib
+    B = a.batch if a.batch is not None else 4
     H = W = a.size
     model = mgunet.UNet(3, 2, 32, 4)
     model.load_state_dict(O.make_unet_params(3, 2, 32, 4, seed=0))
     model = model.to(dev)
-    tr = mgunet.Trainer(model, lr=1e-3, weight_decay=1e-4)
+    # the gradient exchange is libmgunet's own RCCL communicator (mgu_unet_backward_allreduce: buckets overlapped with backward);
+    # at one rank it is created too, so that the single-GPU number contains the (degenerate) collective calls
+    rehearsal = dist is not None and dist.get_backend() != "nccl"
+    tr = mgunet.Trainer(model, lr=1e-3, weight_decay=1e-4, comm="auto" if rehearsal else "rccl")
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
     x = torch.randn((B, 3, H, W), device=dev, generator=gen)
@@ -109,7 +283,24 @@ def bench_train(a, world, rank, local_rank, dev, dist):
     barrier()
     dt = time.perf_counter() - t0
     assert bool(torch.isfinite(loss).all())
+    tr.check()
     dt = max_over_ranks(dt, dist, dev)
+    roof = cpu = None
+    if rank == 0 and not a.no_profile_pass:
+        ctx = model._context(dev)
+        L = _lib.lib()
+        nprof = min(a.steps, 5)
+        L.mgu_profile_enable(ctx.handle, 1)
+        for _ in range(nprof):
+            tr.train_step(x, y)
+        stats = merge_stats(_lib.read_kernel_stats(ctx))
+        L.mgu_profile_enable(ctx.handle, 0)
+        dom = next((k for k in stats if k["pipe"] >= 0 and k["flops_mfma"] > 0), None)
+        roof = roofline_from(stats, nprof, "fp32 operands split exactly into 3 bf16 pieces (6 bf16 MFMA products per fp32 product), fp32 "
+                             "accumulate, for the forward / data-gradient Winograd convolutions; exact fp32 MFMA for the weight gradients",
+                             load_traffic(dom["name"], "train") if dom else None)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline_train(H, W, 4)
     if rank == 0:
         flops = 3.0 * model.flops(B, H, W)  # bwd = dgrad + wgrad ~ 2x fwd
         line = {"metric": "segmented Mpix/sec, MinGraph-UNet train step (fwd + CE + bwd + grad all-reduce + Adam), 512x512",
@@ -119,9 +310,11 @@ def bench_train(a, world, rank, local_rank, dev, dist):
                 "config": {"workload": f"BASELINE configs[4]: train step, {B} images/GPU x 3x{H}x{W} fp32, UNet(3,2,32,4), "
                                        f"CrossEntropy + Adam(1e-3, wd 1e-4), per-shard BatchNorm (DDP semantics)",
                            "images_per_gpu": B, "global_batch": B * world,
-                           "parallelism": f"dp{world}: one flat {tr.flat.numel() * 4 / 1e6:.1f} MB fp32 gradient all-reduce (RCCL) per step"},
+                           "parallelism": (f"dp{world}: mean all-reduce of the flat {tr.flat.numel() * 4 / 1e6:.1f} MB fp32 gradient on "
+                                           f"libmgunet's own RCCL communicator, in >= 4 MB buckets overlapped with backward"
+                                           if tr._rccl else f"dp{world}: gloo rehearsal (host all-reduce)")},
                 "final_loss": round(float(loss), 6),
-                "approx_tflops": round(flops * a.steps / dt / 1e12, 2), "roofline": None, "cpu_baseline": None}
+                "approx_tflops": round(flops * a.steps / dt / 1e12, 2), "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -132,16 +325,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE config 2: 8)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: 8 = BASELINE configs[1]/[2]; train mode: 4 = configs[4])")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer: BASELINE configs[1]/[2] full forward (the headline); train: configs[4] train step "
                          "(fwd + CE + bwd + RCCL grad all-reduce + Adam), 4 images per GPU unless --batch is given")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="f32: exact-fp32 MFMA (BASELINE configs[1], the headline); bf16: bf16 storage + fp32 accumulate "
+                    help="f32: fp32 results (BASELINE configs[1], the headline); bf16: bf16 storage + fp32 accumulate "
                          "(configs[2]'s precision; reported as its own config, never as the fp32 number)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--spread-windows", type=int, default=4, help="extra timed windows of --steps steps for the min/median/max record")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,10 +365,11 @@ def main():
     import mgunet
     import mgunet_oracle as O
     from mgunet import _lib
+    from mgunet.gat import _context as gat_context
 
     if a.mode == "train":
         return bench_train(a, world, rank, local_rank, dev, dist)
-    B, H, W = a.batch, a.size, a.size
+    B, H, W = a.batch if a.batch is not None else 8, a.size, a.size
     unet = mgunet.UNet(3, 2, 32, 4, compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     unet.load_state_dict(O.make_unet_params(3, 2, 32, 4, seed=0))     # random-init-scale formula weights
     gat = mgunet.GATNetwork(32, 128, 64, 4, 1)
@@ -202,58 +397,57 @@ def main():
         ev1.record()
         barrier()
         dt = time.perf_counter() - t0
+        # spread: further windows of the same K steps (local clock; the headline `value` stays the first, barrier-bracketed window)
+        windows = [dt / a.steps * 1e3]
+        for _ in range(max(0, a.spread_windows)):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                out = model(x)
+            torch.cuda.synchronize(dev)
+            windows.append((time.perf_counter() - t1) / a.steps * 1e3)
     assert bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[3]).all())
     dt = max_over_ranks(dt, dist, dev)
     ms_step = dt / a.steps * 1e3
     mpix = world * B * H * W * a.steps / dt / 1e6
 
-    # ---- roofline of the dominant kernel (the fp32 implicit-GEMM conv): HIP events recorded by the
-    # library on the launch stream around every conv/convT/1x1/linear GEMM launch of the same steps
-    roof = None
+    roof = gatrec = timing = None
     if rank == 0 and not a.no_profile_pass:
-        ctx = next(iter(unet._ctx.values()))
+        uctx = next(iter(unet._ctx.values()))
+        gctx = gat_context(dev)
         L = _lib.lib()
-        conv_ms = tot_ms = 0.0
-        launches = 0
         nprof = min(a.steps, 10)
         with torch.no_grad():
+            L.mgu_profile_enable(uctx.handle, 1)
+            L.mgu_profile_enable(gctx.handle, 1)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
             for _ in range(nprof):
-                L.mgu_profile_enable(ctx.handle, 1)
-                model.unet(x)
-                cm, n, tm = C.c_double(), C.c_int(), C.c_double()
-                _lib.check(L.mgu_profile_read(ctx.handle, C.byref(cm), C.byref(n), C.byref(tm)), ctx.handle)
-                conv_ms += cm.value
-                tot_ms += tm.value
-                launches += n.value
-            L.mgu_profile_enable(ctx.handle, 0)
-        flops = unet.flops(B, H, W)
-        exe_flops = float(L.mgu_unet_mfma_flops(ctx.handle, B, H, W))   # after the Winograd F(2x2,3x3) reduction
-        ach = flops * nprof / (conv_ms * 1e-3) / 1e12
-        exe = exe_flops * nprof / (conv_ms * 1e-3) / 1e12
-        # HBM bytes per launch of the same kernels from the committed PMC passes (rocprofv3 cannot run inside
-        # this process); only quoted when the workload is the one they were collected on
-        traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tj) and (B, H, W) == (8, 512, 512):
-            t = json.load(open(tj))
-            traffic, traffic_src = round(t["hbm_bytes_per_launch"]), "profiles/r01_traffic.json (" + t["correction"].split(" (")[0] + ")"
-        peak = PEAK_BF16_MFMA_TFLOPS if a.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        if a.dtype == "bf16":
-            traffic, traffic_src = None, None   # the committed PMC passes are fp32
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                "traffic_source": traffic_src, "algorithmic_flop_per_launch": round(flops / max(launches // nprof, 1)),
-                "note": ("achieved = ALGORITHMIC (direct-convolution, 2*MAC) FLOPs / kernel time; the fp32 3x3 layers run as "
-                         "Winograd F(2x2,3x3), which executes 2.25x fewer multiplies, so frac can exceed 1 -- "
-                         "executed_* are the FLOPs the matrix cores really issue against the same peak"),
-                "executed": round(exe, 2), "executed_frac": round(exe / peak, 4),
-                "executed_flop_per_launch": round(exe_flops / max(launches // nprof, 1)),
-                "kernel": ("wino3x3_f32_kernel (17 conv3x3) + conv3x3_first_kernel + igemm_kernel (4 ConvTranspose) + "
-                           "patch_mean_kernel<float,2> (1x1 head fused with the patch means): the 23 conv launches of a step"
-                           if a.dtype == "f32" else
-                           "conv3x3_halo_kernel<bf16> + igemm_kernel<bf16>: the 23 conv launches of a step"),
-                "launches_per_step": launches // nprof, "kernel_ms_per_step": round(conv_ms / nprof, 4),
-                "unet_ms_per_step_with_events": round(tot_ms / nprof, 4), "gflop_per_step": round(flops / 1e9, 2)}
+                model(x)
+            torch.cuda.synchronize(dev)
+            inst_ms = (time.perf_counter() - t1) / nprof * 1e3
+            ustats, gstats = _lib.read_kernel_stats(uctx), _lib.read_kernel_stats(gctx)
+            L.mgu_profile_enable(uctx.handle, 0)
+            L.mgu_profile_enable(gctx.handle, 0)
+        stats = merge_stats(ustats, gstats)
+        arithmetic = ("bf16 storage, fp32 accumulate" if a.dtype == "bf16" else
+                      ("fp32 operands split exactly into 3 bf16 pieces (6 bf16 MFMA products per fp32 product), fp32 accumulate"
+                       if any("wino3x3_f32_kernel<0,1>" in k["name"] for k in stats) else "exact fp32 MFMA operands"))
+        dom = next((k for k in stats if k["pipe"] >= 0 and k["flops_mfma"] > 0), None)
+        traffic = load_traffic(dom["name"], a.dtype) if dom and (B, H, W) == (8, 512, 512) else None
+        roof = roofline_from(stats, nprof, arithmetic, traffic)
+        ksum = sum(k["ms"] for k in stats) / nprof
+        timing = {"ms_per_step": round(ms_step, 4), "instrumented_ms_per_step": round(inst_ms, 4),
+                  "instrumented_kernel_ms_per_step": round(ksum, 4),
+                  "kernel_ms_per_step_scaled": round(ksum * min(1.0, ms_step / inst_ms), 4),
+                  "note": "event records between launches stretch the instrumented pass; kernel times scale with it (rocprofv3 "
+                          "--kernel-trace summaries of the same command are under profiles/)"}
+        gk = {k["name"]: round(k["ms"] * 1e3 / nprof, 2) for k in gstats}
+        gatrec = {"headline_batch": {"graphs": B, "launches_per_step": round(sum(k["launches"] for k in gstats) / nprof, 2), "kernel_us": gk}}
+        try:
+            gatrec.update(gat_record(dev, L, _lib))
+        except Exception as e:   # the record is diagnostics: never lose the headline line over it
+            gatrec["error"] = repr(e)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -270,7 +464,9 @@ def main():
                                        + "(UNet(3,2,32,4) + patch16 graph GAT(32->64,4 heads)), eval",
                            "images_per_gpu": B, "global_batch": B * world, "parallelism": f"batch-shard x{world}, no collective"},
                 "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / a.steps, 4),
-                "roofline": roof, "cpu_baseline": cpu}
+                "spread": {"windows": len(windows), "steps_per_window": a.steps, "min_ms": round(min(windows), 4),
+                           "median_ms": round(statistics.median(windows), 4), "max_ms": round(max(windows), 4)},
+                "timing": timing, "roofline": roof, "gat": gatrec, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -228,6 +228,18 @@ int mgu_gat_layer_forward(mgu_ctx* ctx, const void* X_dev, int N, int Fin,
                           const void* W_dev, const void* a_dev, int heads, int Fout_head,
                           int concat, float alpha, void* out_dev, void* hip_stream);
 
+/* Steady-state form: the weight-only preparation (W^T a rows, MFMA-fragment-order W^T or the GEMM panel) runs once per weight
+ * version, and a layer call is 2 launches when Fin <= Fout_head (st + per-graph max, then gather + aggregate + linear + ELU) or 3
+ * otherwise (GEMM [Wh | s | t], per-graph max, row gather).  has_edges: whether the graphs the handle will be used on have edges
+ * (a graph without edges -- e.g. a one-node region graph -- takes the gather schedule, whose rows come out exactly 0). */
+typedef struct mgu_gat_weights mgu_gat_weights;
+int mgu_gat_prepare(mgu_ctx* ctx, const void* W_dev, const void* a_dev, int heads, int Fout_head, int Fin, int has_edges,
+                    mgu_gat_weights** out, void* hip_stream);
+void mgu_gat_release(mgu_ctx* ctx, mgu_gat_weights* w);
+int mgu_gat_layer_forward_prepared(mgu_ctx* ctx, const mgu_gat_weights* w, const void* X_dev, int N, const int32_t* rowptr_dev,
+                                   const int32_t* col_dev, int64_t E, const int32_t* graph_ptr_dev, int num_graphs, int concat,
+                                   float alpha, void* out_dev, void* hip_stream);
+
 /* ---- MinCut stage of the patch-graph branch: replaces
  *      model/graph_partition/mincut_refinement.py:30-52 (edge weights), :55-160 (normalized-cut loss), :188-205
  *      (softmax of the segment logits + loss), scripts/train_end_to_end.py:356 (hard labels) ---------------------- */
@@ -279,6 +291,16 @@ double mgu_unet_mfma_flops(mgu_ctx* ctx, int B, int H, int W);
 /* Time the conv/GEMM kernels of the LAST mgu_unet_forward with HIP events on the launch stream:
  * enable before the forward, read after.  Adds event records only (no syncs) while enabled. */
 int mgu_profile_enable(mgu_ctx* ctx, int on);
+/* Per kernel family, summed over the launches recorded since mgu_profile_enable(ctx, 1) (U-Net forward / backward convolutions,
+ * GAT kernels): time between HIP events recorded on the launch stream right around each launch, algorithmic FLOPs (2*MAC of the
+ * operator) and the FLOPs actually issued on the matrix pipe (`pipe`: 0 fp32 MFMA, 1 bf16 MFMA, -1 none).  `name` is the kernel's
+ * name as rocprofv3 --kernel-trace prints it (template arguments included where two instantiations are used). */
+typedef struct {
+  const char* name;
+  double ms, flops_alg, flops_mfma;
+  int launches, pipe;
+} mgu_kernel_stat;
+int mgu_profile_read_kernels(mgu_ctx* ctx, mgu_kernel_stat* out, int cap, int* n_out);
 int mgu_profile_read(mgu_ctx* ctx, double* conv_ms, int* conv_launches, double* total_ms);
 
 #ifdef __cplusplus

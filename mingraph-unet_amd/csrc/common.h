@@ -74,7 +74,8 @@ struct IgemmDesc {
 inline const Tuning& tun(const IgemmDesc& d) { return d.tn ? *d.tn : default_tuning(); }
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
 bool halo_pool_fusable(const IgemmDesc& d, int dtype);   // the halo conv kernel will run: MaxPool2d(2) can ride in its epilogue
-hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s);  // in / w / out point to bf16, sizes in elements
+hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s);
+const char* igemm_kernel_name(const IgemmDesc& d, int dtype);   // the kernel family launch_igemm_* will pick (profiling records)  // in / w / out point to bf16, sizes in elements
 // elementwise.hip: first convolution (<= 4 input channels on the packed NHWC4 input), VALU + scalar-cache weights
 hipError_t launch_pack_first_w(const float* w, float* wf, int Cout, int Cin, hipStream_t s);
 bool first_conv_applicable(int dtype, int Cin, int Cp, int Cout, int ldout, int coff);
@@ -166,18 +167,19 @@ hipError_t launch_gat_wa_rows(const float* W, const float* a, float* panel, int 
 // gat_fused.hip: aggregate-first path (Fin <= F')
 bool gat_fused_applicable(int Fin, int heads, int Fh, int64_t E);
 size_t gat_fused_scratch_floats(int Fin, int heads, int Fh);
-hipError_t launch_gat_prep(const float* W, const float* a, float* wa, float* Wf, int heads, int Fh, int Fin, const int32_t* gp, int G,
-                           int N, int32_t* node_graph, unsigned* gmax, hipStream_t s);
+hipError_t launch_gat_prep(const float* W, const float* a, float* wa, float* Wf, int heads, int Fh, int Fin, hipStream_t s);
+hipError_t launch_gat_stmax(const float* x, const float* wa, int N, int Fin, int heads, const int32_t* rowptr, const int32_t* col,
+                            const int32_t* gp, int G, float alpha, float* st, int32_t* node_graph, unsigned* gmax, hipStream_t s);
 hipError_t launch_gat_st(const float* x, const float* wa, int N, int Fin, int heads, float* st, hipStream_t s);
 hipError_t launch_pack_gat_wf(const float* W, float* Wf, int heads, int Fh, int Fin, hipStream_t s);
 hipError_t launch_gat_fused(const float* x, int Fin, const float* st, const int32_t* rowptr, const int32_t* col,
                             const int32_t* node_graph, const unsigned* gmax, const float* Wf, int N, int heads, int Fh, int concat,
-                            float alpha, float* out, hipStream_t s);
+                            float alpha, float* out, unsigned* gmax_next, int gmax_next_n, hipStream_t s);
 hipError_t launch_gat_node_graph(const int32_t* gp, int G, int nodes_per_graph, int N, int32_t* node_graph, hipStream_t s);
 hipError_t launch_gat_edge_max(const float* st, const int32_t* rowptr, const int32_t* col, const int32_t* node_graph, int N,
                                int heads, float alpha, unsigned* gmax_enc, hipStream_t s);
 hipError_t launch_gat_aggregate(const float* wh, int P, const float* st, const int32_t* rowptr, const int32_t* col,
                                 const int32_t* node_graph, const unsigned* gmax_enc, int N, int heads, int Fh, int concat,
-                                float alpha, float* out, hipStream_t s);
+                                float alpha, float* out, unsigned* gmax_next, int gmax_next_n, hipStream_t s);
 
 }  // namespace mgu

@@ -55,6 +55,10 @@ struct mgu_ctx {
   int pm_patch = 0;
   void* wuws = nullptr;     // Winograd weight scratch of the mgu_conv2d_nhwc building block
   size_t wuws_bytes = 0;
+  unsigned* gmaxbuf = nullptr;   // GAT: two alternating [cap] arrays of per-(graph, head) max accumulators; the aggregate kernel of
+  int gmax_cap = 0;              // one layer call clears the array the next call accumulates into (no memset launches)
+  int gmax_cur = 0, gmax_dirty[2] = {0, 0};
+  struct mgu_gat_weights* gat_tmp = nullptr;   // weights prepared by the one-shot mgu_gat_layer_forward
   void* ncws = nullptr;     // normalized-cut accumulators (mgu_ncut_forward)
   size_t ncws_bytes = 0;
   int in_ch = 0, ncls = 0, feat = 0, depth = 0, dtype = 0, Cp0 = 0;
@@ -73,15 +77,23 @@ struct mgu_ctx {
   int tB = 0, tH = 0, tW = 0;
   std::vector<float*> t_cat, t_feat, t_pooled;
   float* t_logits = nullptr;
-  // gradient exchange (comm.hip): RCCL communicator owned by this context, its stream and a small pool of ordering events
+  void gat_destroy(mgu_ctx* c);   // gat_api.hip
+
+// gradient exchange (comm.hip): RCCL communicator owned by this context, its stream and a small pool of ordering events
   void* comm = nullptr;     // ncclComm_t
   int comm_world = 1, comm_rank = 0;
   hipStream_t comm_stream = nullptr;
   hipEvent_t comm_ev[16] = {};
   int comm_ev_next = 0;
-  // profiling
+  // profiling: HIP event pairs on the launch stream around the launches recorded since mgu_profile_enable(ctx, 1)
   bool prof = false;
   std::vector<hipEvent_t> ev;  // pairs
+  struct ProfRec {
+    const char* name;     // kernel (family) name, static storage
+    double alg, mfma;     // algorithmic FLOPs (2*MAC of the operator) / FLOPs issued on the matrix pipe
+    int pipe;             // matrix pipe: 0 = fp32 MFMA, 1 = bf16 MFMA, -1 = none (VALU / bandwidth kernels)
+  };
+  std::vector<ProfRec> prec;
   int ev_used = 0;
   hipEvent_t ev_total[2] = {nullptr, nullptr};
 };
@@ -121,12 +133,14 @@ inline int ensure(mgu_ctx* c, void** p, size_t* have, size_t need) {
   return MGU_OK;
 }
 
-struct ProfScope {  // records an event pair around one conv/GEMM launch when profiling is on
+struct ProfScope {  // records an event pair around one launch when profiling is on
   mgu_ctx* c;
   hipStream_t s;
   int idx = -1;
-  ProfScope(mgu_ctx* c_, hipStream_t s_) : c(c_), s(s_) {
+  ProfScope(mgu_ctx* c_, hipStream_t s_, const char* name = "conv/GEMM", double alg = 0, double mfma = 0, int pipe = -1) : c(c_), s(s_) {
     if (!c->prof) return;
+    if ((size_t)c->ev_used >= c->prec.size()) c->prec.resize(c->ev_used + 1);
+    c->prec[c->ev_used] = {name, alg, mfma, pipe};
     if ((size_t)(2 * c->ev_used + 2) > c->ev.size()) {
       hipEvent_t a, b;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -157,6 +171,8 @@ int run_layer(mgu_ctx* c, const Layer& L, const void* in, int ldin, int B, int H
               int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s,
               void* pool = nullptr, int ldpool = 0, bool* pool_fused = nullptr,   // optional fused MaxPool2d(2) output
               double* stat_slots = nullptr, bool* stat_fused = nullptr);          // optional fused BatchNorm batch statistics
+
+void gat_destroy(mgu_ctx* c);   // gat_api.hip
 
 // gradient exchange (comm.hip)
 int comm_bucket(mgu_ctx* c, float* flat, int64_t lo, int64_t hi, hipStream_t s);

@@ -150,8 +150,11 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
                                                             const int32_t* __restrict__ col,
                                                             const int32_t* __restrict__ node_graph,
                                                             const unsigned* __restrict__ gmax, int N, int heads, int Fh,
-                                                            int concat, float alpha, float* __restrict__ out) {
+                                                            int concat, float alpha, float* __restrict__ out,
+                                                            unsigned* __restrict__ gmax_next, int gmax_next_n) {
   constexpr int R = 4;    // rows (one CSR segment) per wavefront
+  if (blockIdx.x == 0)    // clear the max accumulators of the NEXT layer call (two alternating arrays, ctx.h)
+    for (int i = threadIdx.x; i < gmax_next_n; i += 256) gmax_next[i] = 0u;
   constexpr int EB = 8;   // row gathers in flight per lane
   __shared__ __attribute__((aligned(16))) float stage[4][NCH * 256];
   const int lane = threadIdx.x & 63;
@@ -272,14 +275,14 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
 
 hipError_t launch_gat_aggregate(const float* wh, int P, const float* st, const int32_t* rowptr, const int32_t* col,
                                 const int32_t* node_graph, const unsigned* gmax_enc, int N, int heads, int Fh, int concat,
-                                float alpha, float* out, hipStream_t s) {
+                                float alpha, float* out, unsigned* gmax_next, int gmax_next_n, hipStream_t s) {
   const int HF = heads * Fh;
   if (HF > GAT_MAX_HF || (Fh & 3) || (P & 3) || (long)N * P >= (1l << 31)) return hipErrorInvalidValue;
   if (N == 0) return hipSuccess;
   dim3 block(256);
 #define MGU_AGG(NCH)                                                                                              \
   hipLaunchKernelGGL(gat_aggregate_kernel<NCH>, dim3((N + 15) / 16), block, 0, s, wh, P, st, rowptr, col, node_graph, gmax_enc, \
-                     N, heads, Fh, concat, alpha, out)
+                     N, heads, Fh, concat, alpha, out, gmax_next, gmax_next_n)
   if (HF <= 256) MGU_AGG(1);
   else if (HF <= 512) MGU_AGG(2);
   else MGU_AGG(4);

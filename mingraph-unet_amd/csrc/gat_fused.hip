@@ -71,6 +71,116 @@ hipError_t launch_gat_st(const float* x, const float* wa, int N, int Fin, int he
   return hipGetLastError();
 }
 
+// ---- st AND the per-(graph, head) max of the attention logits in ONE launch -------------------------------------------
+// The reference takes exp(e - max over ALL edges of the graph) (graph_attention.py:86).  The max needs s of an edge's SOURCE,
+// which another workgroup may still be computing -- unless it is recomputed: s_i = (W_h^T a_src) . x_i is a Fin-long dot
+// product of a row the gather brings in anyway.  Thread j computes s_j, t_j (written to st for the aggregate kernel) and, for
+// each in-edge (i -> j), s_i again from x_i, e = LeakyReLU(s_i + t_j) (LeakyReLU is monotone: the max commutes with it), then
+// wave-reduces and issues one order-encoded atomicMax per (graph, head).  That removes the separate gat_st and gat_edge_max
+// launches and the dependent st[col[k]] round trip of the latter: a patch GAT layer is 2 launches instead of 4.
+// The node -> graph id (binary search over graph_ptr through the scalar cache) is written to node_graph for the aggregate kernel.
+__device__ __forceinline__ unsigned gf_enc_ordered(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void gat_stmax_kernel(const float* __restrict__ x, const float* __restrict__ wa, int N, int Fin,
+                                                        const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                        const int32_t* __restrict__ gp, int G, float alpha, float* __restrict__ st,
+                                                        int32_t* __restrict__ node_graph, unsigned* __restrict__ gmax) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  if (n - lane >= N) return;   // wave-uniform
+  const bool live = n < N;
+  const int nd = live ? n : N - 1;
+  const float* xr = x + (size_t)nd * Fin;
+  float s[H], t[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) s[h] = t[h] = 0.f;
+#pragma unroll 1   // (unrolled, hipcc hoists every wave-uniform weight load and spills SGPRs)
+  for (int c = 0; c < Fin; c += 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float* ws = wa + h * Fin + c;          // wave-uniform: scalar loads
+      const float* wt = wa + (H + h) * Fin + c;
+      s[h] = fmaf(v[0], ws[0], fmaf(v[1], ws[1], fmaf(v[2], ws[2], fmaf(v[3], ws[3], s[h]))));
+      t[h] = fmaf(v[0], wt[0], fmaf(v[1], wt[1], fmaf(v[2], wt[2], fmaf(v[3], wt[3], t[h]))));
+    }
+  }
+  int g = 0;
+  if (gp && G > 1) {
+    int lo = 0, hi = G;  // gp[lo] <= node < gp[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (gp[mid] <= nd) lo = mid; else hi = mid;
+    }
+    g = lo;
+  }
+  if (live) {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      st[(size_t)n * (2 * H) + h] = s[h];
+      st[(size_t)n * (2 * H) + H + h] = t[h];
+    }
+    if (node_graph) node_graph[n] = g;
+  }
+  // max over this node's in-edges of s_src (recomputed from x_src)
+  float m[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) m[h] = -INFINITY;
+  const int k0 = live ? rowptr[n] : 0, k1 = live ? rowptr[n + 1] : 0;
+#pragma unroll 1
+  for (int k = k0; k < k1; ++k) {
+    const float* xs = x + (size_t)col[k] * Fin;
+    float ss[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) ss[h] = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < Fin; c += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xs + c);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float* ws = wa + h * Fin + c;
+        ss[h] = fmaf(v[0], ws[0], fmaf(v[1], ws[1], fmaf(v[2], ws[2], fmaf(v[3], ws[3], ss[h]))));
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) m[h] = fmaxf(m[h], ss[h]);
+  }
+  const int g0 = __builtin_amdgcn_readfirstlane(g);
+  const bool uniform = __all(g == g0 || !live);
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    float e = -INFINITY;
+    if (k1 > k0) {
+      e = m[h] + t[h];
+      e = e > 0.f ? e : alpha * e;
+    }
+    if (uniform) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) e = fmaxf(e, __shfl_xor(e, off));
+      if (lane == 0 && e > -INFINITY) atomicMax(&gmax[g0 * H + h], gf_enc_ordered(e));
+    } else if (e > -INFINITY) {
+      atomicMax(&gmax[g * H + h], gf_enc_ordered(e));
+    }
+  }
+}
+
+hipError_t launch_gat_stmax(const float* x, const float* wa, int N, int Fin, int heads, const int32_t* rowptr, const int32_t* col,
+                            const int32_t* gp, int G, float alpha, float* st, int32_t* node_graph, unsigned* gmax, hipStream_t s) {
+  if (N == 0) return hipSuccess;
+  const dim3 grid((N + 255) / 256), block(256);
+  switch (heads) {
+    case 1: hipLaunchKernelGGL(gat_stmax_kernel<1>, grid, block, 0, s, x, wa, N, Fin, rowptr, col, gp, G, alpha, st, node_graph, gmax); break;
+    case 2: hipLaunchKernelGGL(gat_stmax_kernel<2>, grid, block, 0, s, x, wa, N, Fin, rowptr, col, gp, G, alpha, st, node_graph, gmax); break;
+    case 4: hipLaunchKernelGGL(gat_stmax_kernel<4>, grid, block, 0, s, x, wa, N, Fin, rowptr, col, gp, G, alpha, st, node_graph, gmax); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 // ---- W_h^T in MFMA-fragment order: Wf[h][nt][kk][lane (kh = lane>>5, n = lane&31)][t] = W[h*Fh + 32 nt + n][8 kk + 4 kh + t]
 __global__ void pack_gat_wf_kernel(const float* __restrict__ W, float* __restrict__ Wf, int heads, int Fh, int Fin) {
   const int total = heads * Fh * Fin;
@@ -91,8 +201,7 @@ hipError_t launch_pack_gat_wf(const float* W, float* Wf, int heads, int Fh, int 
   return hipGetLastError();
 }
 
-// ---- everything that depends only on the layer's weights and the batch layout, in ONE launch ----------------------
-// (four ~5 us launch-bound kernels otherwise: W^T a rows, fragment-order W^T, node -> graph table, max reset)
+// ---- everything that depends only on the layer's weights, in ONE launch (mgu_gat_prepare: once per weight version) ----
 __device__ __forceinline__ int gf_graph_of(const int32_t* __restrict__ gp, int G, int node) {
   int lo = 0, hi = G;  // gp[lo] <= node < gp[hi]
   while (hi - lo > 1) {
@@ -103,9 +212,7 @@ __device__ __forceinline__ int gf_graph_of(const int32_t* __restrict__ gp, int G
 }
 
 __global__ __launch_bounds__(256) void gat_prep_kernel(const float* __restrict__ W, const float* __restrict__ a, float* __restrict__ wa,
-                                                       float* __restrict__ Wf, int heads, int Fh, int Fin, const int32_t* __restrict__ gp,
-                                                       int G, int N, int32_t* __restrict__ node_graph, unsigned* __restrict__ gmax,
-                                                       int nb_wf, int nb_ng) {
+                                                       float* __restrict__ Wf, int heads, int Fh, int Fin, int nb_wf) {
   const int b = blockIdx.x, t = threadIdx.x;
   if (b < 2 * heads) {
     // wa[r][k] = sum_f a[h][which*Fh + f] * W[h*Fh + f][k],  r = which*heads + h  (W_h^T a_src | W_h^T a_tgt)
@@ -133,20 +240,12 @@ __global__ __launch_bounds__(256) void gat_prep_kernel(const float* __restrict__
       const int nt = rest % nnt, h = rest / nnt;
       Wf[i] = W[(size_t)(h * Fh + 32 * nt + (lane & 31)) * Fin + 8 * kk + 4 * (lane >> 5) + tt];
     }
-  } else if (b < 2 * heads + nb_wf + nb_ng) {
-    const int j = (b - 2 * heads - nb_wf) * 256 + t;
-    if (j < N) node_graph[j] = gf_graph_of(gp, G, j);
-  } else {
-    for (int i = t; i < G * heads; i += 256) gmax[i] = 0u;
   }
 }
 
-// node_graph may be nullptr (single graph): then no table is built
-hipError_t launch_gat_prep(const float* W, const float* a, float* wa, float* Wf, int heads, int Fh, int Fin, const int32_t* gp, int G,
-                           int N, int32_t* node_graph, unsigned* gmax, hipStream_t s) {
-  const int nb_wf = (heads * Fh * Fin + 255) / 256, nb_ng = node_graph ? (N + 255) / 256 : 0;
-  hipLaunchKernelGGL(gat_prep_kernel, dim3(2 * heads + nb_wf + nb_ng + 1), dim3(256), 0, s, W, a, wa, Wf, heads, Fh, Fin, gp, G, N,
-                     node_graph, gmax, nb_wf, nb_ng);
+hipError_t launch_gat_prep(const float* W, const float* a, float* wa, float* Wf, int heads, int Fh, int Fin, hipStream_t s) {
+  const int nb_wf = (heads * Fh * Fin + 255) / 256;
+  hipLaunchKernelGGL(gat_prep_kernel, dim3(2 * heads + nb_wf), dim3(256), 0, s, W, a, wa, Wf, heads, Fh, Fin, nb_wf);
   return hipGetLastError();
 }
 
@@ -158,7 +257,8 @@ __global__ __launch_bounds__(64 * H) void gat_fused_kernel(const float* __restri
                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                            const int32_t* __restrict__ node_graph,
                                                            const unsigned* __restrict__ gmax, const float* __restrict__ Wf,
-                                                           int N, int concat, float alpha, float* __restrict__ out) {
+                                                           int N, int concat, float alpha, float* __restrict__ out,
+                                                           unsigned* __restrict__ gmax_next, int gmax_next_n) {
   constexpr int LPN = FIN / 4;        // lanes per node in the gather (each a 16-byte slice of the input row)
   constexpr int NPP = 64 / LPN;       // nodes per gather pass
   constexpr int PASSES = 32 / NPP;
@@ -171,6 +271,10 @@ __global__ __launch_bounds__(64 * H) void gat_fused_kernel(const float* __restri
   const int lane = threadIdx.x & 63;
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // this wave's head
   float* agg = agg_s[h];
+  // the max accumulators alternate between two buffers: this launch clears the one the NEXT layer call accumulates into
+  // (nothing of this launch reads it), so no call needs a memset node in front of its atomicMax kernel
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < gmax_next_n; i += 64 * H) gmax_next[i] = 0u;
 
   // XCD-aware order: workgroup b runs on XCD b % 8; give each XCD a contiguous range of node tiles so neighbouring
   // patch rows (j +- 1, j +- npw) are served by the same L2
@@ -292,18 +396,19 @@ size_t gat_fused_scratch_floats(int Fin, int heads, int Fh) { return (size_t)hea
 template <int FIN, int NT, int H>
 static hipError_t launch_fused_t(const float* x, const float* st, const int32_t* rowptr, const int32_t* col,
                                  const int32_t* node_graph, const unsigned* gmax, const float* Wf, int N, int concat, float alpha,
-                                 float* out, hipStream_t s) {
+                                 float* out, unsigned* gmax_next, int gmax_next_n, hipStream_t s) {
   const int ntiles = (N + 31) / 32;
   hipLaunchKernelGGL((gat_fused_kernel<FIN, NT, H>), dim3(ntiles), dim3(64 * H), 0, s, x, st, rowptr, col, node_graph, gmax, Wf, N,
-                     concat, alpha, out);
+                     concat, alpha, out, gmax_next, gmax_next_n);
   return hipGetLastError();
 }
 
 hipError_t launch_gat_fused(const float* x, int Fin, const float* st, const int32_t* rowptr, const int32_t* col,
                             const int32_t* node_graph, const unsigned* gmax, const float* Wf, int N, int heads, int Fh, int concat,
-                            float alpha, float* out, hipStream_t s) {
+                            float alpha, float* out, unsigned* gmax_next, int gmax_next_n, hipStream_t s) {
   if (N == 0) return hipSuccess;
-#define MGU_GF(FIN, NT, H) return launch_fused_t<FIN, NT, H>(x, st, rowptr, col, node_graph, gmax, Wf, N, concat, alpha, out, s)
+#define MGU_GF(FIN, NT, H) \
+  return launch_fused_t<FIN, NT, H>(x, st, rowptr, col, node_graph, gmax, Wf, N, concat, alpha, out, gmax_next, gmax_next_n, s)
 #define MGU_GF_H(FIN, NT)      \
   do {                         \
     if (heads == 1) MGU_GF(FIN, NT, 1); \

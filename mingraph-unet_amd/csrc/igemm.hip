@@ -603,6 +603,21 @@ bool halo_pool_fusable(const IgemmDesc& d, int dtype) {
   return dtype == 0 ? (!wino_applicable(d) && halo_np<float>(d) == 8) : halo_np<__bf16>(d) != 0;
 }
 
+const char* igemm_kernel_name(const IgemmDesc& d, int dtype) {
+  if (dtype == 1) {
+    if (d.out_mode == 1) return "igemm_kernel<bf16> (ConvTranspose)";
+    return halo_np<__bf16>(d) ? "conv3x3_halo_kernel<bf16>" : "igemm_kernel<bf16>";
+  }
+  if (d.out_mode == 1) return "igemm_kernel<f32> (ConvTranspose)";
+  if (wino_applicable(d)) {
+    const bool wide = d.N > 32 && tun(d).wino_mode != 1;
+    if (tun(d).wino_prec) return wide ? "wino3x3_f32_kernel<0,1>" : "wino3x3_f32_kernel<1,1>";
+    return wide ? "wino3x3_f32_kernel<0,0>" : "wino3x3_f32_kernel<1,0>";
+  }
+  if (halo_np<float>(d) == 8) return "conv3x3_halo_kernel<f32>";
+  return d.KS == 2 ? "igemm_kernel<f32> (ConvTranspose dgrad)" : "igemm_kernel<f32>";
+}
+
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s) {
   if (d.M <= 0 || d.N <= 0) return hipSuccess;
   if ((d.Cp & 3) || (d.ldin & 3) || (d.Kp % 32) || d.K > d.Kp) return hipErrorInvalidValue;

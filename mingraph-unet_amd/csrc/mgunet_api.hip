@@ -94,6 +94,7 @@ void mgu_destroy(mgu_ctx* c) {
   if (c->redws) (void)hipFree(c->redws);
   if (c->wuws) (void)hipFree(c->wuws);
   if (c->ncws) (void)hipFree(c->ncws);
+  gat_destroy(c);
   if (c->err_word) (void)hipHostFree(c->err_word);
   for (auto e : c->ev) (void)hipEventDestroy(e);
   for (auto e : c->ev_total)
@@ -356,7 +357,7 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
   if (stat_fused) *stat_fused = false;
   if (L.wf && ldin == L.Cp && first_conv_applicable(c->dtype, L.Cin, L.Cp, L.Cout, ldout, coff) &&
       (int64_t)B * H * W * std::max(ldout, 8) < (1ll << 31)) {
-    ProfScope ps(c, s);
+    ProfScope ps(c, s, "conv3x3_first_kernel", 2.0 * d.M * 9.0 * L.Cin * L.Cout, 0, -1);
     HIPCHK(c, launch_first_conv(c->dtype, in_v, L.wf, scale, shift, out_v, B, H, W, L.Cin, L.Cout, ldout, coff, relu, s));
     return MGU_OK;
   }
@@ -373,7 +374,16 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
     HIPCHK(c, launch_pack_conv_w(L.w_src, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
     L.wp_dirty = false;
   }
-  ProfScope ps(c, s);
+  // profiling record: algorithmic 2*MAC of the operator and what the matrix pipe really issues (Winograd F(2x2,3x3): 16 products
+  // per 2x2 tile and channel pair; the three-piece operand split issues six bf16 products per fp32 product)
+  const double alg = L.convt ? 2.0 * d.M * (double)L.Cin * L.Cout * 4.0 : 2.0 * d.M * (double)L.KS * L.KS * L.Cin * L.Cout;
+  double mfma = L.convt ? alg : 2.0 * d.M * (double)L.K * L.Cout;
+  int pipe = c->dtype == MGU_DTYPE_BF16 ? 1 : 0;
+  if (c->dtype == MGU_DTYPE_F32 && wino_applicable(d)) {
+    mfma = 2.0 * B * ((H + 1) / 2) * ((W + 1) / 2) * 16.0 * L.Cp * L.Cout * (c->tn.wino_prec ? 6.0 : 1.0);
+    pipe = c->tn.wino_prec ? 1 : 0;
+  }
+  ProfScope ps(c, s, igemm_kernel_name(d, c->dtype), alg, mfma, pipe);
   if (c->dtype == MGU_DTYPE_BF16) HIPCHK(c, launch_igemm_bf16(d, s));
   else HIPCHK(c, launch_igemm_f32(d, s));
   return MGU_OK;
@@ -429,7 +439,6 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
   level_dims(H, W, depth, hs, wsz);
 
   if (c->prof) {
-    c->ev_used = 0;
     for (auto& e : c->ev_total)
       if (!e) HIPCHK(c, hipEventCreate(&e));
     HIPCHK(c, hipEventRecord(c->ev_total[0], s));
@@ -479,12 +488,12 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
     const int pm_dtype = c->dtype;   // decoder features are stored in the compute dtype
     if (c->pm_out && F.w_src && F.b_src && patch_mean_head_fusable(pm_dtype, F.Cin, c->ncls) && F.Cin <= 256) {
       // requested patch means + the 1x1 head in ONE pass over the decoder feature (both are pure bandwidth)
-      ProfScope ps(c, s);
+      ProfScope ps(c, s, "patch_mean_kernel (1x1 head + patch means)", 2.0 * B * H * W * F.Cin * c->ncls, 0, -1);
       HIPCHK(c, launch_patch_mean(cur, pm_dtype, (float*)c->pm_out, B, H, W, F.Cin, c->pm_patch, s, F.w_src, F.b_src,
                                   (float*)logits_dev, c->ncls));
       c->pm_out = nullptr;
     } else if (c->ncls <= 4 && F.w_src && F.b_src) {
-      ProfScope ps(c, s);
+      ProfScope ps(c, s, "conv1x1_head_kernel", 2.0 * B * H * W * F.Cin * c->ncls, 0, -1);
       HIPCHK(c, launch_conv1x1_head(cur, c->dtype, cur_ld, F.Cin, F.w_src, F.b_src, (float*)logits_dev, c->ncls, c->ncls,
                                     (int64_t)B * H * W, s));   // logits are always fp32
     } else if ((rc = run_conv(c, F, cur, cur_ld, B, H, W, logits_dev, c->ncls, 0, 0, 0, 0, s))) {
@@ -703,97 +712,6 @@ int mgu_patch_mean(mgu_ctx* c, const void* feat_dev, int feat_dtype, int B, int 
   return MGU_OK;
 }
 
-int mgu_gat_layer_forward(mgu_ctx* c, const void* X_dev, int N, int Fin, const int32_t* rowptr_dev,
-                          const int32_t* col_dev, int64_t E, const int32_t* graph_ptr_dev, int num_graphs,
-                          const void* W_dev, const void* a_dev, int heads, int Fout_head, int concat, float alpha,
-                          void* out_dev, void* hip_stream) {
-  if (!c) return MGU_ERR_INVALID;
-  if (N < 0 || E < 0 || heads < 1 || heads > 32 || Fout_head < 4 || (Fout_head & 3) || Fin < 4 || (Fin & 3))
-    return fail(c, MGU_ERR_INVALID, "GAT layer needs Fin %% 4 == 0, Fout_head %% 4 == 0, 1 <= heads <= 32 (Fin=%d Fout=%d heads=%d)",
-                Fin, Fout_head, heads);
-  const int HF = heads * Fout_head;
-  if (HF > 1024) return fail(c, MGU_ERR_INVALID, "heads*Fout_head = %d exceeds 1024", HF);
-  if (N == 0) return MGU_OK;
-  if (!X_dev || !rowptr_dev || !W_dev || !a_dev || !out_dev || (E > 0 && !col_dev)) return fail(c, MGU_ERR_INVALID, "NULL buffer");
-  if (num_graphs < 1) num_graphs = 1;
-  HIPCHK(c, hipSetDevice(c->device));
-  hipStream_t s = (hipStream_t)hip_stream;
-  if (c->tn.gat_fused && gat_fused_applicable(Fin, heads, Fout_head, E)) {
-    // aggregate-first path (gat_fused.hip): no (N, heads*F') node table, the gather moves Fin floats per edge
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-      size_t o = off;
-      off += (bytes + 255) / 256 * 256;
-      return o;
-    };
-    const size_t o_st = take((size_t)N * 2 * heads * 4), o_wa = take((size_t)2 * heads * Fin * 4);
-    const size_t o_wf = take((size_t)HF * Fin * 4), o_gm = take((size_t)num_graphs * heads * 4), o_ng = take((size_t)N * 4);
-    int rc = ensure(c, &c->gws, &c->gws_bytes, off);
-    if (rc) return rc;
-    char* g = (char*)c->gws;
-    float* st = (float*)(g + o_st);
-    float* wa = (float*)(g + o_wa);
-    float* wf = (float*)(g + o_wf);
-    unsigned* gmax = (unsigned*)(g + o_gm);
-    int32_t* node_graph = (num_graphs > 1 && graph_ptr_dev) ? (int32_t*)(g + o_ng) : nullptr;   // node -> graph id (NULL: one graph)
-    HIPCHK(c, launch_gat_prep((const float*)W_dev, (const float*)a_dev, wa, wf, heads, Fout_head, Fin, graph_ptr_dev, num_graphs, N,
-                              node_graph, gmax, s));
-    HIPCHK(c, launch_gat_st((const float*)X_dev, wa, N, Fin, heads, st, s));
-    HIPCHK(c, launch_gat_edge_max(st, rowptr_dev, col_dev, node_graph, N, heads, alpha, gmax, s));
-    ProfScope ps(c, s);
-    HIPCHK(c, launch_gat_fused((const float*)X_dev, Fin, st, rowptr_dev, col_dev, node_graph, gmax, wf, N, heads, Fout_head, concat,
-                               alpha, (float*)out_dev, s));
-    return MGU_OK;
-  }
-  // scratch: Wh (N, HF) node table | st (N, 2H) attention scalars | packed panel (NPp, Kp) | gmax (G, heads)
-  const int Kp = rup(Fin, 32), NP = HF + 2 * heads, P = HF, NPp = rup(NP, 128);
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    size_t o = off;
-    off += (bytes + 255) / 256 * 256;
-    return o;
-  };
-  const size_t o_wh = take((size_t)N * P * 4), o_st = take((size_t)N * 2 * heads * 4);
-  const size_t o_wp = take((size_t)NPp * Kp * 4), o_gm = take((size_t)num_graphs * heads * 4);
-  const size_t o_ng = take((size_t)N * 4);
-  int rc = ensure(c, &c->gws, &c->gws_bytes, off);
-  if (rc) return rc;
-  char* g = (char*)c->gws;
-  float* Whp = (float*)(g + o_wh);
-  float* st = (float*)(g + o_st);
-  float* wp = (float*)(g + o_wp);
-  unsigned* gmax = (unsigned*)(g + o_gm);
-  HIPCHK(c, hipMemsetAsync(wp, 0, (size_t)NPp * Kp * 4, s));
-  HIPCHK(c, hipMemsetAsync(gmax, 0, (size_t)num_graphs * heads * 4, s));
-  // nn.Linear weight (F',Fin) stacked over heads is already the [N][K] panel (K padded to 32); rows HF.. hold
-  // W^T a_src / W^T a_tgt so the same GEMM emits the attention scalars s, t (graph_attention.py:53,57-64)
-  HIPCHK(c, launch_pack_conv_w((const float*)W_dev, wp, 0, HF, Fin, Fin, 1, Kp, s));
-  HIPCHK(c, launch_gat_wa_rows((const float*)W_dev, (const float*)a_dev, wp, HF, heads, Fout_head, Fin, Kp, s));
-  IgemmDesc d;
-  memset(&d, 0, sizeof d);
-  d.tn = &c->tn;
-  d.in = (const float*)X_dev;
-  d.w = wp;
-  d.out = Whp;
-  d.M = N, d.H = 1, d.W = N;
-  d.Cp = Fin, d.ldin = Fin, d.KS = 1, d.K = Fin, d.Kp = Kp;
-  d.N = NP, d.ldout = P;
-  d.split_n = HF, d.out2 = st, d.ld2 = 2 * heads;
-  {
-    ProfScope ps(c, s);
-    HIPCHK(c, launch_igemm_f32(d, s));
-  }
-  int32_t* node_graph = nullptr;  // node -> graph id (NULL: a single graph)
-  if (num_graphs > 1 && graph_ptr_dev) {
-    node_graph = (int32_t*)(g + o_ng);
-    HIPCHK(c, launch_gat_node_graph(graph_ptr_dev, num_graphs, 0, N, node_graph, s));
-  }
-  HIPCHK(c, launch_gat_edge_max(st, rowptr_dev, col_dev, node_graph, N, heads, alpha, gmax, s));
-  HIPCHK(c, launch_gat_aggregate(Whp, P, st, rowptr_dev, col_dev, node_graph, gmax, N, heads, Fout_head, concat, alpha,
-                                 (float*)out_dev, s));
-  return MGU_OK;
-}
-
 double mgu_unet_flops(mgu_ctx* c, int B, int H, int W) {
   if (!c || !c->configured) return -1.0;
   std::vector<int> hs, wsz;
@@ -844,6 +762,27 @@ int mgu_profile_enable(mgu_ctx* c, int on) {
   if (!c) return MGU_ERR_INVALID;
   c->prof = on != 0;
   c->ev_used = 0;
+  return MGU_OK;
+}
+
+int mgu_profile_read_kernels(mgu_ctx* c, mgu_kernel_stat* out, int cap, int* n_out) {
+  if (!c || !n_out || (cap > 0 && !out)) return MGU_ERR_INVALID;
+  int n = 0;
+  for (int i = 0; i < c->ev_used; ++i) {
+    float ms = 0;
+    HIPCHK(c, hipEventSynchronize(c->ev[2 * i + 1]));
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]));
+    const mgu_ctx::ProfRec& r = c->prec[i];
+    int k = 0;
+    while (k < n && strcmp(out[k].name, r.name) != 0) ++k;
+    if (k == n) {
+      if (n == cap) continue;   // table full: the remaining families are dropped (cap >= 32 holds every family of a step)
+      out[n].name = r.name, out[n].ms = 0, out[n].flops_alg = 0, out[n].flops_mfma = 0, out[n].launches = 0, out[n].pipe = r.pipe;
+      ++n;
+    }
+    out[k].ms += ms, out[k].flops_alg += r.alg, out[k].flops_mfma += r.mfma, out[k].launches += 1;
+  }
+  *n_out = n;
   return MGU_OK;
 }
 

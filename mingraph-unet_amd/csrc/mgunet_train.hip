@@ -125,7 +125,10 @@ int conv_wgrad(Bwd& w, const Layer& L, const float* dz) {
   d.dw = w.dwp;
   d.dw_capacity = w.dwp_floats;
   {
-    ProfScope ps(c, w.s);
+    const double alg = 2.0 * d.M * (double)L.KS * L.KS * L.Cin * L.Cout;
+    const bool ww = wino_wgrad_applicable(d) && !wgrad_thin_applicable(d);
+    ProfScope ps(c, w.s, wgrad_thin_applicable(d) ? "wgrad_thin kernels" : ww ? "wino_wgrad_f32_kernel" : "wgrad (direct) kernels", alg,
+                 ww ? alg * 16.0 / 36.0 : alg, wgrad_thin_applicable(d) ? -1 : 0);
     HIPCHK(c, launch_wgrad_f32(d, w.s));
   }
   HIPCHK(c, launch_unpack_conv_grad(w.dwp, d.groups, (size_t)d.N * d.Kp, w.flat + L.off_w, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, w.s));
@@ -150,8 +153,15 @@ int conv_dgrad(Bwd& w, const Layer& L, const float* dz, float* out, int ldout) {
   // only the weight form the chosen kernel reads is built: Winograd U or the direct flipped/transposed panel
   if (wino_applicable(d)) HIPCHK(c, launch_pack_wino_w(L.w_src, w.wug, L.Cin, L.Cout, Cop, 1, c->tn.wino_prec, w.s));
   else HIPCHK(c, launch_pack_dgrad_w(L.w_src, w.dgp, L.Cout, L.Cin, Cop, L.KS, Kpd, w.s));
-  ProfScope ps(c, w.s);
-  HIPCHK(c, launch_igemm_f32(d, w.s));
+  {
+    const double alg = 2.0 * d.M * (double)L.KS * L.KS * L.Cin * L.Cout;
+    const bool wn = wino_applicable(d);
+    double mfma = 2.0 * d.M * (double)d.K * d.N;
+    if (wn) mfma = 2.0 * L.t_B * ((L.t_H + 1) / 2) * ((L.t_W + 1) / 2) * 16.0 * d.Cp * d.N * (c->tn.wino_prec ? 6.0 : 1.0);
+    ProfScope ps(c, w.s, wn ? (c->tn.wino_prec ? "wino3x3_f32_kernel<*,1> (dgrad)" : "wino3x3_f32_kernel<*,0> (dgrad)") : "igemm/halo (dgrad)", alg,
+                 mfma, wn && c->tn.wino_prec ? 1 : 0);
+    HIPCHK(c, launch_igemm_f32(d, w.s));
+  }
   return MGU_OK;
 }
 

@@ -20,6 +20,20 @@ class TensorDesc(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ptr", C.c_void_p), ("numel", C.c_int64)]
 
 
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("flops_alg", C.c_double), ("flops_mfma", C.c_double),
+                ("launches", C.c_int), ("pipe", C.c_int)]
+
+
+def read_kernel_stats(ctx) -> list:
+    """mgu_profile_read_kernels as a list of dicts (per kernel family since mgu_profile_enable(ctx, 1))."""
+    arr = (KernelStat * 64)()
+    n = C.c_int()
+    check(lib().mgu_profile_read_kernels(ctx.handle, arr, 64, C.byref(n)), ctx.handle)
+    return [{"name": arr[i].name.decode(), "ms": arr[i].ms, "flops_alg": arr[i].flops_alg, "flops_mfma": arr[i].flops_mfma,
+             "launches": arr[i].launches, "pipe": arr[i].pipe} for i in range(n.value)]
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -85,6 +99,10 @@ _PROTOS = {
     "mgu_gat_layer_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_float, C.c_void_p, C.c_void_p]),
+    "mgu_gat_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
+    "mgu_gat_release": (None, [C.c_void_p, C.c_void_p]),
+    "mgu_gat_layer_forward_prepared": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                                 C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "mgu_ncut_edge_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "mgu_ncut_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -99,6 +117,7 @@ _PROTOS = {
     "mgu_unet_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgu_unet_mfma_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mgu_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "mgu_profile_read_kernels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "mgu_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
 }
 

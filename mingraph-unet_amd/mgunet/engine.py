@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .gat import GATNetwork, _context, _csr_cache, stacked_head_weights
+from .gat import GATNetwork, _context, _csr_cache, prepared_head_weights, stacked_head_weights
 from .patch_graph import PatchGraphConstructor
 from .unet import UNet
 
@@ -104,12 +104,13 @@ def gat_forward_csr(gat: GATNetwork, X, rowptr, col, graph_ptr):
             raise ValueError("node feature width must be a multiple of 4 and match W")
         h = h.contiguous()
         out = torch.empty((h.shape[0], H * Fh if layer.concat else Fh), device=dev, dtype=torch.float32)
+        handle = prepared_head_weights(heads, _csr_cache(layer), ctx, dev, col.numel() > 0)
         with torch.cuda.device(dev):
-            rc = _lib.lib().mgu_gat_layer_forward(ctx.handle, h.data_ptr(), h.shape[0], h.shape[1], rowptr.data_ptr(),
-                                                  col.data_ptr() if col.numel() else None, col.numel(),
-                                                  graph_ptr.data_ptr() if graph_ptr is not None else None, G,
-                                                  W.data_ptr(), a.data_ptr(), H, Fh, 1 if layer.concat else 0,
-                                                  float(layer.alpha), out.data_ptr(), _lib.current_stream_ptr(dev))
+            rc = _lib.lib().mgu_gat_layer_forward_prepared(ctx.handle, handle, h.data_ptr(), h.shape[0], rowptr.data_ptr(),
+                                                           col.data_ptr() if col.numel() else None, col.numel(),
+                                                           graph_ptr.data_ptr() if graph_ptr is not None else None, G,
+                                                           1 if layer.concat else 0, float(layer.alpha), out.data_ptr(),
+                                                           _lib.current_stream_ptr(dev))
         _lib.check(rc, ctx.handle)
         h = out
     return h

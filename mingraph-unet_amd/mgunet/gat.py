@@ -93,6 +93,37 @@ def stacked_head_weights(heads, cache):
     return ent[1], ent[2]
 
 
+class _Prepared:
+    """A mgu_gat_weights handle (the layer's weight-only preparation) tied to the weight versions it was built from."""
+
+    def __init__(self, ctx, handle, sig):
+        self.ctx, self.handle, self.sig = ctx, handle, sig
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().mgu_gat_release(self.ctx.handle, self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def prepared_head_weights(heads, cache, ctx, dev, has_edges: bool):
+    """mgu_gat_prepare once per (weight versions, device, has_edges): W^T a rows + fragment-order W^T (or the GEMM panel)."""
+    import ctypes as C
+    W, a = stacked_head_weights(heads, cache)
+    sig = (cache["weights"][0], str(dev), bool(has_edges))
+    ent = cache.get("prepared")
+    if ent is None or ent.sig != sig:
+        Fh = (heads[0].out_features + 3) // 4 * 4
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgu_gat_prepare(ctx.handle, W.data_ptr(), a.data_ptr(), len(heads), Fh, W.shape[1], 1 if has_edges else 0,
+                                                  C.byref(h), _lib.current_stream_ptr(dev)), ctx.handle)
+        ent = cache["prepared"] = _Prepared(ctx, h, sig)
+    return ent.handle
+
+
 def _gat_layer_forward(heads, X, edge_index, concat, alpha, training, dropout_rate, graph_ptr, cache):
     if training and dropout_rate > 0:
         raise RuntimeError("train-mode GAT applies torch-RNG dropout to attention coefficients "
@@ -127,11 +158,14 @@ def _gat_layer_forward(heads, X, edge_index, concat, alpha, training, dropout_ra
         G, gp_ptr = gp.numel() - 1, gp.data_ptr()
     out = torch.empty((N, H * Fh if concat else Fh), device=dev, dtype=torch.float32)
     ctx = _context(dev)
+    if W.device != dev:
+        raise RuntimeError(f"GAT parameters are on {W.device}, node features on {dev}")
+    handle = prepared_head_weights(heads, cache, ctx, dev, col.numel() > 0)
     with torch.cuda.device(dev):
-        rc = _lib.lib().mgu_gat_layer_forward(ctx.handle, Xc.data_ptr(), N, Xc.shape[1], rowptr.data_ptr(),
-                                              col.data_ptr() if col.numel() else None, col.numel(), gp_ptr, G,
-                                              W.data_ptr(), a.data_ptr(), H, Fh, 1 if concat else 0, float(alpha),
-                                              out.data_ptr(), _lib.current_stream_ptr(dev))
+        rc = _lib.lib().mgu_gat_layer_forward_prepared(ctx.handle, handle, Xc.data_ptr(), N, rowptr.data_ptr(),
+                                                       col.data_ptr() if col.numel() else None, col.numel(), gp_ptr, G,
+                                                       1 if concat else 0, float(alpha), out.data_ptr(),
+                                                       _lib.current_stream_ptr(dev))
     _lib.check(rc, ctx.handle)
     if Fh != Fh_true:
         out = out.view(N, -1, Fh)[:, :, :Fh_true].reshape(N, -1).contiguous()

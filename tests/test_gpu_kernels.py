@@ -125,17 +125,17 @@ def test_winograd_conv_vs_torch_and_direct(cuda, B, H, W, Cin, Cout, monkeypatch
     assert not torch.equal(wino, direct)   # the two paths really are different kernels
 
 
-@pytest.mark.parametrize("prec", ["1", "2"])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [
     (2, 12, 10, 64, 64),    # 64-channel work split, four chunks
     (1, 9, 70, 32, 96),     # ragged patches, N tail
     (1, 31, 33, 128, 32),   # the 32-channel work split
-    (1, 8, 32, 48, 40),     # odd chunk count: mode 2 falls back to the mode-1 kernel
+    (1, 8, 32, 48, 40),     # odd chunk count
 ])
-def test_winograd_three_piece_operand_modes(cuda, B, H, W, Cin, Cout, prec, monkeypatch):
-    """MGU_WINO_PREC=1/2 (read at mgu_create): every fp32 operand of the 16 Winograd GEMMs is split exactly into three
-    bf16 pieces and multiplied on the bf16 MFMA with fp32 accumulation (csrc/wino_f32.hip PREC 1, csrc/wino_x3.hip).
-    Same tolerance as the fp32-MFMA kernel: the six kept piece products lose less than one fp32 rounding."""
+def test_winograd_three_piece_vs_fp32_mfma_operands(cuda, B, H, W, Cin, Cout, monkeypatch):
+    """The default (MGU_WINO_PREC=1, read at mgu_create): every fp32 operand of the 16 Winograd GEMMs is split exactly into
+    three bf16 pieces and multiplied on the bf16 MFMA with fp32 accumulation (csrc/wino_f32.hip PREC 1), against the same
+    kernel on v_mfma_f32_32x32x2_f32 operands (MGU_WINO_PREC=0).  Same tolerance for both: the six kept piece products lose
+    less than one fp32 rounding.  (Adversarial operands: test_gpu_backward_kernels.py::test_three_piece_split_adversarial.)"""
     if os.environ.get("MGU_NO_WINOGRAD") or os.environ.get("MGU_WINO_PREC"):
         pytest.skip("an A/B of these switches: meaningless when one of them is forced for the whole run")
     x = torch.from_numpy(O.formula_normal("k3/x", (B, Cin, H, W), seed=H))
@@ -148,13 +148,13 @@ def test_winograd_three_piece_operand_modes(cuda, B, H, W, Cin, Cout, prec, monk
     from mgunet import gat as G
 
     def run():
-        G._CTX.clear()   # new mgu_ctx: the environment switch is read by mgu_create
+        G._CTX.clear()   # new mgu_ctx: the switch is read by mgu_create and lives in the context
         got = conv_gpu(cuda, x, w, b, 3, 1, ld_out=Cout + 8, c_off=4, scale=sc, shift=sh)
         return got[..., 4:4 + Cout].permute(0, 3, 1, 2).double()
 
-    base = run()
-    monkeypatch.setenv("MGU_WINO_PREC", prec)
     split = run()
+    monkeypatch.setenv("MGU_WINO_PREC", "0")
+    base = run()
     monkeypatch.delenv("MGU_WINO_PREC")
     G._CTX.clear()
     _context(cuda)   # back to the default for the rest of the process

@@ -128,8 +128,11 @@ def test_c5_step_record_from_reference(cuda, golden, tag, shape):
     gn = np.array([float(params[k].grad.norm()) for k in names])
     # Conditioning: train-mode BatchNorm + ReLU masks make these gradients sensitive to 1e-7 perturbations; the
     # reference's OWN fp32 gradients sit `cond` (5e-3 .. 9e-3 relative L2) away from its float64 gradients
-    # (recorded by oracle/make_golden.py).  The HIP path must be as close to the float64 truth as the reference's
-    # fp32 path is: per-parameter norm within (2*cond + 1e-3), sampled elements within (2*max cond + 2e-3)*max|g|.
+    # (recorded by oracle/make_golden.py).  The KERNELS are held to 2e-5 against float64 one by one in
+    # test_gpu_backward_kernels.py, where nothing is ill-conditioned; this whole-step record is the integration check: the
+    # HIP path must be as close to the float64 truth as the reference's fp32 path is: per-parameter norm within
+    # (2*cond + 1e-3) (measured worst deviation 2.7e-3 / 1.2e-3), sampled elements within (2*max cond + 2e-3)*max|g|, and the
+    # aggregate error within 1.25x the reference's own.
     ref_gn, cond = g[f"{tag}_grad_norms64"], g[f"{tag}_cond"]
     big = ref_gn > 1e-4 * ref_gn.max()          # conv biases under BatchNorm have analytically zero gradient
     rel = np.abs(gn[big] / ref_gn[big] - 1)
@@ -145,7 +148,7 @@ def test_c5_step_record_from_reference(cuda, golden, tag, shape):
     err_ref = np.linalg.norm(g[f"{tag}_grad_s"] - ref_s) / np.linalg.norm(ref_s)
     print(f"[c5/{tag}] loss {float(loss):.6f} (ref {ref_loss:.6f}); sampled-grad rel L2 error vs float64: HIP {err_hip:.2e}, "
           f"reference fp32 {err_ref:.2e}; worst norm dev {rel.max():.2e}")
-    assert err_hip <= 2.0 * err_ref + 1e-4
+    assert err_hip <= 1.25 * err_ref + 1e-4   # measured r02: 7.7e-3 vs 7.4e-3 (128^2 shard), 4.5e-3 vs 4.3e-3 (512^2 shard)
     tr.optimizer_step(1.0)
     dp = np.abs(tr.flat.cpu()[idx].numpy() - g[f"{tag}_param_s"])
     assert np.quantile(dp, 0.99) <= 5e-5 and dp.max() <= 2.1e-3   # see check_against() on Adam conditioning
