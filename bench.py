@@ -165,10 +165,17 @@ def load_traffic(kernel, dtype):
     if not os.path.exists(tj):
         return None
     t = json.load(open(tj))
+    base = kernel.split("<")[0].split(" ")[0]
+    args = kernel.split("<")[1].split(">")[0].replace(" ", "") if "<" in kernel else ""
+    exact = bool(args) and all(ch.isdigit() or ch == "," for ch in args)    # literal template arguments: one instantiation
+    n = b = 0
     for k, v in t.get("kernels", {}).items():
-        if kernel.split("<")[0] in k and (("<" not in kernel) or kernel.split("<")[1].rstrip(">").replace(" ", "") in k.replace(" ", "")):
-            return round(v["hbm_bytes_per_launch"]), f"profiles/r02_traffic_{dtype}.json ({t.get('correction', '')})"
-    return None
+        if base in k and (not exact or ("<" + args + ">") in k.replace(" ", "")):
+            n += v["launches"]
+            b += v["launches"] * v["hbm_bytes_per_launch"]
+    if not n:
+        return None
+    return round(b / n), f"profiles/r02_traffic_{dtype}.json ({t.get('correction', '')})"
 
 
 def gat_record(dev, L, _lib):
@@ -182,7 +189,8 @@ def gat_record(dev, L, _lib):
     graph = mgunet.PatchGraphConstructor(16)
     Fin, heads, Fh = 32, 4, 64
     for G in (8, 64):
-        rowptr, col, gp, N, E = graph.batched_csr(512, 512, G, dev)
+        rowptr, col, gp, N1, E1 = graph.batched_csr(512, 512, G, dev)
+        N, E = N1 * G, E1 * G
         gen = torch.Generator(device=dev)
         gen.manual_seed(7)
         X = torch.randn((N, Fin), device=dev, generator=gen)

@@ -84,30 +84,44 @@ __device__ __forceinline__ unsigned gf_enc_ordered(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-template <int H>
-__global__ __launch_bounds__(256) void gat_stmax_kernel(const float* __restrict__ x, const float* __restrict__ wa, int N, int Fin,
+// FIN/4 lanes serve one node (each a 16-byte slice of the rows, as in the aggregate kernel): the partial dot products of a
+// slice meet through a log2(FIN/4)-step butterfly, the rows of up to EPT in-edges are in flight at once, and the attention
+// weights of a lane's slice (2H x 4 floats) live in registers -- a thread-per-node version spent 18 us on 8 192 nodes in
+// dependent 128-byte row walks.
+template <int FIN, int H>
+__global__ __launch_bounds__(256) void gat_stmax_kernel(const float* __restrict__ x, const float* __restrict__ wa, int N,
                                                         const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                         const int32_t* __restrict__ gp, int G, float alpha, float* __restrict__ st,
                                                         int32_t* __restrict__ node_graph, unsigned* __restrict__ gmax) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
+  constexpr int LPN = FIN / 4;          // lanes per node
+  constexpr int NPW = 64 / LPN;         // nodes per wavefront
+  constexpr int EPT = 4;                // in-edges in flight per trip (the patch grid has <= 4)
   const int lane = threadIdx.x & 63;
-  if (n - lane >= N) return;   // wave-uniform
+  const int q = lane % LPN, ln = lane / LPN;
+  const int n = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW + ln;
+  if (n - ln >= N) return;   // wave-uniform
   const bool live = n < N;
   const int nd = live ? n : N - 1;
-  const float* xr = x + (size_t)nd * Fin;
-  float s[H], t[H];
+  f32x4 ws[H], wt[H];
 #pragma unroll
-  for (int h = 0; h < H; ++h) s[h] = t[h] = 0.f;
-#pragma unroll 1   // (unrolled, hipcc hoists every wave-uniform weight load and spills SGPRs)
-  for (int c = 0; c < Fin; c += 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+  for (int h = 0; h < H; ++h) {
+    ws[h] = *reinterpret_cast<const f32x4*>(wa + h * FIN + 4 * q);
+    wt[h] = *reinterpret_cast<const f32x4*>(wa + (H + h) * FIN + 4 * q);
+  }
+  auto dot = [](const f32x4 a, const f32x4 b) { return fmaf(a[0], b[0], fmaf(a[1], b[1], fmaf(a[2], b[2], a[3] * b[3]))); };
+  auto fold = [](float v) {   // sum over the LPN lanes of a node (they are consecutive lanes)
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const float* ws = wa + h * Fin + c;          // wave-uniform: scalar loads
-      const float* wt = wa + (H + h) * Fin + c;
-      s[h] = fmaf(v[0], ws[0], fmaf(v[1], ws[1], fmaf(v[2], ws[2], fmaf(v[3], ws[3], s[h]))));
-      t[h] = fmaf(v[0], wt[0], fmaf(v[1], wt[1], fmaf(v[2], wt[2], fmaf(v[3], wt[3], t[h]))));
-    }
+    for (int off = LPN / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+  };
+  const int k0 = rowptr[nd], deg = live ? rowptr[nd + 1] - k0 : 0;
+  const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)nd * FIN + 4 * q);
+  float s[H], t[H], m[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    s[h] = fold(dot(xv, ws[h]));
+    t[h] = fold(dot(xv, wt[h]));
+    m[h] = -INFINITY;
   }
   int g = 0;
   if (gp && G > 1) {
@@ -118,7 +132,7 @@ __global__ __launch_bounds__(256) void gat_stmax_kernel(const float* __restrict_
     }
     g = lo;
   }
-  if (live) {
+  if (live && q == 0) {
 #pragma unroll
     for (int h = 0; h < H; ++h) {
       st[(size_t)n * (2 * H) + h] = s[h];
@@ -126,43 +140,40 @@ __global__ __launch_bounds__(256) void gat_stmax_kernel(const float* __restrict_
     }
     if (node_graph) node_graph[n] = g;
   }
-  // max over this node's in-edges of s_src (recomputed from x_src)
-  float m[H];
+  // s of every in-neighbour, recomputed from its row; every load of a trip is issued before any is consumed (a missing edge
+  // re-reads col[0]'s row and is masked afterwards: no branch around a load)
+  int maxdeg = deg;
 #pragma unroll
-  for (int h = 0; h < H; ++h) m[h] = -INFINITY;
-  const int k0 = live ? rowptr[n] : 0, k1 = live ? rowptr[n + 1] : 0;
-#pragma unroll 1
-  for (int k = k0; k < k1; ++k) {
-    const float* xs = x + (size_t)col[k] * Fin;
-    float ss[H];
+  for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
+  for (int e0 = 0; e0 < maxdeg; e0 += EPT) {
+    f32x4 xs[EPT];
 #pragma unroll
-    for (int h = 0; h < H; ++h) ss[h] = 0.f;
-#pragma unroll 1
-    for (int c = 0; c < Fin; c += 4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xs + c);
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const float* ws = wa + h * Fin + c;
-        ss[h] = fmaf(v[0], ws[0], fmaf(v[1], ws[1], fmaf(v[2], ws[2], fmaf(v[3], ws[3], ss[h]))));
-      }
+    for (int u = 0; u < EPT; ++u) {
+      const int j = col[e0 + u < deg ? k0 + e0 + u : 0];
+      xs[u] = *reinterpret_cast<const f32x4*>(x + (size_t)j * FIN + 4 * q);
     }
 #pragma unroll
-    for (int h = 0; h < H; ++h) m[h] = fmaxf(m[h], ss[h]);
+    for (int u = 0; u < EPT; ++u)
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float sv = fold(dot(xs[u], ws[h]));
+        m[h] = e0 + u < deg ? fmaxf(m[h], sv) : m[h];
+      }
   }
   const int g0 = __builtin_amdgcn_readfirstlane(g);
   const bool uniform = __all(g == g0 || !live);
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     float e = -INFINITY;
-    if (k1 > k0) {
+    if (deg > 0) {
       e = m[h] + t[h];
-      e = e > 0.f ? e : alpha * e;
+      e = e > 0.f ? e : alpha * e;   // LeakyReLU is monotone: the max commutes with it
     }
     if (uniform) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) e = fmaxf(e, __shfl_xor(e, off));
       if (lane == 0 && e > -INFINITY) atomicMax(&gmax[g0 * H + h], gf_enc_ordered(e));
-    } else if (e > -INFINITY) {
+    } else if (q == 0 && e > -INFINITY) {
       atomicMax(&gmax[g * H + h], gf_enc_ordered(e));
     }
   }
@@ -171,13 +182,17 @@ __global__ __launch_bounds__(256) void gat_stmax_kernel(const float* __restrict_
 hipError_t launch_gat_stmax(const float* x, const float* wa, int N, int Fin, int heads, const int32_t* rowptr, const int32_t* col,
                             const int32_t* gp, int G, float alpha, float* st, int32_t* node_graph, unsigned* gmax, hipStream_t s) {
   if (N == 0) return hipSuccess;
-  const dim3 grid((N + 255) / 256), block(256);
-  switch (heads) {
-    case 1: hipLaunchKernelGGL(gat_stmax_kernel<1>, grid, block, 0, s, x, wa, N, Fin, rowptr, col, gp, G, alpha, st, node_graph, gmax); break;
-    case 2: hipLaunchKernelGGL(gat_stmax_kernel<2>, grid, block, 0, s, x, wa, N, Fin, rowptr, col, gp, G, alpha, st, node_graph, gmax); break;
-    case 4: hipLaunchKernelGGL(gat_stmax_kernel<4>, grid, block, 0, s, x, wa, N, Fin, rowptr, col, gp, G, alpha, st, node_graph, gmax); break;
-    default: return hipErrorInvalidValue;
-  }
+  const int npw = 64 / (Fin / 4);
+  const dim3 grid((N + 4 * npw - 1) / (4 * npw)), block(256);
+#define MGU_SM(FIN, H) hipLaunchKernelGGL((gat_stmax_kernel<FIN, H>), grid, block, 0, s, x, wa, N, rowptr, col, gp, G, alpha, st, node_graph, gmax)
+  if (Fin == 32 && heads == 1) MGU_SM(32, 1);
+  else if (Fin == 32 && heads == 2) MGU_SM(32, 2);
+  else if (Fin == 32 && heads == 4) MGU_SM(32, 4);
+  else if (Fin == 64 && heads == 1) MGU_SM(64, 1);
+  else if (Fin == 64 && heads == 2) MGU_SM(64, 2);
+  else if (Fin == 64 && heads == 4) MGU_SM(64, 4);
+  else return hipErrorInvalidValue;
+#undef MGU_SM
   return hipGetLastError();
 }
 

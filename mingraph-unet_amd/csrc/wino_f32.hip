@@ -639,6 +639,359 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   }
 }
 
+// =================================================================================================================
+// Component-pair work split for the three-piece operand mode (the default): wave (i, jp) owns transform row i and the
+// component PAIR j in {2 jp, 2 jp + 1} of BOTH m tiles and ALL n tiles of the workgroup.
+//
+// In wino3x3_f32_kernel<0, 1> wave (i, g) owns all four components of n tile g, so every V value is formed -- transformed and
+// split into three bf16 pieces, 8 VALU per value -- by the two waves g = 0, 1: 490 VALU per 48 MFMAs per wave and chunk,
+// 14 VALU instructions issued per MFMA (rocprofv3, profiles/r01_k_pmc3_prec1.txt), and the matrix pipe 24 % busy.  Here a
+// value is formed exactly once per workgroup: a wave needs only three of the four columns of its raw rows (components 0, 1
+// <- columns 0..2; components 2, 3 <- columns 1..3: 6 instead of 8 LDS reads per half) and splits 32 values instead of 64
+// per chunk: ~270 VALU per 48 MFMAs.  The same 128 accumulator and 48 weight-piece registers as before.
+// The two component pairs of a row meet in the inverse transform: Z[i][q] = sum_j M[i][j] A[j][q] is a sum over j, so the
+// jp = 0 waves store their part of it into the exchange buffer and the jp = 1 waves add theirs with ds_add_f32 one barrier
+// later; the finishing pass (row part, epilogue, fused pool / statistics) is the one of wino3x3_f32_kernel.
+// =================================================================================================================
+template <int NTB, bool STATS>
+__global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y, const int total_patches,
+                        const int patches_per_block, const int ngroups, const int nitems, const int per_xcd) {
+  constexpr int NWAVES = 8;
+  constexpr int MT = 2;                          // both m tiles of the 8 x 32 pixel patch
+  constexpr int NC = 32 * NTB;                   // output channels per workgroup
+  constexpr int ZP = NC + 8;                     // exchange-buffer pitch of a tile (floats)
+  constexpr int QPT = NC / 4;                    // channel quads per tile
+  constexpr int UPT = 64 * QPT / 512;            // (tile, channel quad) units a thread finishes per pass
+  constexpr int RH = 10, RW = 34, HPIX = RH * RW;
+  constexpr int PLD = 20;
+  constexpr int HSTRIDE = NWAVES * 16;
+  constexpr int HR = (HPIX + HSTRIDE - 1) / HSTRIDE;
+  constexpr int S1 = 17 * PLD, S2 = PLD, S3 = 17 * PLD + PLD;   // LDS offsets of tile columns 1..3 (parity planes)
+  constexpr int RAWF = HR * HSTRIDE / RW * 34 * PLD + 34 * PLD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Zx = smem + 2 * RAWF;      // [4 rows i][64 tiles][ZP]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave & 3, jp = wave >> 2;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int tx = lr & 15, ty = lr >> 4;
+  const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (item >= nitems) return;
+  const int nblock = item / ngroups;
+  const int p_begin = (item - nblock * ngroups) * patches_per_block;
+  const int npatch = min(patches_per_block, total_patches - p_begin);
+  if (npatch <= 0) return;
+
+  // row i of B^T d:  i=0: d0 - d2,  i=1: d1 + d2,  i=2: d2 - d1,  i=3: d1 - d3
+  const int ra = wi == 0 ? 0 : (wi == 2 ? 2 : 1);
+  const int rb = wi == 0 ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+  const float sgn = wi == 1 ? 1.f : -1.f;
+  int offA[MT], offB[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int rowbase = 2 * (2 * mi + ty);
+    offA[mi] = ((rowbase + ra) * 34 + tx) * PLD + lh * 8;
+    offB[mi] = ((rowbase + rb) * 34 + tx) * PLD + lh * 8;
+  }
+  const int nC = d.Cp >> 4;                        // 16-channel raw chunks
+  // three-piece layout: 16-byte lane loads, [n tile][chunk][i*4+j][piece][lane]
+  const u32x4* const upx = reinterpret_cast<const u32x4*>(d.wu) + ((size_t)(nblock * NTB) * nC * 16 + wi * 4 + 2 * jp) * 192 + lane;
+  const size_t nt_stride = (size_t)nC * 16 * 192;
+
+  // ---- raw halo staging (as wino3x3_f32_kernel) ----
+  const int kq = tid & 3, hp0 = tid >> 2;
+  int hoff[HR];
+  unsigned hmask = 0u, hmask_next = 0u;
+  const float* load_base = d.in;
+  auto setup_patch = [&](int p, int& img, int& y0, int& x0) {
+    const int px = p % tiles_x;
+    const int py = (p / tiles_x) % tiles_y;
+    img = p / (tiles_x * tiles_y);
+    y0 = py * 8;
+    x0 = px * 32;
+  };
+  auto setup_load = [&](int p) {
+    int img, y0, x0;
+    setup_patch(p, img, y0, x0);
+    load_base = d.in + (size_t)img * d.H * d.W * d.ldin + kq * 4;
+    unsigned mk = 0u;
+#pragma unroll
+    for (int i = 0; i < HR; ++i) {
+      const int hp = hp0 + HSTRIDE * i;
+      const int r = hp / RW, cc = hp - r * RW;
+      const int y = y0 - 1 + r, x = x0 - 1 + cc;
+      const bool ok = hp < HPIX && y >= 0 && y < d.H && x >= 0 && x < d.W;
+      hoff[i] = ok ? (y * d.W + x) * d.ldin : 0;
+      mk |= ok ? (1u << i) : 0u;
+    }
+    hmask_next = mk;
+  };
+  f32x4 hreg[HR];
+  auto load_halo = [&](int c) {
+    hmask = hmask_next;
+#pragma unroll
+    for (int i = 0; i < HR; ++i) hreg[i] = *reinterpret_cast<const f32x4*>(load_base + hoff[i] + c * 16);
+  };
+  auto store_halo = [&](float* Hs) {
+#pragma unroll
+    for (int i = 0; i < HR; ++i) {
+      const int hp = hp0 + HSTRIDE * i;
+      const int r = hp / RW, cc = hp - r * RW;
+      *reinterpret_cast<f32x4*>(Hs + ((r * 2 + (cc & 1)) * 17 + (cc >> 1)) * PLD + kq * 4) =
+          ((hmask >> i) & 1u) ? hreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int lp = 0, lc = 0;
+  auto prep_next = [&]() {
+    if (lc == 0 && lp < npatch) setup_load(p_begin + lp);
+  };
+  auto load_next = [&]() {
+    load_halo(lc);
+    lc = lc + 1 == nC ? 0 : lc + 1;
+    lp += lc == 0 ? 1 : 0;
+  };
+
+  const int cq = tid % QPT;
+  const int n0 = nblock * NC + cq * 4;
+  const bool fast_n = (d.N % NC == 0) && (d.ldout % 4 == 0) && (d.coff % 4 == 0) && (!d.pool || d.ldpool % 4 == 0);
+  u32x4 bx[2][NTB][3];   // the three pieces of this wave's two components, every n tile, one 16-channel chunk
+  auto load_bx = [&](int jj, int chunk) {
+#pragma unroll
+    for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) bx[jj][nt][pc] = upx[nt * nt_stride + (size_t)chunk * (16 * 192) + jj * 192 + pc * 64];
+  };
+
+  f32x16 acc[2][NTB][MT];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+    for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jj][nt][mi][r] = 0.f;
+
+  prep_next();
+  load_next();
+  load_bx(0, 0);
+  load_bx(1, 0);
+  store_halo(smem);
+  prep_next();
+  load_next();
+  f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+  int buf = 0;
+  for (int pi = 0; pi < npatch; ++pi) {
+    for (int c = 0; c < nC; ++c) {
+      prep_next();
+      lds_barrier();
+      const float* Hs = smem + buf * RAWF;
+      store_halo(smem + (buf ^ 1) * RAWF);
+      load_next();
+      const int cn = c + 1 == nC ? 0 : c + 1;
+      // component jj of the pair needs TWO raw columns:  V = (ra_x + sgn rb_x) + w (ra_y + sgn rb_y)
+      //   jp = 0: V0 = r0 - r2 (x = col 0, y = col 2, w = -1),  V1 = r1 + r2 (x = col 1, y = col 2, w = +1)
+      //   jp = 1: V2 = r2 - r1 (x = col 2, y = col 1, w = -1),  V3 = r1 - r3 (x = col 1, y = col 3, w = -1)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int cx = jj == 0 ? (jp ? S2 : 0) : S1;
+        const int cy = jj == 0 ? (jp ? S1 : S2) : (jp ? S3 : S2);
+        const float w = (jj == 1 && jp == 0) ? 1.f : -1.f;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          u32x4 a0, a1, a2;
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const float* pa = Hs + offA[mi] + hf * 4;
+            const float* pb = Hs + offB[mi] + hf * 4;
+            const f32x4 qx = *reinterpret_cast<const f32x4*>(pa + cx) + sgn * *reinterpret_cast<const f32x4*>(pb + cx);
+            const f32x4 qy = *reinterpret_cast<const f32x4*>(pa + cy) + sgn * *reinterpret_cast<const f32x4*>(pb + cy);
+            const f32x4 v = qx + w * qy;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              unsigned p0, p1, p2;
+              split3_pack(v[2 * e], v[2 * e + 1], p0, p1, p2);
+              a0[hf * 2 + e] = p0, a1[hf * 2 + e] = p1, a2[hf * 2 + e] = p2;
+            }
+          }
+#pragma unroll
+          for (int nt = 0; nt < NTB; ++nt) {
+            f32x16 t = acc[jj][nt][mi];
+            t = mfma_bf16(a2, bx[jj][nt][0], t);
+            t = mfma_bf16(a0, bx[jj][nt][2], t);
+            t = mfma_bf16(a1, bx[jj][nt][1], t);
+            t = mfma_bf16(a1, bx[jj][nt][0], t);
+            t = mfma_bf16(a0, bx[jj][nt][1], t);
+            t = mfma_bf16(a0, bx[jj][nt][0], t);
+            acc[jj][nt][mi] = t;
+          }
+          // one (component, m tile) step at a time: without this fence hipcc hoists the transforms and splits of all four
+          // steps above the first MFMA and spills ~130 registers; the VALU of one wave overlaps with the MFMAs of the other
+          // wave of its SIMD instead
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        load_bx(jj, cn);   // this component's pieces of the next chunk (or the next patch's first)
+      }
+      buf ^= 1;
+    }
+    // ---- inverse transform + epilogue of patch pi ----
+    int img, y0, x0;
+    setup_patch(p_begin + pi, img, y0, x0);
+    float* const img_out = d.out + (size_t)img * d.H * d.W * d.ldout + d.coff;
+    const unsigned sW = (unsigned)(d.W * d.ldout);
+    const bool interior = (y0 + 8 <= d.H) && (x0 + 32 <= d.W) && fast_n;
+    float* pool_out = nullptr;
+    if (d.pool) pool_out = d.pool + (size_t)img * (d.H >> 1) * (d.W >> 1) * d.ldpool;
+    f32x4 pmax[UPT];
+    // per-channel scale / shift of this thread's channel quad: (re)loaded per patch from L1/L2 rather than held in eight
+    // registers through the main loop (the loop runs at the 256-register limit)
+    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n0 + e < d.N) {
+        if (d.scale) sc4[e] = d.scale[n0 + e];
+        if (d.shift) sh4[e] = d.shift[n0 + e];
+      }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      // column part, this wave's share of Z[i][q] = sum_j M[i][j] A[j][q]  (A^T = [1 1 1 0; 0 1 -1 -1]):
+      //   jp = 0 (M0, M1): q = 0: M0 + M1, q = 1: M1;      jp = 1 (M2, M3): q = 0: M2, q = 1: -M2 - M3
+      if (jp == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float z = q == 0 ? acc[0][nt][mi][r] + acc[1][nt][mi][r] : acc[1][nt][mi][r];
+              const int T = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              Zx[(wi * 64 + T) * ZP + nt * 32 + lr] = z;
+            }
+      }
+      lds_barrier();
+      if (jp == 1) {
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float z = q == 0 ? acc[0][nt][mi][r] : -acc[0][nt][mi][r] - acc[1][nt][mi][r];
+              const int T = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              (void)__hip_atomic_fetch_add(&Zx[(wi * 64 + T) * ZP + nt * 32 + lr], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+      }
+      lds_barrier();
+      // row part + epilogue: unit u = (tile, channel quad); y(2tr, .) = Z0 + Z1 + Z2, y(2tr+1, .) = Z1 - Z2 - Z3
+#pragma unroll
+      for (int k = 0; k < UPT; ++k) {
+        const int u = tid + k * 512;
+        const int T = u / QPT;
+        const float* zp = Zx + T * ZP + cq * 4;
+        const f32x4 z0 = *reinterpret_cast<const f32x4*>(zp);
+        const f32x4 z1 = *reinterpret_cast<const f32x4*>(zp + 64 * ZP);
+        const f32x4 z2 = *reinterpret_cast<const f32x4*>(zp + 128 * ZP);
+        const f32x4 z3 = *reinterpret_cast<const f32x4*>(zp + 192 * ZP);
+        f32x4 ya = (z0 + z1 + z2) * sc4 + sh4;
+        f32x4 yb = (z1 - z2 - z3) * sc4 + sh4;
+        if (d.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ya[e] = fmaxf(ya[e], 0.f), yb[e] = fmaxf(yb[e], 0.f);
+        }
+        const int oy = y0 + 2 * (T >> 4), ox = x0 + 2 * (T & 15) + q;
+        if (STATS) {
+          const float ma = (interior || (ox < d.W && oy < d.H)) ? 1.f : 0.f;
+          const float mb = (interior || (ox < d.W && oy + 1 < d.H)) ? 1.f : 0.f;
+          st1 += ma * ya + mb * yb;
+          st2 += ma * ya * ya + mb * yb * yb;
+        }
+        const unsigned idx = (unsigned)((oy * d.W + ox) * d.ldout + n0);
+        if (interior) {
+          *reinterpret_cast<f32x4*>(img_out + idx) = ya;
+          *reinterpret_cast<f32x4*>(img_out + idx + sW) = yb;
+        } else if (ox < d.W) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n0 + e < d.N) {
+              if (oy < d.H) img_out[idx + e] = ya[e];
+              if (oy + 1 < d.H) img_out[idx + sW + e] = yb[e];
+            }
+        }
+        if (d.pool) {
+          f32x4 m;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[e] = fmaxf(ya[e], yb[e]);
+          if (q == 0) {
+            pmax[k] = m;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], pmax[k][e]);
+            const int py = oy >> 1, px = ox >> 1;
+            if (oy + 1 < d.H && ox < d.W) {
+              float* pp = pool_out + (size_t)(py * (d.W >> 1) + px) * d.ldpool + n0;
+              if (fast_n) {
+                *reinterpret_cast<f32x4*>(pp) = m;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (n0 + e < d.N) pp[e] = m[e];
+              }
+            }
+          }
+        }
+      }
+      lds_barrier();   // Zx is rewritten by the next pass / patch
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[jj][nt][mi][r] = 0.f;
+  }
+  if (STATS) {
+    float* red = smem;   // [512][8]
+    lds_barrier();
+    *reinterpret_cast<f32x4*>(red + tid * 8) = st1;
+    *reinterpret_cast<f32x4*>(red + tid * 8 + 4) = st2;
+    lds_barrier();
+    if (tid < 8 * QPT) {
+      const int which = tid / (4 * QPT), rem = tid - which * 4 * QPT, qd = rem >> 2, e = rem & 3;
+      double sum = 0.0;
+      for (int k = qd; k < 512; k += QPT) sum += (double)red[k * 8 + which * 4 + e];
+      const int n = nblock * NC + qd * 4 + e;
+      if (n < d.N) atomicAdd(d.stat_slots + (size_t)(blockIdx.x & 63) * 2 * d.N + which * d.N + n, sum);
+    }
+  }
+}
+
+template <int NTB, bool STATS>
+static hipError_t launch_wino_cp(const IgemmDesc& d, hipStream_t s) {
+  constexpr int NWAVES = 8;
+  const int tiles_x = (d.W + 31) / 32, tiles_y = (d.H + 7) / 8;
+  const int B = d.M / (d.H * d.W);
+  const int total = tiles_x * tiles_y * B, nblk = (d.N + 32 * NTB - 1) / (32 * NTB);
+  const int rounds = std::max(1, tun(d).wino_rounds), cap = std::max(1, tun(d).wino_ppb_cap);
+  int ppb = (int)(((long)total * nblk) / (256 * rounds));
+  if (ppb < 1) ppb = 1;
+  if (ppb > cap) ppb = cap;
+  const int ngroups = (total + ppb - 1) / ppb;
+  const int per_xcd = (ngroups * nblk + 7) / 8;
+  dim3 grid(8 * per_xcd, 1);
+  constexpr int HSTRIDE = NWAVES * 16, HR = (340 + HSTRIDE - 1) / HSTRIDE;
+  constexpr int RAWF = HR * HSTRIDE / 34 * 34 * 20 + 34 * 20;   // must match the kernel
+  const size_t lds = (size_t)(2 * RAWF + 4 * 64 * (32 * NTB + 8)) * sizeof(float);
+  static bool attr_done[64] = {};
+  hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&wino3x3_cp_kernel<NTB, STATS>), lds, attr_done);
+  if (ae != hipSuccess) return ae;
+  hipLaunchKernelGGL((wino3x3_cp_kernel<NTB, STATS>), grid, dim3(64 * NWAVES), lds, s, d, tiles_x, tiles_y, total, ppb, ngroups, ngroups * nblk,
+                     per_xcd);
+  return hipGetLastError();
+}
+
 template <int MODE, int PREC>
 static hipError_t launch_wino_mode(const IgemmDesc& d, hipStream_t s) {
   constexpr int NTB = MODE == 0 ? 2 : 1, NWAVES = 8;
@@ -672,6 +1025,10 @@ bool wino_applicable(const IgemmDesc& d) {
 
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
   const bool wide = d.N > 32 && tun(d).wino_mode != 1;
+  if (tun(d).wino_prec && tun(d).wino_cp) {
+    if (d.stat_slots) return wide ? launch_wino_cp<2, true>(d, s) : launch_wino_cp<1, true>(d, s);
+    return wide ? launch_wino_cp<2, false>(d, s) : launch_wino_cp<1, false>(d, s);
+  }
   if (tun(d).wino_prec) return wide ? launch_wino_mode<0, 1>(d, s) : launch_wino_mode<1, 1>(d, s);
   return wide ? launch_wino_mode<0, 0>(d, s) : launch_wino_mode<1, 0>(d, s);
 }
