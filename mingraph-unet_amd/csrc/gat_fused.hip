@@ -84,45 +84,24 @@ __device__ __forceinline__ unsigned gf_enc_ordered(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// FIN/4 lanes serve one node (each a 16-byte slice of the rows, as in the aggregate kernel): the partial dot products of a
-// slice meet through a log2(FIN/4)-step butterfly, the rows of up to EPT in-edges are in flight at once, and the attention
-// weights of a lane's slice (2H x 4 floats) live in registers -- a thread-per-node version spent 18 us on 8 192 nodes in
-// dependent 128-byte row walks.
+// Eight lanes serve one node: lane slot 0 takes the node's own row (s_j, t_j), slots 1..7 one in-edge each (s_src, recomputed
+// from the source's row); every lane loads ITS row whole (FIN/4 16-byte loads issued back to back) and keeps the 2H dot
+// products to itself, so the only cross-lane traffic is the max over a node's eight slots (two DPP quad permutes and one
+// swizzle per head).  Rows with more than 7 in-edges take further trips.  (A thread-per-node version walked its rows with
+// dependent 16-byte loads: 18 us for 8 192 nodes; a slice-per-lane version folded 24 partial sums through ds_bpermute: 30 us.)
 template <int FIN, int H>
 __global__ __launch_bounds__(256) void gat_stmax_kernel(const float* __restrict__ x, const float* __restrict__ wa, int N,
                                                         const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                         const int32_t* __restrict__ gp, int G, float alpha, float* __restrict__ st,
                                                         int32_t* __restrict__ node_graph, unsigned* __restrict__ gmax) {
-  constexpr int LPN = FIN / 4;          // lanes per node
-  constexpr int NPW = 64 / LPN;         // nodes per wavefront
-  constexpr int EPT = 4;                // in-edges in flight per trip (the patch grid has <= 4)
+  constexpr int SL = 8, NPW = 64 / SL, NQ = FIN / 4;
   const int lane = threadIdx.x & 63;
-  const int q = lane % LPN, ln = lane / LPN;
+  const int slot = lane & (SL - 1), ln = lane >> 3;
   const int n = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW + ln;
   if (n - ln >= N) return;   // wave-uniform
   const bool live = n < N;
   const int nd = live ? n : N - 1;
-  f32x4 ws[H], wt[H];
-#pragma unroll
-  for (int h = 0; h < H; ++h) {
-    ws[h] = *reinterpret_cast<const f32x4*>(wa + h * FIN + 4 * q);
-    wt[h] = *reinterpret_cast<const f32x4*>(wa + (H + h) * FIN + 4 * q);
-  }
-  auto dot = [](const f32x4 a, const f32x4 b) { return fmaf(a[0], b[0], fmaf(a[1], b[1], fmaf(a[2], b[2], a[3] * b[3]))); };
-  auto fold = [](float v) {   // sum over the LPN lanes of a node (they are consecutive lanes)
-#pragma unroll
-    for (int off = LPN / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-  };
   const int k0 = rowptr[nd], deg = live ? rowptr[nd + 1] - k0 : 0;
-  const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)nd * FIN + 4 * q);
-  float s[H], t[H], m[H];
-#pragma unroll
-  for (int h = 0; h < H; ++h) {
-    s[h] = fold(dot(xv, ws[h]));
-    t[h] = fold(dot(xv, wt[h]));
-    m[h] = -INFINITY;
-  }
   int g = 0;
   if (gp && G > 1) {
     int lo = 0, hi = G;  // gp[lo] <= node < gp[hi]
@@ -132,48 +111,79 @@ __global__ __launch_bounds__(256) void gat_stmax_kernel(const float* __restrict_
     }
     g = lo;
   }
-  if (live && q == 0) {
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      st[(size_t)n * (2 * H) + h] = s[h];
-      st[(size_t)n * (2 * H) + H + h] = t[h];
-    }
-    if (node_graph) node_graph[n] = g;
-  }
-  // s of every in-neighbour, recomputed from its row; every load of a trip is issued before any is consumed (a missing edge
-  // re-reads col[0]'s row and is masked afterwards: no branch around a load)
   int maxdeg = deg;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
-  for (int e0 = 0; e0 < maxdeg; e0 += EPT) {
-    f32x4 xs[EPT];
+  float m[H], tt[H];
 #pragma unroll
-    for (int u = 0; u < EPT; ++u) {
-      const int j = col[e0 + u < deg ? k0 + e0 + u : 0];
-      xs[u] = *reinterpret_cast<const f32x4*>(x + (size_t)j * FIN + 4 * q);
+  for (int h = 0; h < H; ++h) m[h] = -INFINITY, tt[h] = 0.f;
+  for (int e0 = 0; e0 == 0 || e0 < maxdeg; e0 += SL - 1) {
+    // slot 0 of the first trip: the node itself; otherwise in-edge e0 + slot - 1 (a missing edge re-reads the node's own row
+    // and is masked: no branch around a load)
+    const int e = e0 + slot - 1;
+    const bool is_edge = slot > 0 && e < deg;
+    const int src = is_edge ? col[k0 + e] : nd;
+    const float* xr = x + (size_t)src * FIN;
+    f32x4 xv[NQ];
+#pragma unroll
+    for (int c = 0; c < NQ; ++c) xv[c] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
+    float s[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      float a = 0.f;
+#pragma unroll
+      for (int c = 0; c < NQ; ++c) {
+        const float* w = wa + h * FIN + 4 * c;      // wave-uniform: scalar loads
+        a = fmaf(xv[c][0], w[0], fmaf(xv[c][1], w[1], fmaf(xv[c][2], w[2], fmaf(xv[c][3], w[3], a))));
+      }
+      s[h] = a;
     }
-#pragma unroll
-    for (int u = 0; u < EPT; ++u)
+    if (e0 == 0) {   // t_j (slot 0 lanes use it; the others compute it for nothing, without a divergent branch)
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        const float sv = fold(dot(xs[u], ws[h]));
-        m[h] = e0 + u < deg ? fmaxf(m[h], sv) : m[h];
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < NQ; ++c) {
+          const float* w = wa + (H + h) * FIN + 4 * c;
+          a = fmaf(xv[c][0], w[0], fmaf(xv[c][1], w[1], fmaf(xv[c][2], w[2], fmaf(xv[c][3], w[3], a))));
+        }
+        tt[h] = a;
       }
+      if (live && slot == 0) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          st[(size_t)n * (2 * H) + h] = s[h];
+          st[(size_t)n * (2 * H) + H + h] = tt[h];
+        }
+        if (node_graph) node_graph[n] = g;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) m[h] = fmaxf(m[h], is_edge ? s[h] : -INFINITY);
+  }
+  // max over the eight slots of a node, then t_j of slot 0 joins: quad_perm xor 1, xor 2 (DPP), xor 4 (swizzle)
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    float v = m[h];
+    v = fmaxf(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F)));   // BitMode xor 4
+    m[h] = v;
   }
   const int g0 = __builtin_amdgcn_readfirstlane(g);
   const bool uniform = __all(g == g0 || !live);
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     float e = -INFINITY;
-    if (deg > 0) {
-      e = m[h] + t[h];
+    if (slot == 0 && deg > 0) {
+      e = m[h] + tt[h];
       e = e > 0.f ? e : alpha * e;   // LeakyReLU is monotone: the max commutes with it
     }
     if (uniform) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) e = fmaxf(e, __shfl_xor(e, off));
       if (lane == 0 && e > -INFINITY) atomicMax(&gmax[g0 * H + h], gf_enc_ordered(e));
-    } else if (q == 0 && e > -INFINITY) {
+    } else if (e > -INFINITY) {
       atomicMax(&gmax[g * H + h], gf_enc_ordered(e));
     }
   }
@@ -182,8 +192,7 @@ __global__ __launch_bounds__(256) void gat_stmax_kernel(const float* __restrict_
 hipError_t launch_gat_stmax(const float* x, const float* wa, int N, int Fin, int heads, const int32_t* rowptr, const int32_t* col,
                             const int32_t* gp, int G, float alpha, float* st, int32_t* node_graph, unsigned* gmax, hipStream_t s) {
   if (N == 0) return hipSuccess;
-  const int npw = 64 / (Fin / 4);
-  const dim3 grid((N + 4 * npw - 1) / (4 * npw)), block(256);
+  const dim3 grid((N + 31) / 32), block(256);   // 8 nodes per wavefront
 #define MGU_SM(FIN, H) hipLaunchKernelGGL((gat_stmax_kernel<FIN, H>), grid, block, 0, s, x, wa, N, rowptr, col, gp, G, alpha, st, node_graph, gmax)
   if (Fin == 32 && heads == 1) MGU_SM(32, 1);
   else if (Fin == 32 && heads == 2) MGU_SM(32, 2);

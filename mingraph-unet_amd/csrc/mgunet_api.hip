@@ -72,6 +72,7 @@ int mgu_create(int device_id, mgu_ctx** out) {
   t.wino_mode = num("MGU_WINO_MODE", -1);
   t.wino_prec = num("MGU_WINO_PREC", t.wino_prec) ? 1 : 0;
   t.wino_cp = !flag("MGU_NO_WINO_CP");
+  t.wino_cp_narrow = num("MGU_WINO_CP_NARROW", 1) != 0;
   t.wino_rounds = std::max(1, num("MGU_WINO_ROUNDS", 1));
   t.wino_ppb_cap = std::max(1, num("MGU_WINO_PPB_CAP", 32));
   t.wgrad_halo = !flag("MGU_NO_WGRAD_HALO");

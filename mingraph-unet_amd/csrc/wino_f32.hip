@@ -696,14 +696,20 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
   }
   const int nC = d.Cp >> 4;                        // 16-channel raw chunks
   // three-piece layout: 16-byte lane loads, [n tile][chunk][i*4+j][piece][lane]
-  const u32x4* const upx = reinterpret_cast<const u32x4*>(d.wu) + ((size_t)(nblock * NTB) * nC * 16 + wi * 4 + 2 * jp) * 192 + lane;
-  const size_t nt_stride = (size_t)nC * 16 * 192;
-
+  // weight pieces through a buffer descriptor: wave-uniform base + SGPR offset + ONE 32-bit lane offset (lane * 16 bytes), so
+  // the 12 NTB piece loads of a chunk cost no 64-bit VGPR address arithmetic and no address registers
+  const size_t u_base = ((size_t)(nblock * NTB) * nC * 16 + wi * 4 + 2 * jp) * 192 * sizeof(u32x4);
+  const size_t u_bytes = (size_t)NTB * nC * 16 * 192 * sizeof(u32x4);
+  const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(d.wu)) + u_base, 0,
+                                                         (int)u_bytes, 0x00020000);
+  const unsigned nt_stride = (unsigned)nC * 16 * 192 * (unsigned)sizeof(u32x4);
+  const unsigned lane16 = (unsigned)lane * 16u;
   // ---- raw halo staging (as wino3x3_f32_kernel) ----
   const int kq = tid & 3, hp0 = tid >> 2;
   int hoff[HR];
   unsigned hmask = 0u, hmask_next = 0u;
-  const float* load_base = d.in;
+  auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.in), 0, 0x7ffffff0, 0x00020000);
+  const int img_bytes = d.H * d.W * d.ldin * (int)sizeof(float);   // the launcher guarantees H*W*ldin < 2^31 elements ... and bytes fit below
   auto setup_patch = [&](int p, int& img, int& y0, int& x0) {
     const int px = p % tiles_x;
     const int py = (p / tiles_x) % tiles_y;
@@ -714,7 +720,8 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
   auto setup_load = [&](int p) {
     int img, y0, x0;
     setup_patch(p, img, y0, x0);
-    load_base = d.in + (size_t)img * d.H * d.W * d.ldin + kq * 4;
+    // wave-uniform image base in the descriptor; the lane's pixel and 16-byte piece ride in hoff (bytes)
+    in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.in) + (size_t)img * d.H * d.W * d.ldin, 0, img_bytes, 0x00020000);
     unsigned mk = 0u;
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
@@ -722,7 +729,7 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
       const int r = hp / RW, cc = hp - r * RW;
       const int y = y0 - 1 + r, x = x0 - 1 + cc;
       const bool ok = hp < HPIX && y >= 0 && y < d.H && x >= 0 && x < d.W;
-      hoff[i] = ok ? (y * d.W + x) * d.ldin : 0;
+      hoff[i] = ((ok ? (y * d.W + x) * d.ldin : 0) + kq * 4) * (int)sizeof(float);
       mk |= ok ? (1u << i) : 0u;
     }
     hmask_next = mk;
@@ -731,7 +738,8 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
   auto load_halo = [&](int c) {
     hmask = hmask_next;
 #pragma unroll
-    for (int i = 0; i < HR; ++i) hreg[i] = *reinterpret_cast<const f32x4*>(load_base + hoff[i] + c * 16);
+    for (int i = 0; i < HR; ++i)
+      hreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, hoff[i], c * 64, 0));
   };
   auto store_halo = [&](float* Hs) {
 #pragma unroll
@@ -752,15 +760,15 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
     lp += lc == 0 ? 1 : 0;
   };
 
-  const int cq = tid % QPT;
-  const int n0 = nblock * NC + cq * 4;
-  const bool fast_n = (d.N % NC == 0) && (d.ldout % 4 == 0) && (d.coff % 4 == 0) && (!d.pool || d.ldpool % 4 == 0);
+  const bool fast_n = (d.N % NC == 0) && (d.ldout % 4 == 0) && (d.coff % 4 == 0) && (!d.pool || d.ldpool % 4 == 0);   // uniform
   u32x4 bx[2][NTB][3];   // the three pieces of this wave's two components, every n tile, one 16-channel chunk
   auto load_bx = [&](int jj, int chunk) {
 #pragma unroll
     for (int nt = 0; nt < NTB; ++nt)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) bx[jj][nt][pc] = upx[nt * nt_stride + (size_t)chunk * (16 * 192) + jj * 192 + pc * 64];
+      for (int pc = 0; pc < 3; ++pc)
+        bx[jj][nt][pc] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            u_rsrc, lane16, (unsigned)(nt * nt_stride + ((unsigned)chunk * (16 * 192) + jj * 192 + pc * 64) * 16u), 0));
   };
 
   f32x16 acc[2][NTB][MT];
@@ -773,66 +781,89 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[jj][nt][mi][r] = 0.f;
 
+  // A chunk is four STEPS (component jj of the pair, m tile mi), 6 NTB MFMAs each.  Component jj needs TWO raw columns:
+  //   V = (ra_x + sgn rb_x) + w (ra_y + sgn rb_y)
+  //   jp = 0: V0 = r0 - r2 (x = col 0, y = col 2, w = -1),  V1 = r1 + r2 (x = col 1, y = col 2, w = +1)
+  //   jp = 1: V2 = r2 - r1 (x = col 2, y = col 1, w = -1),  V3 = r1 - r3 (x = col 1, y = col 3, w = -1)
+  u32x4 pc[2][3];   // the three bf16 pieces of a step's A operand, double buffered
+  auto form = [&](const float* Hs, const int jj, const int mi, const int slot) {
+    const int cx = jj == 0 ? (jp ? S2 : 0) : S1;
+    const int cy = jj == 0 ? (jp ? S1 : S2) : (jp ? S3 : S2);
+    const float w = (jj == 1 && jp == 0) ? 1.f : -1.f;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const float* pa = Hs + offA[mi] + hf * 4;
+      const float* pb = Hs + offB[mi] + hf * 4;
+      const f32x4 qx = *reinterpret_cast<const f32x4*>(pa + cx) + sgn * *reinterpret_cast<const f32x4*>(pb + cx);
+      const f32x4 qy = *reinterpret_cast<const f32x4*>(pa + cy) + sgn * *reinterpret_cast<const f32x4*>(pb + cy);
+      const f32x4 v = qx + w * qy;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        unsigned p0, p1, p2;
+        split3_pack(v[2 * e], v[2 * e + 1], p0, p1, p2);
+        pc[slot][0][hf * 2 + e] = p0, pc[slot][1][hf * 2 + e] = p1, pc[slot][2][hf * 2 + e] = p2;
+      }
+    }
+  };
+
+  // Issue order = the steady state's (vmcnt retires in order and hipcc merges the pending-load state of the loop's two
+  // predecessors): the oldest pending loads at the top of a chunk are the halo of the next chunk, then the weight pieces.
+  prep_next();
+  load_next();
+  store_halo(smem);
   prep_next();
   load_next();
   load_bx(0, 0);
   load_bx(1, 0);
-  store_halo(smem);
-  prep_next();
-  load_next();
+  lds_barrier();
+  form(smem, 0, 0, 0);      // step 0 of the first chunk
   f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
   int buf = 0;
   for (int pi = 0; pi < npatch; ++pi) {
     for (int c = 0; c < nC; ++c) {
+      // Software pipeline WITHOUT a lead-in or a tail: the MFMAs of every step run beside the LDS reads, transform and
+      // three-way split of the NEXT step -- and the last step's partner is step 0 of the next chunk, whose raw data (parked
+      // in the other buffer at the top of this chunk) become visible at the mid-chunk barrier B1.  So a wave's VALU work
+      // always has MFMAs of its own to hide behind (the bf16 MFMA lets the VALU issue beside it), and the two waves of a SIMD
+      // (the two component pairs of a row) need not alternate phases.  Two barriers per chunk:
+      //   B0 (top): every wave has finished reading the buffer that now receives chunk c + 1;
+      //   B1 (after step 1): chunk c + 1 is complete in LDS.
       prep_next();
-      lds_barrier();
-      const float* Hs = smem + buf * RAWF;
+      lds_barrier();                                     // B0
+      const float* Hs = smem + buf * RAWF;               // chunk c
+      const float* Hn = smem + (buf ^ 1) * RAWF;         // chunk c + 1 (or the next patch's first)
       store_halo(smem + (buf ^ 1) * RAWF);
       load_next();
       const int cn = c + 1 == nC ? 0 : c + 1;
-      // component jj of the pair needs TWO raw columns:  V = (ra_x + sgn rb_x) + w (ra_y + sgn rb_y)
-      //   jp = 0: V0 = r0 - r2 (x = col 0, y = col 2, w = -1),  V1 = r1 + r2 (x = col 1, y = col 2, w = +1)
-      //   jp = 1: V2 = r2 - r1 (x = col 2, y = col 1, w = -1),  V3 = r1 - r3 (x = col 1, y = col 3, w = -1)
+      static_for<0, 4>([&](auto st_c) {
+        constexpr int st = decltype(st_c)::value;
+        constexpr int jj = st >> 1, mi = st & 1, slot = st & 1;
+        if constexpr (st == 2) lds_barrier();            // B1
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int cx = jj == 0 ? (jp ? S2 : 0) : S1;
-        const int cy = jj == 0 ? (jp ? S1 : S2) : (jp ? S3 : S2);
-        const float w = (jj == 1 && jp == 0) ? 1.f : -1.f;
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-          u32x4 a0, a1, a2;
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            const float* pa = Hs + offA[mi] + hf * 4;
-            const float* pb = Hs + offB[mi] + hf * 4;
-            const f32x4 qx = *reinterpret_cast<const f32x4*>(pa + cx) + sgn * *reinterpret_cast<const f32x4*>(pb + cx);
-            const f32x4 qy = *reinterpret_cast<const f32x4*>(pa + cy) + sgn * *reinterpret_cast<const f32x4*>(pb + cy);
-            const f32x4 v = qx + w * qy;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              unsigned p0, p1, p2;
-              split3_pack(v[2 * e], v[2 * e + 1], p0, p1, p2);
-              a0[hf * 2 + e] = p0, a1[hf * 2 + e] = p1, a2[hf * 2 + e] = p2;
-            }
-          }
-#pragma unroll
-          for (int nt = 0; nt < NTB; ++nt) {
-            f32x16 t = acc[jj][nt][mi];
-            t = mfma_bf16(a2, bx[jj][nt][0], t);
-            t = mfma_bf16(a0, bx[jj][nt][2], t);
-            t = mfma_bf16(a1, bx[jj][nt][1], t);
-            t = mfma_bf16(a1, bx[jj][nt][0], t);
-            t = mfma_bf16(a0, bx[jj][nt][1], t);
-            t = mfma_bf16(a0, bx[jj][nt][0], t);
-            acc[jj][nt][mi] = t;
-          }
-          // one (component, m tile) step at a time: without this fence hipcc hoists the transforms and splits of all four
-          // steps above the first MFMA and spills ~130 registers; the VALU of one wave overlaps with the MFMAs of the other
-          // wave of its SIMD instead
-          __builtin_amdgcn_sched_barrier(0);
+        for (int nt = 0; nt < NTB; ++nt) {
+          f32x16 t = acc[jj][nt][mi];
+          t = mfma_bf16(pc[slot][2], bx[jj][nt][0], t);
+          t = mfma_bf16(pc[slot][0], bx[jj][nt][2], t);
+          t = mfma_bf16(pc[slot][1], bx[jj][nt][1], t);
+          t = mfma_bf16(pc[slot][1], bx[jj][nt][0], t);
+          t = mfma_bf16(pc[slot][0], bx[jj][nt][1], t);
+          t = mfma_bf16(pc[slot][0], bx[jj][nt][0], t);
+          acc[jj][nt][mi] = t;
         }
-        load_bx(jj, cn);   // this component's pieces of the next chunk (or the next patch's first)
-      }
+        if constexpr (st < 3) form(Hs, (st + 1) >> 1, (st + 1) & 1, slot ^ 1);
+        else form(Hn, 0, 0, slot ^ 1);
+        if constexpr (mi == 1) load_bx(jj, cn);   // this component's pieces of the next chunk (or the next patch's first)
+        constexpr int NM = 6 * NTB;                               // MFMAs of the step
+        constexpr int per = (72 + NM - 1) / NM;                   // transform (24) + split (44) + addresses of the next step
+#pragma unroll
+        for (int k = 0; k < NM; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   // one MFMA
+          if (NM >= 8 ? (k < 8) : true) __builtin_amdgcn_sched_group_barrier(0x100, NM >= 8 ? 1 : 2, 0);   // LDS reads (8 per step)
+          __builtin_amdgcn_sched_group_barrier(0x002, per, 0);                                 // VALU
+          if constexpr (mi == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // a weight-piece load
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
       buf ^= 1;
     }
     // ---- inverse transform + epilogue of patch pi ----
@@ -844,6 +875,18 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
     float* pool_out = nullptr;
     if (d.pool) pool_out = d.pool + (size_t)img * (d.H >> 1) * (d.W >> 1) * d.ldpool;
     f32x4 pmax[UPT];
+    // exchange-buffer slot of this lane's accumulator register 0; register r of (m tile mi, n tile nt) sits a COMPILE-TIME
+    // constant away.  The asm makes the base opaque per patch: otherwise hipcc hoists all 64 addresses out of the patch loop
+    // (they are loop invariant), keeps them live across the main loop at the 256-register limit and spills every one of
+    // them -- each reload then waited vmcnt(0) in the middle of the epilogue (2.2x on the whole kernel)
+    // Everything per-lane the epilogue needs is re-derived here from an OPAQUE copy of the thread id, so that none of it is
+    // live across the main loop.
+    int et = threadIdx.x;
+    asm volatile("" : "+v"(et));
+    const int cq = et % QPT;
+    const int n0 = nblock * NC + cq * 4;
+    int zb = (wi * 64 + 4 * ((et >> 5) & 1)) * ZP + (et & 31);
+    asm volatile("" : "+v"(zb));
     // per-channel scale / shift of this thread's channel quad: (re)loaded per patch from L1/L2 rather than held in eight
     // registers through the main loop (the loop runs at the 256-register limit)
     f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
@@ -865,28 +908,37 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float z = q == 0 ? acc[0][nt][mi][r] + acc[1][nt][mi][r] : acc[1][nt][mi][r];
-              const int T = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-              Zx[(wi * 64 + T) * ZP + nt * 32 + lr] = z;
+              Zx[zb + (mi * 32 + (r & 3) + 8 * (r >> 2)) * ZP + nt * 32] = z;
             }
       }
       lds_barrier();
       if (jp == 1) {
+        // read-add-write in groups of four slots (this lane is the only one adding to a slot; ds_add_f32 was measured 2x slower
+        // on the WHOLE kernel: LDS float atomics serialise).  The fence keeps hipcc from batching all 64 reads, which needs 64
+        // more registers than the epilogue has (accumulators and the next patch's weight pieces are live).
 #pragma unroll
         for (int nt = 0; nt < NTB; ++nt)
 #pragma unroll
           for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float z = q == 0 ? acc[0][nt][mi][r] : -acc[0][nt][mi][r] - acc[1][nt][mi][r];
-              const int T = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-              (void)__hip_atomic_fetch_add(&Zx[(wi * 64 + T) * ZP + nt * 32 + lr], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int rg = 0; rg < 4; ++rg) {
+              float old[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) old[e] = Zx[zb + (mi * 32 + e + 8 * rg) * ZP + nt * 32];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int r = rg * 4 + e;
+                const float z = q == 0 ? acc[0][nt][mi][r] : -acc[0][nt][mi][r] - acc[1][nt][mi][r];
+                Zx[zb + (mi * 32 + e + 8 * rg) * ZP + nt * 32] = old[e] + z;
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
       }
       lds_barrier();
       // row part + epilogue: unit u = (tile, channel quad); y(2tr, .) = Z0 + Z1 + Z2, y(2tr+1, .) = Z1 - Z2 - Z3
 #pragma unroll
       for (int k = 0; k < UPT; ++k) {
-        const int u = tid + k * 512;
+        const int u = et + k * 512;
         const int T = u / QPT;
         const float* zp = Zx + T * ZP + cq * 4;
         const f32x4 z0 = *reinterpret_cast<const f32x4*>(zp);
@@ -954,6 +1006,8 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
   }
   if (STATS) {
     float* red = smem;   // [512][8]
+    const int cq = tid % QPT;
+    (void)cq;
     lds_barrier();
     *reinterpret_cast<f32x4*>(red + tid * 8) = st1;
     *reinterpret_cast<f32x4*>(red + tid * 8 + 4) = st2;
@@ -1025,7 +1079,8 @@ bool wino_applicable(const IgemmDesc& d) {
 
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
   const bool wide = d.N > 32 && tun(d).wino_mode != 1;
-  if (tun(d).wino_prec && tun(d).wino_cp) {
+  if (tun(d).wino_prec && tun(d).wino_cp && (wide || tun(d).wino_cp_narrow) &&
+      (long)d.H * d.W * d.ldin * 4 < (1l << 31)) {   // image bytes fit a buffer descriptor
     if (d.stat_slots) return wide ? launch_wino_cp<2, true>(d, s) : launch_wino_cp<1, true>(d, s);
     return wide ? launch_wino_cp<2, false>(d, s) : launch_wino_cp<1, false>(d, s);
   }
