@@ -55,9 +55,9 @@ struct mgu_ctx {
   int pm_patch = 0;
   void* wuws = nullptr;     // Winograd weight scratch of the mgu_conv2d_nhwc building block
   size_t wuws_bytes = 0;
-  unsigned* gmaxbuf = nullptr;   // GAT: two alternating [cap] arrays of per-(graph, head) max accumulators; the aggregate kernel of
-  int gmax_cap = 0;              // one layer call clears the array the next call accumulates into (no memset launches)
-  int gmax_cur = 0, gmax_dirty[2] = {0, 0};
+  unsigned long long* gmaxbuf = nullptr;   // GAT: [64 slots][gmax_cap] per-(graph, head) max accumulators, (generation, value) words
+  int gmax_cap = 0;
+  unsigned gmax_gen = 0;                   // generation of the last layer call (gat_common.h)
   struct mgu_gat_weights* gat_tmp = nullptr;   // weights prepared by the one-shot mgu_gat_layer_forward
   void* ncws = nullptr;     // normalized-cut accumulators (mgu_ncut_forward)
   size_t ncws_bytes = 0;

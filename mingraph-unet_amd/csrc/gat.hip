@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gat_common.h"
 
 namespace mgu {
 
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void gat_edge_max_kernel(const float* __restri
                                                            const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ col,
                                                            const int32_t* __restrict__ node_graph, int N, int heads,
-                                                           float alpha, unsigned* __restrict__ gmax) {
+                                                           float alpha, gmax_t* __restrict__ gmax, int gstride, unsigned gen) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int wave_first = j - lane;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256) void gat_edge_max_kernel(const float* __restri
   const int g0 = __builtin_amdgcn_readfirstlane(g);
   const bool uniform = __all(g == g0);
   const int P = 2 * heads;
+  const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) & (GMAX_SLOTS - 1);   // this wave's accumulator line (gat_common.h)
   const float* s = st;
   const float* t = st + heads;
   int start = 0, end = 0;
@@ -119,20 +121,19 @@ __global__ __launch_bounds__(256) void gat_edge_max_kernel(const float* __restri
       e = e > 0.f ? e : alpha * e;  // LeakyReLU is monotone: max commutes with it
     }
     if (uniform) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) e = fmaxf(e, __shfl_xor(e, off));
-      if (lane == 0 && e > -INFINITY) atomicMax(&gmax[g0 * heads + h], enc_ordered(e));
+      e = wave_max_f32(e);
+      if (lane == 0 && e > -INFINITY) gmax_add(gmax, gstride, slot, g0 * heads + h, gen, e);
     } else if (e > -INFINITY) {
-      atomicMax(&gmax[g * heads + h], enc_ordered(e));
+      gmax_add(gmax, gstride, slot, g * heads + h, gen, e);
     }
   }
 }
 
 hipError_t launch_gat_edge_max(const float* st, const int32_t* rowptr, const int32_t* col, const int32_t* node_graph, int N,
-                               int heads, float alpha, unsigned* gmax_enc, hipStream_t s) {
+                               int heads, float alpha, unsigned long long* gmax_enc, int gstride, unsigned gen, hipStream_t s) {
   if (N == 0) return hipSuccess;
   hipLaunchKernelGGL(gat_edge_max_kernel, dim3((N + 255) / 256), dim3(256), 0, s, st, rowptr, col, node_graph, N, heads, alpha,
-                     gmax_enc);
+                     gmax_enc, gstride, gen);
   return hipGetLastError();
 }
 
@@ -149,14 +150,11 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
                                                             const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col,
                                                             const int32_t* __restrict__ node_graph,
-                                                            const unsigned* __restrict__ gmax, int N, int heads, int Fh,
-                                                            int concat, float alpha, float* __restrict__ out,
-                                                            unsigned* __restrict__ gmax_next, int gmax_next_n) {
+                                                            const gmax_t* __restrict__ gmax, int N, int heads, int Fh,
+                                                            int concat, float alpha, float* __restrict__ out, int gstride, unsigned gen) {
   constexpr int R = 4;    // rows (one CSR segment) per wavefront
-  if (blockIdx.x == 0)    // clear the max accumulators of the NEXT layer call (two alternating arrays, ctx.h)
-    for (int i = threadIdx.x; i < gmax_next_n; i += 256) gmax_next[i] = 0u;
   constexpr int EB = 8;   // row gathers in flight per lane
-  __shared__ __attribute__((aligned(16))) float stage[4][NCH * 256];
+  __shared__ __attribute__((aligned(16))) float stage[4][NCH == 1 ? 4 * 256 : NCH * 256];   // NCH 1: room for a wave's four rows
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // XCD-aware bijective remap of the workgroup id (blocks b, b+8, ... share an XCD)
@@ -185,6 +183,83 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
     coff4[i] = on[i] ? (unsigned)c * 4u : 0u;
   }
 
+  // per-(graph, head) max: when the segment's rows lie in ONE graph (wave-uniform, the usual case) each head's 64 slots are read
+  // once by the whole wave; a lane then keeps the value of the head its channels belong to
+  const int gs0 = node_graph ? node_graph[j0] : 0, gs1 = node_graph ? node_graph[min(j0 + R - 1, N - 1)] : 0;
+  const bool seg_one_graph = gs0 == gs1;
+  float gm_seg[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) gm_seg[i] = 0.f;
+  if (seg_one_graph)
+    for (int h = 0; h < heads; ++h) {
+      const float mh = gmax_read_wave(gmax, gstride, gs0 * heads + h, gen);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) gm_seg[i] = head[i] == h ? mh : gm_seg[i];
+    }
+
+  // ---- fast path (every patch-graph segment): all R rows have <= 4 in-edges and lie inside the graph ------------------------
+  // The R rows are processed TOGETHER: their 16 source-row gathers (16 KiB per wave) and 16 attention scalars are all in
+  // flight before the first is consumed, instead of four rows one after the other with 4 gathers each.  The row-by-row loop
+  // below costs ~350 issued instructions per row (loop control, per-row setup, per-batch masks) and leaves one row's worth
+  // of loads in flight per wave; this form issues each of them once per segment.
+  if (NCH == 1 && j0 + R <= N && ne <= 4 * R) {
+    bool small = true;
+    int s0r[R], dg[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      s0r[r] = __builtin_amdgcn_readlane(rpv, r) - start;
+      dg[r] = __builtin_amdgcn_readlane(rpv, r + 1) - start - s0r[r];
+      small = small && dg[r] <= 4;
+    }
+    if (small) {   // wave-uniform
+      f32x4 v[R][4];
+      float sv[R][4], tj[R], gm[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          // slots past the row's degree re-read its last neighbour (row j0 itself for an isolated row) and get weight 0
+          const int src = dg[r] > 0 ? __builtin_amdgcn_readlane(seg_ids, s0r[r] + min(k, dg[r] - 1)) : j0;
+          v[r][k] = *reinterpret_cast<const f32x4*>(wh + (unsigned)(src * P) + coff4[0]);
+          sv[r][k] = st[(unsigned)(src * H2) + head[0]];
+        }
+        tj[r] = st[(size_t)(j0 + r) * H2 + heads + head[0]];
+        gm[r] = seg_one_graph ? gm_seg[0] : gmax_read_lane(gmax, gstride, (node_graph ? node_graph[j0 + r] : 0) * heads + head[0], gen);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float D = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float ev = sv[r][k] + tj[r];
+          ev = ev > 0.f ? ev : alpha * ev;                                  // LeakyReLU (:65)
+          const float x = (k < dg[r] && on[0]) ? __expf(ev - gm[r]) : 0.f;  // exp(e - max(e)) (:86)
+          D += x;
+          acc += x * v[r][k];
+        }
+        if (on[0]) {
+          const float inv = __frcp_rn(D + 1e-10f);                          // (:96)
+          f32x4 o = acc * inv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : (__expf(o[q]) - 1.f);   // ELU (:118)
+          if (concat) *reinterpret_cast<f32x4*>(out + (size_t)(j0 + r) * HF + lane * 4) = o;
+          else *reinterpret_cast<f32x4*>(&stage[wave][r * 256 + lane * 4]) = o;
+        }
+      }
+      if (!concat) {   // head mean (:158): the wave's four rows through its own LDS stage
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (int u = lane; u < R * qh; u += 64) {
+          const int r = u / qh, c = u - r * qh;
+          f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+          for (int h = 0; h < heads; ++h) sum += *reinterpret_cast<const f32x4*>(&stage[wave][r * 256 + h * Fh + c * 4]);
+          *reinterpret_cast<f32x4*>(out + (size_t)(j0 + r) * Fh + c * 4) = sum * inv_heads;
+        }
+      }
+      return;
+    }
+  }
+
 #pragma unroll 1
   for (int r = 0; r < R; ++r) {
     const int j = j0 + r;
@@ -197,7 +272,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       tj[i] = st[(size_t)j * H2 + heads + head[i]];
-      gm[i] = dec_ordered(gmax[g * heads + head[i]]);
+      gm[i] = seg_one_graph ? gm_seg[i] : gmax_read_lane(gmax, gstride, g * heads + head[i], gen);
       D[i] = 0.f;
       acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -274,15 +349,15 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
 }
 
 hipError_t launch_gat_aggregate(const float* wh, int P, const float* st, const int32_t* rowptr, const int32_t* col,
-                                const int32_t* node_graph, const unsigned* gmax_enc, int N, int heads, int Fh, int concat,
-                                float alpha, float* out, unsigned* gmax_next, int gmax_next_n, hipStream_t s) {
+                                const int32_t* node_graph, const unsigned long long* gmax_enc, int N, int heads, int Fh, int concat,
+                                float alpha, float* out, int gstride, unsigned gen, hipStream_t s) {
   const int HF = heads * Fh;
   if (HF > GAT_MAX_HF || (Fh & 3) || (P & 3) || (long)N * P >= (1l << 31)) return hipErrorInvalidValue;
   if (N == 0) return hipSuccess;
   dim3 block(256);
 #define MGU_AGG(NCH)                                                                                              \
   hipLaunchKernelGGL(gat_aggregate_kernel<NCH>, dim3((N + 15) / 16), block, 0, s, wh, P, st, rowptr, col, node_graph, gmax_enc, \
-                     N, heads, Fh, concat, alpha, out, gmax_next, gmax_next_n)
+                     N, heads, Fh, concat, alpha, out, gstride, gen)
   if (HF <= 256) MGU_AGG(1);
   else if (HF <= 512) MGU_AGG(2);
   else MGU_AGG(4);

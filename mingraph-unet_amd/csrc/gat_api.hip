@@ -4,8 +4,7 @@
 // Launches per layer call with prepared weights (mgu_gat_prepare, once per weight version):
 //   Fin <= F' (the patch GAT 32 -> 4 x 64, the stress graph 64 -> 4 x 64): gat_stmax (st + per-graph max) -> gat_fused  = 2
 //   otherwise (a concat hidden layer):  GEMM [Wh | s | t] -> gat_edge_max -> gat_aggregate                              = 3
-// No memset nodes: the per-(graph, head) max accumulators alternate between two arrays and each call's last kernel clears the
-// array of the next call.
+// No memset nodes: the per-(graph, head) max accumulators carry a generation number (gat_common.h), so stale words lose every max.
 #include <algorithm>
 
 #include "ctx.h"
@@ -59,26 +58,26 @@ int check_layer_shape(mgu_ctx* c, int Fin, int heads, int Fh) {
   return MGU_OK;
 }
 
-// the array this call accumulates its maxima into, and the one its last kernel must clear for the next call
-int gmax_buffers(mgu_ctx* c, int need, unsigned** cur, unsigned** next, int* next_n) {
+// the slotted per-(graph, head) max accumulators [64 slots][cap] of 64-bit (generation, value) words and this call's generation
+int gmax_buffer(mgu_ctx* c, int need, unsigned long long** buf, unsigned* gen) {
   if (need > c->gmax_cap) {
-    const int cap = std::max(need, 1024);
+    const int cap = (std::max(need, 256) + 15) / 16 * 16;   // entries per slot: whole 128-byte lines
     if (c->gmaxbuf) {
       HIPCHK(c, hipDeviceSynchronize());
       HIPCHK(c, hipFree(c->gmaxbuf));
       c->gmaxbuf = nullptr;
     }
-    HIPCHK(c, hipMalloc((void**)&c->gmaxbuf, (size_t)2 * cap * sizeof(unsigned)));
-    HIPCHK(c, hipMemset(c->gmaxbuf, 0, (size_t)2 * cap * sizeof(unsigned)));
-    c->gmax_cap = cap, c->gmax_cur = 0, c->gmax_dirty[0] = c->gmax_dirty[1] = 0;
+    HIPCHK(c, hipMalloc((void**)&c->gmaxbuf, (size_t)64 * cap * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemset(c->gmaxbuf, 0, (size_t)64 * cap * sizeof(unsigned long long)));
+    c->gmax_cap = cap, c->gmax_gen = 0;
   }
-  const int k = c->gmax_cur;
-  *cur = c->gmaxbuf + (size_t)k * c->gmax_cap;
-  *next = c->gmaxbuf + (size_t)(k ^ 1) * c->gmax_cap;
-  *next_n = c->gmax_dirty[k ^ 1];       // what an earlier call left in the other array
-  c->gmax_dirty[k] = std::max(c->gmax_dirty[k], need);
-  c->gmax_dirty[k ^ 1] = 0;
-  c->gmax_cur = k ^ 1;
+  if (c->gmax_gen == 0xffffffffu) {   // generation wrap: start over from a cleared array
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemset(c->gmaxbuf, 0, (size_t)64 * c->gmax_cap * sizeof(unsigned long long)));
+    c->gmax_gen = 0;
+  }
+  *buf = c->gmaxbuf;
+  *gen = ++c->gmax_gen;
   return MGU_OK;
 }
 
@@ -86,9 +85,9 @@ int forward_prepared(mgu_ctx* c, const mgu_gat_weights* p, const float* X, int N
                      const int32_t* graph_ptr, int num_graphs, int concat, float alpha, float* out, hipStream_t s) {
   const int heads = p->heads, Fh = p->Fh, Fin = p->Fin, HF = heads * Fh;
   if (num_graphs < 1 || !graph_ptr) num_graphs = 1, graph_ptr = nullptr;
-  unsigned *gmax, *gnext;
-  int gnext_n;
-  int rc = gmax_buffers(c, num_graphs * heads, &gmax, &gnext, &gnext_n);
+  unsigned long long* gmax;
+  unsigned gen;
+  int rc = gmax_buffer(c, num_graphs * heads, &gmax, &gen);
   if (rc) return rc;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -107,10 +106,10 @@ int forward_prepared(mgu_ctx* c, const mgu_gat_weights* p, const float* X, int N
     const float* wf = p->buf + (size_t)2 * heads * Fin;
     {
       ProfScope ps(c, s, "gat_stmax_kernel");
-      HIPCHK(c, launch_gat_stmax(X, wa, N, Fin, heads, rowptr, col, graph_ptr, num_graphs, alpha, st, node_graph, gmax, s));
+      HIPCHK(c, launch_gat_stmax(X, wa, N, Fin, heads, rowptr, col, graph_ptr, num_graphs, alpha, st, node_graph, gmax, c->gmax_cap, gen, s));
     }
     ProfScope ps(c, s, "gat_fused_kernel");
-    HIPCHK(c, launch_gat_fused(X, Fin, st, rowptr, col, node_graph, gmax, wf, N, heads, Fh, concat, alpha, out, gnext, gnext_n, s));
+    HIPCHK(c, launch_gat_fused(X, Fin, st, rowptr, col, node_graph, gmax, wf, N, heads, Fh, concat, alpha, out, c->gmax_cap, gen, s));
     return MGU_OK;
   }
   // gather path: Wh (N, HF) node table | st (N, 2H) attention scalars from ONE GEMM, then per-graph max, then the row gather
@@ -143,10 +142,10 @@ int forward_prepared(mgu_ctx* c, const mgu_gat_weights* p, const float* X, int N
   }
   {
     ProfScope ps(c, s, "gat_edge_max_kernel");
-    HIPCHK(c, launch_gat_edge_max(st, rowptr, col, node_graph, N, heads, alpha, gmax, s));
+    HIPCHK(c, launch_gat_edge_max(st, rowptr, col, node_graph, N, heads, alpha, gmax, c->gmax_cap, gen, s));
   }
   ProfScope ps(c, s, "gat_aggregate_kernel");
-  HIPCHK(c, launch_gat_aggregate(Whp, HF, st, rowptr, col, node_graph, gmax, N, heads, Fh, concat, alpha, out, gnext, gnext_n, s));
+  HIPCHK(c, launch_gat_aggregate(Whp, HF, st, rowptr, col, node_graph, gmax, N, heads, Fh, concat, alpha, out, c->gmax_cap, gen, s));
   return MGU_OK;
 }
 

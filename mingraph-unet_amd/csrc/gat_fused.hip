@@ -24,6 +24,7 @@
 // The reference's result is reproduced up to fp32 reassociation (the sum over edges now happens before the dot
 // products with W): the parity tests' 1e-3 bar is met with > 100x margin.
 #include "common.h"
+#include "gat_common.h"
 
 namespace mgu {
 
@@ -84,24 +85,54 @@ __device__ __forceinline__ unsigned gf_enc_ordered(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// Eight lanes serve one node: lane slot 0 takes the node's own row (s_j, t_j), slots 1..7 one in-edge each (s_src, recomputed
-// from the source's row); every lane loads ITS row whole (FIN/4 16-byte loads issued back to back) and keeps the 2H dot
-// products to itself, so the only cross-lane traffic is the max over a node's eight slots (two DPP quad permutes and one
-// swizzle per head).  Rows with more than 7 in-edges take further trips.  (A thread-per-node version walked its rows with
-// dependent 16-byte loads: 18 us for 8 192 nodes; a slice-per-lane version folded 24 partial sums through ds_bpermute: 30 us.)
+// FIN/4 lanes serve one node, each a 16-byte slice of the rows -- one 128- or 256-byte line per node and load instruction, as
+// in the aggregate kernel (a row-per-lane version made the texture unit serve 64 different lines per instruction: 100 us at
+// 64 graphs).  The partial dot products of a node's lanes are folded with DPP adds (quad permutes + row_shl; the sum lands in
+// the node's first lanes), never through LDS permutes (a ds_bpermute fold: 30 us at 8 graphs); the weights of a lane's slice
+// (2H x 4 floats) stay in registers; up to four in-edge rows are in flight per trip.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int LPN>
+__device__ __forceinline__ float node_sum(float v) {   // valid in the first lanes of every LPN-lane group
+  v = dpp_add<0xB1>(v);          // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);          // quad_perm [2,3,0,1]
+  v = dpp_add<0x104>(v);         // row_shl:4  (lane i += lane i + 4)
+  if (LPN == 16) v = dpp_add<0x108>(v);   // row_shl:8
+  return v;
+}
+
 template <int FIN, int H>
 __global__ __launch_bounds__(256) void gat_stmax_kernel(const float* __restrict__ x, const float* __restrict__ wa, int N,
                                                         const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                         const int32_t* __restrict__ gp, int G, float alpha, float* __restrict__ st,
-                                                        int32_t* __restrict__ node_graph, unsigned* __restrict__ gmax) {
-  constexpr int SL = 8, NPW = 64 / SL, NQ = FIN / 4;
+                                                        int32_t* __restrict__ node_graph, gmax_t* __restrict__ gmax, int gstride, unsigned gen) {
+  constexpr int LPN = FIN / 4;          // lanes per node
+  constexpr int NPW = 64 / LPN;         // nodes per wavefront
+  constexpr int EPT = 4;                // in-edges in flight per trip (the patch grid has <= 4)
   const int lane = threadIdx.x & 63;
-  const int slot = lane & (SL - 1), ln = lane >> 3;
+  const int q = lane % LPN, ln = lane / LPN;
   const int n = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW + ln;
   if (n - ln >= N) return;   // wave-uniform
   const bool live = n < N;
   const int nd = live ? n : N - 1;
+  f32x4 ws[H], wt[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    ws[h] = *reinterpret_cast<const f32x4*>(wa + h * FIN + 4 * q);
+    wt[h] = *reinterpret_cast<const f32x4*>(wa + (H + h) * FIN + 4 * q);
+  }
+  auto dot = [](const f32x4 a, const f32x4 b) { return fmaf(a[0], b[0], fmaf(a[1], b[1], fmaf(a[2], b[2], a[3] * b[3]))); };
   const int k0 = rowptr[nd], deg = live ? rowptr[nd + 1] - k0 : 0;
+  const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)nd * FIN + 4 * q);
+  float s[H], t[H], m[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    s[h] = node_sum<LPN>(dot(xv, ws[h]));
+    t[h] = node_sum<LPN>(dot(xv, wt[h]));
+    m[h] = -INFINITY;
+  }
   int g = 0;
   if (gp && G > 1) {
     int lo = 0, hi = G;  // gp[lo] <= node < gp[hi]
@@ -111,89 +142,58 @@ __global__ __launch_bounds__(256) void gat_stmax_kernel(const float* __restrict_
     }
     g = lo;
   }
-  int maxdeg = deg;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, off));
-  float m[H], tt[H];
-#pragma unroll
-  for (int h = 0; h < H; ++h) m[h] = -INFINITY, tt[h] = 0.f;
-  for (int e0 = 0; e0 == 0 || e0 < maxdeg; e0 += SL - 1) {
-    // slot 0 of the first trip: the node itself; otherwise in-edge e0 + slot - 1 (a missing edge re-reads the node's own row
-    // and is masked: no branch around a load)
-    const int e = e0 + slot - 1;
-    const bool is_edge = slot > 0 && e < deg;
-    const int src = is_edge ? col[k0 + e] : nd;
-    const float* xr = x + (size_t)src * FIN;
-    f32x4 xv[NQ];
-#pragma unroll
-    for (int c = 0; c < NQ; ++c) xv[c] = *reinterpret_cast<const f32x4*>(xr + 4 * c);
-    float s[H];
+  if (live && q == 0) {
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-      float a = 0.f;
-#pragma unroll
-      for (int c = 0; c < NQ; ++c) {
-        const float* w = wa + h * FIN + 4 * c;      // wave-uniform: scalar loads
-        a = fmaf(xv[c][0], w[0], fmaf(xv[c][1], w[1], fmaf(xv[c][2], w[2], fmaf(xv[c][3], w[3], a))));
-      }
-      s[h] = a;
+      st[(size_t)n * (2 * H) + h] = s[h];
+      st[(size_t)n * (2 * H) + H + h] = t[h];
     }
-    if (e0 == 0) {   // t_j (slot 0 lanes use it; the others compute it for nothing, without a divergent branch)
+    if (node_graph) node_graph[n] = g;
+  }
+  // s of every in-neighbour, recomputed from its row; every load of a trip is issued before any is consumed (a missing edge
+  // re-reads col[0]'s row and is masked afterwards: no branch around a load)
+  const int maxdeg = (int)wave_max_u32((unsigned)deg);
+  for (int e0 = 0; e0 < maxdeg; e0 += EPT) {
+    f32x4 xs[EPT];
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+      const int j = col[e0 + u < deg ? k0 + e0 + u : 0];
+      xs[u] = *reinterpret_cast<const f32x4*>(x + (size_t)j * FIN + 4 * q);
+    }
+#pragma unroll
+    for (int u = 0; u < EPT; ++u)
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        float a = 0.f;
-#pragma unroll
-        for (int c = 0; c < NQ; ++c) {
-          const float* w = wa + (H + h) * FIN + 4 * c;
-          a = fmaf(xv[c][0], w[0], fmaf(xv[c][1], w[1], fmaf(xv[c][2], w[2], fmaf(xv[c][3], w[3], a))));
-        }
-        tt[h] = a;
+        const float sv = node_sum<LPN>(dot(xs[u], ws[h]));
+        m[h] = e0 + u < deg ? fmaxf(m[h], sv) : m[h];
       }
-      if (live && slot == 0) {
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-          st[(size_t)n * (2 * H) + h] = s[h];
-          st[(size_t)n * (2 * H) + H + h] = tt[h];
-        }
-        if (node_graph) node_graph[n] = g;
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < H; ++h) m[h] = fmaxf(m[h], is_edge ? s[h] : -INFINITY);
-  }
-  // max over the eight slots of a node, then t_j of slot 0 joins: quad_perm xor 1, xor 2 (DPP), xor 4 (swizzle)
-#pragma unroll
-  for (int h = 0; h < H; ++h) {
-    float v = m[h];
-    v = fmaxf(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    v = fmaxf(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F)));   // BitMode xor 4
-    m[h] = v;
   }
   const int g0 = __builtin_amdgcn_readfirstlane(g);
   const bool uniform = __all(g == g0 || !live);
+  const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) & (GMAX_SLOTS - 1);   // this wave's accumulator line (gat_common.h)
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     float e = -INFINITY;
-    if (slot == 0 && deg > 0) {
-      e = m[h] + tt[h];
+    if (q == 0 && deg > 0) {           // lane 0 of the node holds the folded sums
+      e = m[h] + t[h];
       e = e > 0.f ? e : alpha * e;   // LeakyReLU is monotone: the max commutes with it
     }
     if (uniform) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) e = fmaxf(e, __shfl_xor(e, off));
-      if (lane == 0 && e > -INFINITY) atomicMax(&gmax[g0 * H + h], gf_enc_ordered(e));
+      e = wave_max_f32(e);
+      if (lane == 0 && e > -INFINITY) gmax_add(gmax, gstride, slot, g0 * H + h, gen, e);
     } else if (e > -INFINITY) {
-      atomicMax(&gmax[g * H + h], gf_enc_ordered(e));
+      gmax_add(gmax, gstride, slot, g * H + h, gen, e);
     }
   }
 }
 
 hipError_t launch_gat_stmax(const float* x, const float* wa, int N, int Fin, int heads, const int32_t* rowptr, const int32_t* col,
-                            const int32_t* gp, int G, float alpha, float* st, int32_t* node_graph, unsigned* gmax, hipStream_t s) {
+                            const int32_t* gp, int G, float alpha, float* st, int32_t* node_graph, unsigned long long* gmax, int gstride,
+                            unsigned gen, hipStream_t s) {
   if (N == 0) return hipSuccess;
-  const dim3 grid((N + 31) / 32), block(256);   // 8 nodes per wavefront
-#define MGU_SM(FIN, H) hipLaunchKernelGGL((gat_stmax_kernel<FIN, H>), grid, block, 0, s, x, wa, N, rowptr, col, gp, G, alpha, st, node_graph, gmax)
+  const int npw = 64 / (Fin / 4);
+  const dim3 grid((N + 4 * npw - 1) / (4 * npw)), block(256);
+#define MGU_SM(FIN, H) hipLaunchKernelGGL((gat_stmax_kernel<FIN, H>), grid, block, 0, s, x, wa, N, rowptr, col, gp, G, alpha, st, node_graph, gmax, gstride, gen)
   if (Fin == 32 && heads == 1) MGU_SM(32, 1);
   else if (Fin == 32 && heads == 2) MGU_SM(32, 2);
   else if (Fin == 32 && heads == 4) MGU_SM(32, 4);
@@ -280,9 +280,9 @@ template <int FIN, int NT, int H>
 __global__ __launch_bounds__(64 * H) void gat_fused_kernel(const float* __restrict__ x, const float* __restrict__ st,
                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                            const int32_t* __restrict__ node_graph,
-                                                           const unsigned* __restrict__ gmax, const float* __restrict__ Wf,
+                                                           const gmax_t* __restrict__ gmax, const float* __restrict__ Wf,
                                                            int N, int concat, float alpha, float* __restrict__ out,
-                                                           unsigned* __restrict__ gmax_next, int gmax_next_n) {
+                                                           int gstride, unsigned gen) {
   constexpr int LPN = FIN / 4;        // lanes per node in the gather (each a 16-byte slice of the input row)
   constexpr int NPP = 64 / LPN;       // nodes per gather pass
   constexpr int PASSES = 32 / NPP;
@@ -295,10 +295,6 @@ __global__ __launch_bounds__(64 * H) void gat_fused_kernel(const float* __restri
   const int lane = threadIdx.x & 63;
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // this wave's head
   float* agg = agg_s[h];
-  // the max accumulators alternate between two buffers: this launch clears the one the NEXT layer call accumulates into
-  // (nothing of this launch reads it), so no call needs a memset node in front of its atomicMax kernel
-  if (blockIdx.x == 0)
-    for (int i = threadIdx.x; i < gmax_next_n; i += 64 * H) gmax_next[i] = 0u;
 
   // XCD-aware order: workgroup b runs on XCD b % 8; give each XCD a contiguous range of node tiles so neighbouring
   // patch rows (j +- 1, j +- npw) are served by the same L2
@@ -315,6 +311,10 @@ __global__ __launch_bounds__(64 * H) void gat_fused_kernel(const float* __restri
   float ti[PASSES], gm[PASSES], D[PASSES];
   f32x4 acc[PASSES];
   int maxdeg = 0;
+  // per-graph max of this head: one cooperative 64-slot read when the whole tile lies in one graph (the usual case)
+  const int gt0 = node_graph ? node_graph[min(n0, N - 1)] : 0, gt1 = node_graph ? node_graph[min(n0 + 31, N - 1)] : 0;
+  const bool one_graph = gt0 == gt1;                 // block-uniform
+  const float gm_tile = one_graph ? gmax_read_wave(gmax, gstride, gt0 * H + h, gen) : 0.f;
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
     const int node = n0 + p * NPP + ln;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64 * H) void gat_fused_kernel(const float* __restri
     maxdeg = max(maxdeg, deg[p]);
     const int g = node_graph ? node_graph[nd] : 0;
     ti[p] = st[(size_t)nd * P2 + H + h];
-    gm[p] = gf_dec_ordered(gmax[g * H + h]);
+    gm[p] = one_graph ? gm_tile : gmax_read_lane(gmax, gstride, g * H + h, gen);
     D[p] = 0.f;
     acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -419,20 +419,20 @@ size_t gat_fused_scratch_floats(int Fin, int heads, int Fh) { return (size_t)hea
 
 template <int FIN, int NT, int H>
 static hipError_t launch_fused_t(const float* x, const float* st, const int32_t* rowptr, const int32_t* col,
-                                 const int32_t* node_graph, const unsigned* gmax, const float* Wf, int N, int concat, float alpha,
-                                 float* out, unsigned* gmax_next, int gmax_next_n, hipStream_t s) {
+                                 const int32_t* node_graph, const unsigned long long* gmax, const float* Wf, int N, int concat, float alpha,
+                                 float* out, int gstride, unsigned gen, hipStream_t s) {
   const int ntiles = (N + 31) / 32;
   hipLaunchKernelGGL((gat_fused_kernel<FIN, NT, H>), dim3(ntiles), dim3(64 * H), 0, s, x, st, rowptr, col, node_graph, gmax, Wf, N,
-                     concat, alpha, out, gmax_next, gmax_next_n);
+                     concat, alpha, out, gstride, gen);
   return hipGetLastError();
 }
 
 hipError_t launch_gat_fused(const float* x, int Fin, const float* st, const int32_t* rowptr, const int32_t* col,
-                            const int32_t* node_graph, const unsigned* gmax, const float* Wf, int N, int heads, int Fh, int concat,
-                            float alpha, float* out, unsigned* gmax_next, int gmax_next_n, hipStream_t s) {
+                            const int32_t* node_graph, const unsigned long long* gmax, const float* Wf, int N, int heads, int Fh, int concat,
+                            float alpha, float* out, int gstride, unsigned gen, hipStream_t s) {
   if (N == 0) return hipSuccess;
 #define MGU_GF(FIN, NT, H) \
-  return launch_fused_t<FIN, NT, H>(x, st, rowptr, col, node_graph, gmax, Wf, N, concat, alpha, out, gmax_next, gmax_next_n, s)
+  return launch_fused_t<FIN, NT, H>(x, st, rowptr, col, node_graph, gmax, Wf, N, concat, alpha, out, gstride, gen, s)
 #define MGU_GF_H(FIN, NT)      \
   do {                         \
     if (heads == 1) MGU_GF(FIN, NT, 1); \

@@ -1,0 +1,97 @@
+"""Both GAT layer schedules through the prepared-weights entry points (mgu_gat_prepare / mgu_gat_layer_forward_prepared)
+against the oracle's per-head forward (model/gat/graph_attention.py:40-118, 150-160):
+  aggregate-first (Fin <= F': gat_stmax_kernel + gat_fused_kernel, 2 launches) and the Wh-row gather (GEMM + gat_edge_max +
+  gat_aggregate, forced with MGU_NO_GAT_FUSED=1 in a context of its own), on block-diagonal patch graphs (the fast path of the
+  gather kernel: every row <= 4 in-edges), a ragged random graph (rows with 0..11 in-edges, isolated nodes, a tail that is not
+  a multiple of the kernels' row groups) and repeated calls (the two alternating per-graph max arrays)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mgunet
+import mgunet_oracle as O
+from mgunet import _lib
+from mgunet.gat import coo_to_csr_device
+
+pytestmark = pytest.mark.gpu
+
+
+def make_ctx(env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return _lib.Context(0)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
+def oracle_layer(X, ei_list, W, a, heads, Fh, concat, alpha=0.2):
+    outs = []
+    for ei, lo, hi in ei_list:          # one graph at a time: the max of e is per graph (graph_attention.py:86)
+        hs = [O.gat_head_forward(X[lo:hi], ei, W[h * Fh:(h + 1) * Fh], a[h:h + 1], alpha) for h in range(heads)]
+        outs.append(torch.cat(hs, 1) if concat else torch.stack(hs).mean(0))
+    return torch.cat(outs, 0)
+
+
+def run(ctx, cuda, X, rowptr, col, gp, W, a, heads, Fh, concat):
+    L = _lib.lib()
+    N, Fin = X.shape
+    E = col.numel()
+    h = C.c_void_p()
+    s = _lib.current_stream_ptr(cuda)
+    Wd, ad = W.contiguous().to(cuda), a.contiguous().to(cuda)
+    _lib.check(L.mgu_gat_prepare(ctx.handle, Wd.data_ptr(), ad.data_ptr(), heads, Fh, Fin, 1 if E else 0, C.byref(h), s), ctx.handle)
+    out = torch.full((N, heads * Fh if concat else Fh), float("nan"), device=cuda)
+    res = []
+    for _ in range(3):                  # consecutive calls alternate between the two max-accumulator arrays
+        _lib.check(L.mgu_gat_layer_forward_prepared(ctx.handle, h, X.data_ptr(), N, rowptr.data_ptr(), col.data_ptr() if E else None, E,
+                                                    gp.data_ptr() if gp is not None else None, gp.numel() - 1 if gp is not None else 1,
+                                                    1 if concat else 0, 0.2, out.data_ptr(), s), ctx.handle)
+        res.append(out.clone())
+    torch.cuda.synchronize()
+    L.mgu_gat_release(ctx.handle, h)
+    assert torch.equal(res[0], res[1]) and torch.equal(res[1], res[2])
+    return res[0].cpu()
+
+
+@pytest.mark.parametrize("sched", ["aggregate_first", "wh_row_gather"])
+@pytest.mark.parametrize("concat", [0, 1])
+@pytest.mark.parametrize("Fin,heads,Fh", [(32, 4, 64), (64, 4, 64), (32, 2, 32)])
+def test_batched_patch_graphs(cuda, sched, concat, Fin, heads, Fh):
+    G, H, Wd = 3, 80, 112                                   # 5 x 7 patch grids
+    ctx = make_ctx({"MGU_NO_GAT_FUSED": "1"} if sched == "wh_row_gather" else {})
+    pg = mgunet.PatchGraphConstructor(16)
+    rowptr, col, gp, N1, E1 = pg.batched_csr(H, Wd, G, cuda)
+    ei = torch.from_numpy(O.patch_graph_edges(H, Wd, 16))
+    N = N1 * G
+    X = torch.from_numpy(O.formula_normal("gs/x", (N, Fin), seed=Fin + heads))
+    W = torch.from_numpy(O.formula_uniform("gs/w", (heads * Fh, Fin), -0.4, 0.4, seed=1))
+    a = torch.from_numpy(O.formula_uniform("gs/a", (heads, 2 * Fh), -0.4, 0.4, seed=2))
+    ref = oracle_layer(X, [(ei, g * N1, (g + 1) * N1) for g in range(G)], W, a, heads, Fh, concat)
+    got = run(ctx, cuda, X.to(cuda), rowptr, col, gp, W, a, heads, Fh, concat)
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("sched", ["aggregate_first", "wh_row_gather"])
+def test_ragged_random_graph_with_isolated_nodes(cuda, sched):
+    ctx = make_ctx({"MGU_NO_GAT_FUSED": "1"} if sched == "wh_row_gather" else {})
+    rng = np.random.default_rng(5)
+    N, Fin, heads, Fh = 203, 32, 4, 64
+    deg = rng.integers(0, 12, size=N)
+    deg[::9] = 0                                            # isolated targets: rows must be exactly 0
+    tgt = np.repeat(np.arange(N), deg)
+    src = rng.integers(0, N, size=tgt.size)
+    perm = rng.permutation(tgt.size)                        # COO in arbitrary order
+    ei = torch.from_numpy(np.stack([src[perm], tgt[perm]]).astype(np.int64))
+    rowptr, col = coo_to_csr_device(ei.to(cuda), N)
+    X = torch.from_numpy(O.formula_normal("gs/rx", (N, Fin), seed=3)) * 2.0
+    W = torch.from_numpy(O.formula_uniform("gs/rw", (heads * Fh, Fin), -0.5, 0.5, seed=4))
+    a = torch.from_numpy(O.formula_uniform("gs/ra", (heads, 2 * Fh), -0.5, 0.5, seed=5))
+    ref = oracle_layer(X, [(ei, 0, N)], W, a, heads, Fh, 0)
+    got = run(ctx, cuda, X.to(cuda), rowptr, col, None, W, a, heads, Fh, 0)
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float(got[::9].abs().max()) == 0.0
