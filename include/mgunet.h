@@ -269,6 +269,67 @@ int mgu_region_mean_pool(mgu_ctx* ctx, const float* feats_dev, const int32_t* ha
 int mgu_region_fuse_nhwc(mgu_ctx* ctx, const float* fu_nhwc_dev, int Cu, const float* region_emb_dev, const int32_t* hard_dev,
                          int B, int H, int W, int nph, int npw, int K, int D, float* out_nhwc_dev, void* hip_stream);
 
+/* ---- auxiliary losses of the training loops: forward values, one device float each ---------------------------
+ * Streaming reductions in double precision with a fixed summation order (bitwise reproducible); every tensor is addressed by
+ * ELEMENT strides so NCHW and NHWC storage both work without a copy. */
+/* TVLoss.forward (scripts/train_end_to_end.py:73-89): weight * (sum (x[y+1]-x[y])^2 / ((H-1) W) + sum (x[x+1]-x[x])^2 / (H (W-1))) / B
+ * over x (B,C,H,W), element (n,c,y,x) at x_dev[n*xs_n + c*xs_c + y*xs_h + x*xs_w]. */
+int mgu_tv_loss(mgu_ctx* ctx, const void* x_dev, int B, int C, int H, int W, int64_t xs_n, int64_t xs_c, int64_t xs_h, int64_t xs_w,
+                float weight, float* loss_dev, void* hip_stream);
+/* dice_loss (scripts/train_segmentation.py:29-40): softmax over the classes, one-hot target, Dice with additive smoothing per
+ * (image, class), 1 - mean.  logits element (b, c, pixel p) at logits_dev[b*ls_n + c*ls_c + p*ls_p]; labels int64 (B, HW);
+ * num_classes <= 8.  A label outside [0, num_classes) (F.one_hot raises) is reported like mgu_cross_entropy's. */
+int mgu_dice_loss(mgu_ctx* ctx, const void* logits_dev, const int64_t* labels_dev, int B, int64_t HW, int num_classes, int64_t ls_n,
+                  int64_t ls_c, int64_t ls_p, float smooth, float* loss_dev, void* hip_stream);
+/* FeatureConsistencyLoss.forward (model/unet/feature_loss.py:88-125), the (B, N, D) / (B, N) form: f_unet, f_graph (B,N,D) fp32
+ * contiguous, y (B,N) fp32 (the reference casts y.float()): mean_b sum_n [ y d^2 + (1-y) relu(margin - sqrt(d^2 + 1e-8))^2 ]. */
+int mgu_feature_consistency_loss(mgu_ctx* ctx, const void* f_unet_dev, const void* f_graph_dev, const void* y_dev, int B, int N, int D,
+                                 float margin, float* loss_dev, void* hip_stream);
+/* EllipticalShapeLoss.forward (model/unet/shape_loss.py:17-180).  _masks: the object_masks_list form, all masks of the batch
+ * stacked (num_objects, H, W) uint8 (non-zero = object pixel).  _probs: the form without masks -- per image, the pixels whose
+ * arg-max class is 1 are ONE object (:61-98); probabilities (B,C,H,W) at probs_dev[b*ps_n + c*ps_c + p*ps_p].  Objects under 10
+ * pixels are skipped; the loss is the mean over the processed objects of mean_pixels (p^T (cov + eps I)^-1 p - 1)^2, 0 if none. */
+int mgu_elliptical_shape_loss_masks(mgu_ctx* ctx, const uint8_t* masks_dev, int num_objects, int H, int W, float epsilon, float* loss_dev,
+                                    void* hip_stream);
+int mgu_elliptical_shape_loss_probs(mgu_ctx* ctx, const void* probs_dev, int B, int num_classes, int H, int W, int64_t ps_n, int64_t ps_c,
+                                    int64_t ps_p, float epsilon, float* loss_dev, void* hip_stream);
+
+/* ---- resize / gather building blocks of FeatureFusion (model/fusion_detection/feature_fusion.py:43-162) ----------------------------
+ * F.interpolate(mode='bilinear', align_corners=False) (:69-76, :140-144) of an NHWC fp32 map (B,Hi,Wi,C) with pixel pitch ld_in into
+ * channels [c_off, c_off + C) of a (B,Ho,Wo,ld_out) buffer -- i.e. straight into its slice of the fused tensor. */
+int mgu_resize_bilinear_nhwc(mgu_ctx* ctx, const void* in_dev, int ld_in, int B, int Hi, int Wi, int C, void* out_dev, int ld_out, int c_off,
+                             int Ho, int Wo, void* hip_stream);
+/* The per-region branch (:84-138): out[pixel][c_off + d] = table[ids[pixel]][d]; an id outside [0, R) gives zeros (the reference
+ * leaves such pixels of its zero-initialised map untouched).  table (R, D) fp32, ids int64 (npix). */
+int mgu_region_map_gather_nhwc(mgu_ctx* ctx, const float* table_dev, int R, int D, const int64_t* ids_dev, int64_t npix, float* out_dev,
+                               int ld_out, int c_off, void* hip_stream);
+
+/* ---- input / output pipeline around the network: byte and integer work reproduced exactly ---------------------------
+ * The reference does these steps on the host with cv2 / PIL / torchvision.  Images are HWC uint8 in device memory.
+ * ImagePreprocessor.preprocess (preprocessing/image_preprocessing/image_preprocess.py:26-31, 57-85): [BGR -> RGB | grey -> RGB] ->
+ * torchvision Resize on a PIL image = PIL's antialiased BILINEAR resample in 8-bit fixed point (horizontal pass, then vertical, 22-bit
+ * coefficients) -> ToTensor (/255) -> Normalize.  mean3 / std3: HOST arrays of 3 floats.  out element (c, y, x) at
+ * out_dev[c*os_c + y*os_h + x*os_w] (fp32): CHW as the reference returns it, or an NHWC slot of a batch. */
+int mgu_preprocess_image_u8(mgu_ctx* ctx, const uint8_t* img_dev, int Hs, int Ws, int channels /* 1 | 3 */, int bgr, int H, int W,
+                            const float* mean3, const float* std3, void* out_dev, int64_t os_c, int64_t os_h, int64_t os_w, void* hip_stream);
+/* preprocess_mask (:87-126): cv2.resize(INTER_NEAREST) (source index floor(dst * src/dst), clamped), np.clip to [0, num_classes-1], int64. */
+int mgu_preprocess_mask_u8(mgu_ctx* ctx, const uint8_t* mask_dev, int Hs, int Ws, int H, int W, int num_classes, int64_t* out_dev,
+                           void* hip_stream);
+/* EdgeDetector.sobel_edges (preprocessing/graph_feature_processing/edge_detection.py:14-44), kernel size 3: RGB -> grey (14-bit fixed
+ * point), Sobel x / y with reflect-101 borders, magnitude / max * 255 in double, truncated to uint8.  rgb (H,W,3) -> out (H,W). */
+int mgu_sobel_edges_u8(mgu_ctx* ctx, const uint8_t* rgb_dev, int H, int W, uint8_t* out_dev, void* hip_stream);
+/* HistogramEqualizer.equalize_histogram_rgb (histogram_equalization.py:13-35): RGB -> YUV, equalizeHist on Y, YUV -> RGB. */
+int mgu_equalize_hist_rgb_u8(mgu_ctx* ctx, const uint8_t* rgb_dev, int H, int W, uint8_t* out_dev, void* hip_stream);
+/* image_to_patches(map).mean(...) (scripts/graph_refinement.py:97-104): mean over each patch x patch window of a uint8 HWC map, zero
+ * padded bottom / right; per_channel = 0: one value per patch over all channels, 1: one per channel.  out (nph*npw, 1 | channels). */
+int mgu_patch_mean_u8(mgu_ctx* ctx, const uint8_t* img_dev, int H, int W, int channels, int patch, int per_channel, float* out_dev,
+                      void* hip_stream);
+/* postprocess_segmentation (scripts/infer_segmentation.py:20-51, :123): class labels int64 -> colour map uint8 (npix, 3) through a
+ * palette (num_classes, 3) the caller provides (the reference's BGR list), labels outside [0, num_classes) stay black; and, if
+ * labels_u8_dev != NULL, the uint8 label map written next to it. */
+int mgu_colorize_labels(mgu_ctx* ctx, const int64_t* labels_dev, int64_t npix, const uint8_t* palette_dev, int num_classes, uint8_t* vis_dev,
+                        uint8_t* labels_u8_dev, void* hip_stream);
+
 /* ---- per-channel building blocks of the DetectionHead: model/fusion_detection/detection_head.py ---- */
 /* y[m][c] = act(scale[c] * x[m][c] + shift[c]) over an (M, C) NHWC view with row pitches ldx / ldy (floats); scale / shift
  * may be NULL (1 / 0); act 0 = none (the BatchNorm2d that follows a ReLU, :33-38), 1 = ReLU, 2 = sigmoid (:101,104).

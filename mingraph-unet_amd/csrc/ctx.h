@@ -59,6 +59,10 @@ struct mgu_ctx {
   int gmax_cap = 0;
   unsigned gmax_gen = 0;                   // generation of the last layer call (gat_common.h)
   struct mgu_gat_weights* gat_tmp = nullptr;   // weights prepared by the one-shot mgu_gat_layer_forward
+  void* lossws = nullptr;   // partial records of the auxiliary-loss reductions (losses.hip)
+  size_t lossws_bytes = 0;
+  void* imgws = nullptr;    // resampling coefficient tables / histograms of the input pipeline (imageops.hip)
+  size_t imgws_bytes = 0;
   void* ncws = nullptr;     // normalized-cut accumulators (mgu_ncut_forward)
   size_t ncws_bytes = 0;
   int in_ch = 0, ncls = 0, feat = 0, depth = 0, dtype = 0, Cp0 = 0;

@@ -96,6 +96,8 @@ void mgu_destroy(mgu_ctx* c) {
   if (c->redws) (void)hipFree(c->redws);
   if (c->wuws) (void)hipFree(c->wuws);
   if (c->ncws) (void)hipFree(c->ncws);
+  if (c->lossws) (void)hipFree(c->lossws);
+  if (c->imgws) (void)hipFree(c->imgws);
   gat_destroy(c);
   if (c->err_word) (void)hipHostFree(c->err_word);
   for (auto e : c->ev) (void)hipEventDestroy(e);

@@ -98,8 +98,10 @@ def region_stage(patch_feats, hard_labels, B, K, region_gat: GATNetwork, nph, np
 
 
 class FeatureFusion(nn.Module):
-    """feature_fusion.py:5-162 for spatially aligned inputs -- the call of train_end_to_end.py:433-437 -- and for per-region
-    F_g with a pixel map.  Resizing mismatched scales (bilinear, :69-76, :140-143) is not on the path and raises."""
+    """feature_fusion.py:5-162 in full: every U-Net scale is brought to the target size (bilinear, align_corners=False, :69-76)
+    and written STRAIGHT into its channel slice of the fused NHWC tensor (mgu_resize_bilinear_nhwc); F_g is gathered per pixel
+    from the per-region table (:84-138, invalid ids stay zero: mgu_region_map_gather_nhwc) or resized like a scale (:140-144).
+    'concat' never materialises the intermediate torch.cat([...]) tensors; 'add' sums the two assembled maps."""
 
     def __init__(self, unet_feature_dims, gat_feature_dim, fusion_method="concat"):
         super().__init__()
@@ -107,34 +109,62 @@ class FeatureFusion(nn.Module):
         self.gat_feature_dim = gat_feature_dim
         self.fusion_method = fusion_method.lower()
 
+    @staticmethod
+    def _place(ctx, src_nchw, out_nhwc, c_off, H, W):
+        """src (B, C, h, w) -> channels [c_off, c_off + C) of out (B, H, W, ld)."""
+        B, Cs, h, w = src_nchw.shape
+        if Cs % 4:
+            raise ValueError("feature widths must be multiples of 4 (16-byte NHWC lanes)")
+        if (h, w) == (H, W):
+            out_nhwc[..., c_off:c_off + Cs] = src_nchw.permute(0, 2, 3, 1)      # same size: a strided copy, no arithmetic
+            return
+        src = src_nchw.detach().float().permute(0, 2, 3, 1).contiguous()        # a no-op for mgunet's NHWC-stored feature maps
+        dev = src.device
+        with torch.cuda.device(dev):
+            rc = _lib.lib().mgu_resize_bilinear_nhwc(ctx.handle, src.data_ptr(), Cs, B, h, w, Cs, out_nhwc.data_ptr(), out_nhwc.shape[3],
+                                                     c_off, H, W, _lib.current_stream_ptr(dev))
+        _lib.check(rc, ctx.handle)
+
     def forward(self, f_u_list, f_g, target_spatial_size=None, region_to_pixel_map=None):
         B = f_u_list[0].size(0)
         if target_spatial_size is None:
             target_spatial_size = (f_u_list[0].size(2), f_u_list[0].size(3))
-        H, W = target_spatial_size
-        for t in f_u_list:
-            if (t.size(2), t.size(3)) != (H, W):
-                raise NotImplementedError("bilinear resizing of a U-Net scale (feature_fusion.py:69-76) is not built: pass aligned features")
-        f_u = f_u_list[0] if len(f_u_list) == 1 else torch.cat(list(f_u_list), dim=1)
+        H, W = int(target_spatial_size[0]), int(target_spatial_size[1])
         if self.fusion_method not in ("concat", "add"):
             raise NotImplementedError(f"Fusion method '{self.fusion_method}' not implemented.")  # :157
-        if f_g.ndim == 2 and region_to_pixel_map is not None:
-            # per-region embeddings + a (B, H, W) map of region indices into f_g (:83-138): the fuse kernel with one "patch"
-            # per pixel and ONE table of all regions
-            idx = region_to_pixel_map.to(device=f_g.device, dtype=torch.int64)
-            valid = (idx >= 0) & (idx < f_g.shape[0])
-            table = torch.cat([f_g, torch.zeros(1, f_g.shape[1], device=f_g.device)], 0)   # invalid pixels stay zero (:137)
-            lbl = torch.where(valid, idx, torch.full_like(idx, f_g.shape[0])).reshape(-1)
-            g_nchw = region_fuse(None, table, lbl, 1, B * H, W, B * H, W, table.shape[0]).reshape(1, -1, B, H, W)[0].permute(1, 0, 2, 3)
-        elif f_g.ndim == 4:
-            if (f_g.size(2), f_g.size(3)) != (H, W):
-                raise NotImplementedError("bilinear resizing of F_g (feature_fusion.py:140-143) is not built: pass aligned features")
-            g_nchw = f_g
-        else:
+        dev = f_u_list[0].device
+        if not f_u_list[0].is_cuda:
+            raise RuntimeError("mgunet.FeatureFusion runs only on a HIP device (MI355X); there is deliberately no CPU fallback")
+        per_region = f_g.ndim == 2 and region_to_pixel_map is not None
+        if not per_region and f_g.ndim != 4:
             raise ValueError(f"f_g has unsupported shape {f_g.shape}. "
                              "Expected (Num_regions, D_gat) with region_map or (B, D_gat, H, W).")  # :144-146
-        if self.fusion_method == "add":
-            if f_u.shape[1] != g_nchw.shape[1]:
-                raise ValueError("Channel dimensions must match for 'add' fusion or implement adaptation.")  # :153-154
-            return f_u + g_nchw
-        return torch.cat([f_u, g_nchw], dim=1)
+        Cu = sum(int(t.size(1)) for t in f_u_list)
+        Dg = self.gat_feature_dim if per_region else int(f_g.size(1))
+        add = self.fusion_method == "add"
+        if add and Cu != Dg:
+            raise ValueError("Channel dimensions must match for 'add' fusion or implement adaptation.")  # :153-154
+        ctx = _context(dev)
+        fused = torch.empty((B, H, W, Cu if add else Cu + Dg), device=dev, dtype=torch.float32)
+        gbuf = torch.empty((B, H, W, Dg), device=dev, dtype=torch.float32) if add else fused
+        g_off = 0 if add else Cu
+        off = 0
+        for t in f_u_list:                                                      # :67-78
+            self._place(ctx, t, fused, off, H, W)
+            off += int(t.size(1))
+        if per_region:                                                          # :84-138
+            if Dg % 4 or f_g.shape[1] != Dg:
+                raise ValueError("gat_feature_dim must be a multiple of 4 and match f_g's width")
+            ids = region_to_pixel_map.to(device=dev, dtype=torch.int64).contiguous()
+            if tuple(ids.shape) != (B, H, W):
+                raise ValueError(f"region_to_pixel_map must be (B, H, W) = ({B}, {H}, {W})")
+            table = f_g.detach().float().contiguous()
+            with torch.cuda.device(dev):
+                rc = _lib.lib().mgu_region_map_gather_nhwc(ctx.handle, table.data_ptr(), table.shape[0], Dg, ids.data_ptr(), B * H * W,
+                                                           gbuf.data_ptr(), gbuf.shape[3], g_off, _lib.current_stream_ptr(dev))
+            _lib.check(rc, ctx.handle)
+        else:                                                                   # :140-144
+            self._place(ctx, f_g, gbuf, g_off, H, W)
+        if add:
+            fused += gbuf
+        return fused.permute(0, 3, 1, 2)

@@ -7,7 +7,7 @@ weights / inputs of oracle/mgunet_oracle.py, checks that the oracle restatement 
 stores the reference's outputs as small fixtures.  Fixtures hold data only (inputs that are
 not formula-derivable, expected outputs, sample indices) -- never reference source text.
 
-Usage:  python oracle/make_golden.py [--only tiny,gat,graph,mincut,region,dethead,c1,c2,c4,c5]
+Usage:  python oracle/make_golden.py [--only tiny,gat,graph,mincut,region,dethead,losses,c1,c2,c4,c5]
 """
 import argparse
 import os
@@ -30,6 +30,8 @@ from preprocessing.graph_construction.patch_graph_construction import PatchGraph
 from model.graph_partition.mincut_refinement import MinCutRefinement as RefMinCut  # noqa: E402
 from model.fusion_detection.feature_fusion import FeatureFusion as RefFusion  # noqa: E402
 from model.fusion_detection.detection_head import DetectionHead as RefDet  # noqa: E402
+from model.unet.feature_loss import FeatureConsistencyLoss as RefFeatLoss  # noqa: E402
+from model.unet.shape_loss import EllipticalShapeLoss as RefShapeLoss  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 TOL = 1e-5
@@ -302,6 +304,78 @@ def gen_dethead():
     save("dethead.npz", **out)
 
 
+def ellipse_mask(H, W, cy, cx, a, b, theta):
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    c, s_ = np.cos(theta), np.sin(theta)
+    u, v = (yy - cy) * c + (xx - cx) * s_, -(yy - cy) * s_ + (xx - cx) * c
+    return torch.from_numpy((u / a) ** 2 + (v / b) ** 2 <= 1.0)
+
+
+def gen_losses():
+    print("[losses] FeatureConsistencyLoss, EllipticalShapeLoss (SURVEY 8f row 3) + FeatureFusion's resize / region-map branches")
+    out = {}
+    # ---- FeatureConsistencyLoss (model/unet/feature_loss.py:88-125): (B, N, D) features, (B, N) labels ----
+    for tag, (B, N, D, margin, scale) in {"fc_a": (2, 64, 64, 1.0, 0.1), "fc_b": (3, 1024, 32, 2.5, 0.3), "fc_c": (1, 7, 20, 0.5, 1.0)}.items():
+        fu = torch.from_numpy(O.formula_normal(f"loss/{tag}/u", (B, N, D), seed=1)) * scale
+        fg = fu + torch.from_numpy(O.formula_normal(f"loss/{tag}/g", (B, N, D), seed=2)) * scale * 0.5
+        y = torch.from_numpy(O.formula_labels(f"loss/{tag}/y", (B, N), 2, seed=3))
+        fg[0, 0] = fu[0, 0]                                   # an identical pair: dist = sqrt(1e-8)
+        ref = RefFeatLoss(margin=margin)(fu, fg, y)
+        check(tag, O.feature_consistency_loss(fu, fg, y, margin).reshape(1), ref.reshape(1), tol=1e-6 * max(1.0, float(ref)))
+        out[tag] = np.float32(float(ref))
+        print(f"   {tag}: loss {float(ref):.6f}")
+    # ---- EllipticalShapeLoss (model/unet/shape_loss.py:17-180) ----
+    H, W = 96, 128
+    masks = [[ellipse_mask(H, W, 40, 50, 25, 12, 0.4), ellipse_mask(H, W, 70, 100, 8, 15, -0.9), torch.zeros(H, W, dtype=torch.bool)],
+             [ellipse_mask(H, W, 30, 30, 3, 1, 0.0),                      # 9 pixels: skipped (< 10)
+              torch.from_numpy(np.pad(np.ones((20, 30), bool), ((10, 66), (40, 58)))),          # a rectangle
+              ellipse_mask(H, W, 60, 64, 30, 30, 0.0)]]
+    ref = RefShapeLoss(epsilon=1e-6)(None, object_masks_list=masks)
+    check("shape_masks", O.elliptical_shape_loss(None, masks, 1e-6).reshape(1), torch.as_tensor(ref).reshape(1), tol=1e-5)
+    out["shape_masks"] = np.float32(float(ref))
+    out["shape_masks_in"] = np.stack([np.stack([m.numpy() for m in img]) for img in masks]).astype(np.uint8)
+    print(f"   shape (mask list): loss {float(ref):.6f}")
+    # from probabilities: class-1 arg-max region of each image as one object (:61-98); image 2 has no foreground, image 3 a tiny one
+    probs = torch.zeros(4, 3, H, W)
+    fg = [ellipse_mask(H, W, 48, 64, 35, 18, 0.7) | ellipse_mask(H, W, 20, 20, 6, 6, 0.0), ellipse_mask(H, W, 50, 60, 20, 20, 0.0),
+          torch.zeros(H, W, dtype=torch.bool), ellipse_mask(H, W, 10, 10, 1.5, 1.5, 0.0)]
+    noise = torch.from_numpy(O.formula_uniform("loss/shape/p", (4, 3, H, W), 0.0, 0.2, seed=4))
+    for b in range(4):
+        probs[b, 0] = 0.5 + noise[b, 0]
+        probs[b, 1] = torch.where(fg[b], torch.tensor(0.9), torch.tensor(0.1)) + noise[b, 1]
+        probs[b, 2] = 0.3 + noise[b, 2]
+    probs = probs / probs.sum(1, keepdim=True)
+    ref = RefShapeLoss(epsilon=1e-6)(probs)
+    check("shape_probs", O.elliptical_shape_loss(probs, None, 1e-6).reshape(1), torch.as_tensor(ref).reshape(1), tol=1e-5)
+    out["shape_probs"] = np.float32(float(ref))
+    out["shape_probs_in"] = probs.numpy()
+    ref1 = RefShapeLoss()(probs[:, :1])                       # a single class: 0 (:63-64)
+    assert float(ref1) == 0.0 and float(O.elliptical_shape_loss(probs[:, :1])) == 0.0
+    print(f"   shape (probabilities): loss {float(ref):.6f}")
+    # ---- FeatureFusion: bilinear resize of multi-scale F_u (:69-76) and of a per-pixel F_g (:140-144), region map with -1 (:84-138)
+    fu0 = torch.from_numpy(O.formula_normal("loss/ff/u0", (2, 8, 24, 40), seed=5))
+    fu1 = torch.from_numpy(O.formula_normal("loss/ff/u1", (2, 16, 12, 20), seed=6))
+    fu2 = torch.from_numpy(O.formula_normal("loss/ff/u2", (2, 4, 7, 9), seed=7))
+    fg4 = torch.from_numpy(O.formula_normal("loss/ff/g4", (2, 12, 5, 11), seed=8))
+    ref = RefFusion([8, 16, 4], 12)([fu0, fu1, fu2], fg4)
+    check("ff_multi", O.feature_fusion_full([fu0, fu1, fu2], fg4, 12), ref, tol=1e-6)
+    out["ff_multi"] = ref.numpy()
+    ref = RefFusion([8, 16, 4], 12)([fu0, fu1, fu2], fg4, target_spatial_size=(33, 17))     # up AND down scaling, odd target
+    check("ff_target", O.feature_fusion_full([fu0, fu1, fu2], fg4, 12, target_spatial_size=(33, 17)), ref, tol=1e-6)
+    out["ff_target"] = ref.numpy()
+    fg2 = torch.from_numpy(O.formula_normal("loss/ff/g2", (7, 12), seed=9))
+    rmap = torch.from_numpy(O.formula_labels("loss/ff/map", (2, 24, 40), 9, seed=10)) - 1    # ids -1 .. 7: -1 and 7 are invalid
+    ref = RefFusion([8, 16], 12)([fu0, fu1], fg2, region_to_pixel_map=rmap)
+    check("ff_regions", O.feature_fusion_full([fu0, fu1], fg2, 12, region_to_pixel_map=rmap), ref, tol=1e-6)
+    out["ff_regions"] = ref.numpy()
+    out["ff_regions_map"] = rmap.numpy().astype(np.int64)
+    fadd = torch.from_numpy(O.formula_normal("loss/ff/ga", (2, 24, 6, 10), seed=11))
+    ref = RefFusion([8, 16], 24, fusion_method="add")([fu0, fu1], fadd)
+    check("ff_add", O.feature_fusion_full([fu0, fu1], fadd, 24, method="add"), ref, tol=1e-6)
+    out["ff_add"] = ref.numpy()
+    save("losses.npz", **out)
+
+
 def gen_graph():
     print("[graph] COO index maps: 128^2/p32, 130x140/p32, 512^2/p16, 1024^2/p16, 16x16/p16 (empty)")
     out = {}
@@ -470,11 +544,11 @@ def gen_c5():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,gat,graph,mincut,region,dethead,c1,c2,c4,c5")
+    ap.add_argument("--only", default="tiny,gat,graph,mincut,region,dethead,losses,c1,c2,c4,c5")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    fns = {"tiny": gen_tiny, "gat": gen_gat, "graph": gen_graph, "mincut": gen_mincut, "region": gen_region, "dethead": gen_dethead, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
+    fns = {"tiny": gen_tiny, "gat": gen_gat, "graph": gen_graph, "mincut": gen_mincut, "region": gen_region, "dethead": gen_dethead, "losses": gen_losses, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
     for k in a.only.split(","):
         t0 = time.time()
         fns[k]()

@@ -11,12 +11,20 @@ Parity status: PINNED.  `oracle/make_golden.py` (run in the build container, whe
 `model.unet.unet_model.UNet`, `model.gat.graph_attention.GATNetwork`,
 `model.graph_partition.mincut_refinement.MinCutRefinement`,
 `model.fusion_detection.feature_fusion.FeatureFusion`,
-`model.fusion_detection.detection_head.DetectionHead` and
+`model.fusion_detection.detection_head.DetectionHead`, `model.unet.feature_loss.FeatureConsistencyLoss`,
+`model.unet.shape_loss.EllipticalShapeLoss` and
 `preprocessing.graph_construction.patch_graph_construction.PatchGraphConstructor`, asserts
 this restatement agrees (<= 1e-5 abs on O(1) logits; index maps bit-exact) and writes the
 reference's outputs to `tests/golden/`.  `tests/test_oracle_golden.py` re-checks this file against
 those fixtures on every run.  The reference's own tests hold no numeric expectations
 (SURVEY.md section 4), so the fixtures generated from the reference are the pin.
+
+NOT pinned by import (stated here and in DESIGN.md): `TVLoss` (scripts/train_end_to_end.py:73-89) and `dice_loss`
+(scripts/train_segmentation.py:29-40) live in script modules whose import needs cv2 / torchvision (absent, no network);
+`tv_loss` / `dice_loss` below restate the few lines of arithmetic and are pinned by hand-computed known answers
+(tests/test_oracle_golden.py).  The input-pipeline functions (resize / normalise / mask resize / Sobel / histogram equalisation /
+colour mask) restate cv2 and torchvision calls of modules that cannot be imported either; they are written against the
+published definitions of those operations and carry no reference-generated fixture.
 
 All citations are relative to /root/reference/MinGraph-UNet/.
 """
@@ -443,6 +451,207 @@ def feature_fusion(f_u_list, f_g, method="concat"):
             raise ValueError("Channel dimensions must match for 'add' fusion or implement adaptation.")  # :153-154
         return f_u + f_g
     raise NotImplementedError(f"Fusion method '{method}' not implemented.")  # :157
+
+
+def feature_fusion_full(f_u_list, f_g, gat_feature_dim, method="concat", target_spatial_size=None, region_to_pixel_map=None):
+    """FeatureFusion.forward in full (feature_fusion.py:43-162): multi-scale F_u brought to the target size with
+    F.interpolate(bilinear, align_corners=False) (:69-76); F_g per region gathered through region_to_pixel_map with invalid
+    ids left zero (:84-138) or per pixel and bilinearly resized (:140-144); concat | add (:149-157)."""
+    B = f_u_list[0].size(0)
+    if target_spatial_size is None:
+        target_spatial_size = (f_u_list[0].size(2), f_u_list[0].size(3))  # :64-65
+    proc = []
+    for fu in f_u_list:
+        if (fu.size(2), fu.size(3)) != tuple(target_spatial_size):
+            fu = F.interpolate(fu, size=tuple(target_spatial_size), mode="bilinear", align_corners=False)  # :71
+        proc.append(fu)
+    f_u = torch.cat(proc, dim=1)  # :78
+    if f_g.ndim == 2 and region_to_pixel_map is not None:
+        Ht, Wt = target_spatial_size
+        pix = torch.zeros(B, gat_feature_dim, Ht, Wt, dtype=f_g.dtype)  # :88
+        for b in range(B):
+            flat = region_to_pixel_map[b].reshape(-1).long()  # :120
+            valid = (flat >= 0) & (flat < f_g.shape[0])  # :123
+            tmp = torch.zeros(gat_feature_dim, Ht * Wt, dtype=f_g.dtype)
+            if int(valid.sum()) > 0:
+                tmp[:, torch.arange(Ht * Wt)[valid]] = f_g[flat[valid]].T  # :126-134
+            pix[b] = tmp.view(gat_feature_dim, Ht, Wt)  # :136
+        f_g_al = pix
+    elif f_g.ndim == 4:
+        if (f_g.size(2), f_g.size(3)) != tuple(target_spatial_size):
+            f_g_al = F.interpolate(f_g, size=tuple(target_spatial_size), mode="bilinear", align_corners=False)  # :142
+        else:
+            f_g_al = f_g
+    else:
+        raise ValueError(f"f_g has unsupported shape {f_g.shape}. Expected (Num_regions, D_gat) with region_map or (B, D_gat, H, W).")
+    if method == "concat":
+        return torch.cat([f_u, f_g_al], dim=1)
+    if method == "add":
+        if f_u.shape[1] != f_g_al.shape[1]:
+            raise ValueError("Channel dimensions must match for 'add' fusion or implement adaptation.")
+        return f_u + f_g_al
+    raise NotImplementedError(f"Fusion method '{method}' not implemented.")
+
+
+# --------------------------------------------------------------------------------------
+# Auxiliary losses (SURVEY 8f row 3), forward values
+# --------------------------------------------------------------------------------------
+def tv_loss(x: torch.Tensor, weight: float = 1.0) -> torch.Tensor:
+    """TVLoss.forward, scripts/train_end_to_end.py:78-89: squared differences of vertical / horizontal neighbours, each sum
+    divided by its count (H-1)W / H(W-1), the total divided by the batch size."""
+    B, _, H, W = x.shape
+    h_tv = ((x[:, :, 1:, :] - x[:, :, :-1, :]) ** 2).sum()   # :86
+    w_tv = ((x[:, :, :, 1:] - x[:, :, :, :-1]) ** 2).sum()   # :87
+    return weight * (h_tv / ((H - 1) * W) + w_tv / (H * (W - 1))) / B   # :84-85, :88
+
+
+def dice_loss(pred: torch.Tensor, target: torch.Tensor, smooth: float = 1.0) -> torch.Tensor:
+    """dice_loss, scripts/train_segmentation.py:29-40: softmax over classes, one-hot target, per (image, class) Dice with
+    additive smoothing, 1 - mean."""
+    p = torch.softmax(pred, dim=1)  # :30
+    onehot = F.one_hot(target, num_classes=p.shape[1]).permute(0, 3, 1, 2).float()  # :34
+    inter = (p * onehot).sum(dim=(2, 3))  # :36
+    union = p.sum(dim=(2, 3)) + onehot.sum(dim=(2, 3))  # :37
+    return 1.0 - ((2.0 * inter + smooth) / (union + smooth)).mean()  # :39-40
+
+
+def feature_consistency_loss(f_unet: torch.Tensor, f_graph: torch.Tensor, y: torch.Tensor, margin: float = 1.0) -> torch.Tensor:
+    """FeatureConsistencyLoss.forward, model/unet/feature_loss.py:88-125 -- the (B, N, D) / (B, N) form:
+    sum_p [ y ||a-b||^2 + (1-y) relu(m - sqrt(||a-b||^2 + 1e-8))^2 ], mean over the batch."""
+    if f_unet.shape != f_graph.shape:
+        raise ValueError(f"f_unet ({f_unet.shape}) and f_graph ({f_graph.shape}) must have same dimensions for this loss version.")  # :96
+    B, N, _ = f_unet.shape
+    if tuple(y.shape) != (B, N):
+        raise ValueError(f"correspondence_map_y (patch_region_labels_y) shape ({y.shape}) is not (Batch, Num_Patches) = ({B}, {N}).")  # :99-100
+    yp = y.float()  # :103
+    d2 = ((f_unet - f_graph) ** 2).sum(dim=2)  # :106
+    dist = torch.sqrt(d2 + 1e-8)  # :115
+    per = yp * d2 + (1 - yp) * F.relu(margin - dist) ** 2  # :109, :117-118
+    return per.sum(dim=1).mean()  # :123
+
+
+def _ellipse_object_term(mask: torch.Tensor, eps: float):
+    """One object of EllipticalShapeLoss (shape_loss.py:100-144 / :155-175): mean over its pixels of (p^T S^-1 p - 1)^2 with S the
+    sample covariance (torch.cov: divisor N - 1) of the centred (row, col) coordinates plus eps I; None if it is skipped."""
+    if mask.sum() < 10:  # :96, :100, :157
+        return None
+    coords = torch.nonzero(mask, as_tuple=False).float()  # :104
+    centred = coords - coords.mean(dim=0)  # :110-113
+    cov = torch.cov(centred.T)  # :131
+    inv = torch.inverse(cov + eps * torch.eye(2))  # :137
+    mah = torch.diag(centred @ inv @ centred.T)  # :143
+    return torch.mean((mah - 1.0) ** 2)  # :145
+
+
+def elliptical_shape_loss(segmentation_probs: torch.Tensor = None, object_masks_list=None, eps: float = 1e-6) -> torch.Tensor:
+    """EllipticalShapeLoss.forward, model/unet/shape_loss.py:17-180: with masks, every listed object; without, the arg-max == 1
+    region of each image as ONE object (:61-98); objects under 10 pixels are skipped; mean over the processed objects, 0 if none."""
+    terms = []
+    if object_masks_list is None:
+        B, C, _, _ = segmentation_probs.shape
+        if C <= 1:
+            return torch.tensor(0.0)  # :63-64
+        labels = torch.argmax(segmentation_probs, dim=1)  # :74
+        for b in range(B):
+            t = _ellipse_object_term(labels[b] == 1, eps)  # :68, :94-98
+            if t is not None:
+                terms.append(t)
+    else:
+        for masks in object_masks_list:
+            for m in masks:
+                t = _ellipse_object_term(m, eps)
+                if t is not None:
+                    terms.append(t)
+    return torch.stack(terms).sum() / len(terms) if terms else torch.tensor(0.0)  # :147, :177
+
+
+# --------------------------------------------------------------------------------------
+# Input / output pipeline (SURVEY 8f row 4).  cv2 and torchvision are absent, so these restate the library calls of
+# modules that cannot be imported: PIL (present) does the resize torchvision.transforms.Resize delegates to; the cv2 steps
+# follow OpenCV's documented fixed-point implementations.  No reference-generated fixture pins them.
+# --------------------------------------------------------------------------------------
+def preprocess_image(image_u8: np.ndarray, resize_dim, mean, std, bgr: bool = True) -> torch.Tensor:
+    """ImagePreprocessor.preprocess, image_preprocess.py:57-85 with the transforms of :26-31: BGR->RGB (or grey -> 3 channels),
+    ToPILImage, Resize (PIL BILINEAR with antialiasing), ToTensor (/255), Normalize."""
+    from PIL import Image
+    if image_u8.ndim == 2:
+        rgb = np.stack([image_u8] * 3, axis=2)          # cv2.COLOR_GRAY2RGB, :79-80
+    else:
+        rgb = image_u8[:, :, ::-1] if bgr else image_u8  # cv2.COLOR_BGR2RGB, :77-78
+    pil = Image.fromarray(np.ascontiguousarray(rgb))
+    pil = pil.resize((int(resize_dim[1]), int(resize_dim[0])), Image.BILINEAR)      # transforms.Resize((H, W)) on a PIL image
+    t = torch.from_numpy(np.asarray(pil).copy()).permute(2, 0, 1).float().div(255)  # ToTensor
+    m, s_ = torch.tensor(mean, dtype=torch.float32).view(3, 1, 1), torch.tensor(std, dtype=torch.float32).view(3, 1, 1)
+    return (t - m) / s_                                                              # Normalize
+
+
+def preprocess_mask(mask_u8: np.ndarray, resize_dim, num_classes: int) -> torch.Tensor:
+    """preprocess_mask, image_preprocess.py:117-125: cv2.resize(INTER_NEAREST) -- source index min(floor(dst * (1 / (dst/src))),
+    src - 1) -- np.clip, long."""
+    H, W = int(resize_dim[0]), int(resize_dim[1])
+    Hs, Ws = mask_u8.shape
+    ify, ifx = 1.0 / (H / Hs), 1.0 / (W / Ws)
+    sy = np.minimum(np.floor(np.arange(H) * ify).astype(np.int64), Hs - 1)
+    sx = np.minimum(np.floor(np.arange(W) * ifx).astype(np.int64), Ws - 1)
+    return torch.from_numpy(np.clip(mask_u8[sy][:, sx].astype(np.int64), 0, num_classes - 1))
+
+
+def _cv_gray(rgb: np.ndarray) -> np.ndarray:
+    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    return (r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14          # cv2.COLOR_RGB2GRAY, 14-bit fixed point
+
+
+def sobel_edges(rgb_u8: np.ndarray) -> np.ndarray:
+    """EdgeDetector.sobel_edges, edge_detection.py:28-44 (ksize 3): grey, Sobel x / y (BORDER_REFLECT_101) in CV_64F, magnitude,
+    / max * 255, astype(uint8)."""
+    g = np.pad(_cv_gray(rgb_u8), 1, mode="reflect").astype(np.float64)
+    gx = (g[:-2, 2:] + 2 * g[1:-1, 2:] + g[2:, 2:]) - (g[:-2, :-2] + 2 * g[1:-1, :-2] + g[2:, :-2])
+    gy = (g[2:, :-2] + 2 * g[2:, 1:-1] + g[2:, 2:]) - (g[:-2, :-2] + 2 * g[:-2, 1:-1] + g[:-2, 2:])
+    mag = np.sqrt(gx ** 2 + gy ** 2)
+    if np.max(mag) > 0:
+        return (mag / np.max(mag) * 255).astype(np.uint8)
+    return np.zeros_like(mag, dtype=np.uint8)
+
+
+def equalize_histogram_rgb(rgb_u8: np.ndarray) -> np.ndarray:
+    """HistogramEqualizer.equalize_histogram_rgb, histogram_equalization.py:27-35: cv2 RGB2YUV (14-bit fixed point), equalizeHist on
+    Y, YUV2RGB."""
+    def descale(v):
+        return (v + (1 << 13)) >> 14
+    r, g, b = (rgb_u8[..., i].astype(np.int64) for i in range(3))
+    Y = descale(r * 4899 + g * 9617 + b * 1868)
+    U = np.clip(descale((b - Y) * 8061 + (128 << 14)), 0, 255)
+    V = np.clip(descale((r - Y) * 14369 + (128 << 14)), 0, 255)
+    hist = np.bincount(Y.reshape(-1), minlength=256)
+    i0 = int(np.nonzero(hist)[0][0])
+    total = Y.size
+    lut = np.arange(256, dtype=np.int64)
+    if hist[i0] == total:
+        lut[:] = i0
+    else:
+        scale = np.float32(255.0) / np.float32(total - hist[i0])
+        csum = np.cumsum(np.where(np.arange(256) > i0, hist, 0))
+        lut = np.where(np.arange(256) > i0, np.clip(np.rint(csum.astype(np.float32) * scale), 0, 255), 0).astype(np.int64)
+    Y2 = lut[Y]
+    u, v = U - 128, V - 128
+    out = np.stack([Y2 + descale(v * 18678), Y2 + descale(u * -6472 + v * -9519), Y2 + descale(u * 33292)], axis=-1)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def patch_mean_u8(img_u8: np.ndarray, patch: int, per_channel: bool = False) -> torch.Tensor:
+    """image_to_patches(...).mean(dim=[1,2,3]) / per channel (scripts/graph_refinement.py:97-104; zero padding of :28-33)."""
+    a = img_u8[..., None] if img_u8.ndim == 2 else img_u8
+    t = torch.from_numpy(a.astype(np.float32)).permute(2, 0, 1)
+    patches, _ = image_to_patches(t, patch)
+    return patches.mean(dim=[2, 3]) if per_channel else patches.mean(dim=[1, 2, 3]).unsqueeze(-1)
+
+
+def colorize_labels(labels: np.ndarray, num_classes: int, colors) -> np.ndarray:
+    """postprocess_segmentation's colour map, infer_segmentation.py:36-49."""
+    vis = np.zeros(labels.shape + (3,), dtype=np.uint8)
+    for k in range(num_classes):
+        vis[labels == k] = colors[k]
+    return vis
 
 
 # --------------------------------------------------------------------------------------

@@ -205,3 +205,70 @@ def test_detection_head_vs_reference_fixture(golden, tag):
     assert len(got) == (3 if ncls > 1 else 2)
     for nm, t in zip(("bbox", "conf", "cls"), got):
         assert np.abs(t.numpy() - g[f"{tag}_{nm}"]).max() <= 1e-6
+
+
+def test_aux_losses_and_feature_fusion_branches_vs_reference_fixtures(golden):
+    """FeatureConsistencyLoss / EllipticalShapeLoss values and FeatureFusion's bilinear-resize and region-map branches as the
+    reference's own classes produced them (oracle/make_golden.py gen_losses)."""
+    g = golden["losses"]
+    for tag, (B, N, D, margin, scale) in {"fc_a": (2, 64, 64, 1.0, 0.1), "fc_b": (3, 1024, 32, 2.5, 0.3), "fc_c": (1, 7, 20, 0.5, 1.0)}.items():
+        fu = torch.from_numpy(O.formula_normal(f"loss/{tag}/u", (B, N, D), seed=1)) * scale
+        fg = fu + torch.from_numpy(O.formula_normal(f"loss/{tag}/g", (B, N, D), seed=2)) * scale * 0.5
+        y = torch.from_numpy(O.formula_labels(f"loss/{tag}/y", (B, N), 2, seed=3))
+        fg[0, 0] = fu[0, 0]
+        assert abs(float(O.feature_consistency_loss(fu, fg, y, margin)) - float(g[tag])) <= 1e-6 * max(1.0, float(g[tag]))
+    masks = [[torch.from_numpy(m.astype(bool)) for m in img] for img in g["shape_masks_in"]]
+    assert abs(float(O.elliptical_shape_loss(None, masks, 1e-6)) - float(g["shape_masks"])) <= 1e-5
+    probs = torch.from_numpy(g["shape_probs_in"])
+    assert abs(float(O.elliptical_shape_loss(probs, None, 1e-6)) - float(g["shape_probs"])) <= 1e-5
+    assert float(O.elliptical_shape_loss(probs[:, :1])) == 0.0
+    fu0 = torch.from_numpy(O.formula_normal("loss/ff/u0", (2, 8, 24, 40), seed=5))
+    fu1 = torch.from_numpy(O.formula_normal("loss/ff/u1", (2, 16, 12, 20), seed=6))
+    fu2 = torch.from_numpy(O.formula_normal("loss/ff/u2", (2, 4, 7, 9), seed=7))
+    fg4 = torch.from_numpy(O.formula_normal("loss/ff/g4", (2, 12, 5, 11), seed=8))
+    assert float((O.feature_fusion_full([fu0, fu1, fu2], fg4, 12) - torch.from_numpy(g["ff_multi"])).abs().max()) <= 1e-6
+    assert float((O.feature_fusion_full([fu0, fu1, fu2], fg4, 12, target_spatial_size=(33, 17)) - torch.from_numpy(g["ff_target"])).abs().max()) <= 1e-6
+    fg2 = torch.from_numpy(O.formula_normal("loss/ff/g2", (7, 12), seed=9))
+    rmap = torch.from_numpy(g["ff_regions_map"])
+    assert torch.equal(O.feature_fusion_full([fu0, fu1], fg2, 12, region_to_pixel_map=rmap), torch.from_numpy(g["ff_regions"]))
+
+
+def test_tv_and_dice_known_answers():
+    """TVLoss / dice_loss live in script modules that need cv2 (not importable here): their restatements are pinned by answers worked
+    out by hand from scripts/train_end_to_end.py:84-88 and scripts/train_segmentation.py:30-40."""
+    x = torch.arange(24.0).reshape(1, 1, 4, 6)              # vertical steps 6, horizontal steps 1
+    assert float(O.tv_loss(x)) == 37.0                      # 18*36/18 + 20*1/20
+    assert float(O.tv_loss(torch.cat([x, x]), weight=0.5)) == 18.5     # sums double, / batch 2, * weight
+    assert float(O.tv_loss(torch.ones(2, 3, 5, 5))) == 0.0
+    z = torch.zeros(1, 2, 2, 2)                             # uniform probabilities 0.5
+    t = torch.tensor([[[0, 1], [1, 1]]])
+    # class 0: I = .5, P = 2, T = 1 -> 2/4;  class 1: I = 1.5, P = 2, T = 3 -> 4/6;  1 - mean = 5/12
+    assert abs(float(O.dice_loss(z, t)) - 5.0 / 12.0) <= 1e-6
+    big = torch.full((1, 2, 2, 2), -30.0)
+    big[0, 0, 0, 0] = big[0, 1, 0, 1] = big[0, 1, 1, 0] = big[0, 1, 1, 1] = 30.0     # a perfect prediction: dice 1 per class
+    assert abs(float(O.dice_loss(big, t))) <= 1e-6
+    assert abs(float(O.dice_loss(z, t, smooth=0.0)) - (1 - (1 / 3 + 3 / 5) / 2)) <= 1e-6
+
+
+def test_input_pipeline_restatements_self_consistency():
+    """The pipeline restatements (cv2 / torchvision absent: written against the libraries' published definitions) on cases with
+    known answers: identity-size resize is the identity, nearest mask resize picks floor(dst * src / dst), a flat image has no
+    edges, equalising a two-level image stretches it to 0 / 255, patch means zero-pad."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    t = O.preprocess_image(img, (20, 30), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), bgr=True)
+    assert torch.equal(t, torch.from_numpy(img[:, :, ::-1].copy()).permute(2, 0, 1).float().div(255))
+    m = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    assert torch.equal(O.preprocess_mask(m, (6, 8), 100), torch.from_numpy(np.repeat(np.repeat(m, 2, 0), 2, 1).astype(np.int64)))
+    assert int(O.preprocess_mask(m, (2, 2), 5).max()) == 4                       # np.clip to num_classes - 1
+    assert int(O.sobel_edges(np.full((9, 9, 3), 77, np.uint8)).max()) == 0
+    step = np.zeros((8, 8, 3), np.uint8)
+    step[:, 4:] = 200
+    e = O.sobel_edges(step)
+    assert e[:, 3:5].min() == 255 and e[:, :2].max() == 0 and e[:, 6:].max() == 0
+    two = np.full((4, 4, 3), 60, np.uint8)
+    two[2:] = 180
+    h = O.equalize_histogram_rgb(two)
+    assert h[:2].max() <= 1 and h[2:].min() >= 254                               # luminance stretched to the ends
+    pm = O.patch_mean_u8(np.full((5, 5), 100, np.uint8), 4)
+    assert pm.shape == (4, 1) and abs(float(pm[0]) - 100) < 1e-4 and abs(float(pm[3]) - 100 / 16) < 1e-4
