@@ -210,6 +210,12 @@ int mgu_patch_graph_build(int H, int W, int patch, int64_t* coo, int32_t* rowptr
                           int64_t* E_out, int* nph_out, int* npw_out);
 /* HOST: stable COO(2,E int64) -> CSR-by-target for an arbitrary graph (order[k] = COO position). */
 int mgu_coo_to_csr(const int64_t* coo, int64_t E, int num_nodes, int32_t* rowptr, int32_t* col);
+/* DEVICE: the same for a graph that already lives in device memory (the reference's forward takes any (2, E) int64 edge_index,
+ * model/gat/graph_attention.py:40-58): stable sort by target, so each target's sources keep their COO order.  *status_dev (device
+ * int) becomes non-zero if an id lies outside [0, num_nodes) -- torch's indexing raises IndexError there; the caller decides when
+ * to look at it (one synchronisation per NEW graph, none per forward).  E < 2^31. */
+int mgu_coo_to_csr_device(mgu_ctx* ctx, const int64_t* coo_dev, int64_t E, int num_nodes, int32_t* rowptr_dev, int32_t* col_dev,
+                          int* status_dev, void* hip_stream);
 /* Node features of the 'full forward' (SURVEY 8a row L3): mean over each patch x patch window of an
  * NHWC feature map, zero padded bottom/right as image_to_patches does (:26-47).
  * out_dev: (B*nph*npw, C) fp32. */

@@ -165,6 +165,44 @@ def allreduce_mean_(flat: torch.Tensor, group=None) -> float:
     return 1.0 / world
 
 
+def adam_state_dict(params, exp_avg_flat, exp_avg_sq_flat, step, lr, betas, eps, weight_decay) -> dict:
+    """torch.optim.Adam.state_dict() layout from flat moment buffers in named_parameters() order (pure tensor plumbing: runs on any
+    device; the CPU tier checks it against a real torch.optim.Adam)."""
+    state, off = {}, 0
+    for i, p in enumerate(params):
+        k = p.numel()
+        if step > 0:
+            state[i] = {"step": torch.tensor(float(step)), "exp_avg": exp_avg_flat[off:off + k].detach().clone().view_as(p),
+                        "exp_avg_sq": exp_avg_sq_flat[off:off + k].detach().clone().view_as(p)}
+        off += k
+    group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False, "maximize": False, "foreach": None,
+             "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False, "params": list(range(len(params)))}
+    return {"state": state, "param_groups": [group]}
+
+
+class StepLR:
+    """optim.lr_scheduler.StepLR(optimizer, step_size, gamma) for a Trainer (train_segmentation.py:105, stepped once per epoch at
+    :143): lr = base_lr * gamma ** (epoch // step_size)."""
+
+    def __init__(self, trainer, step_size: int, gamma: float = 0.1):
+        self.trainer, self.step_size, self.gamma = trainer, int(step_size), float(gamma)
+        self.base_lr, self.last_epoch = trainer.lr, 0
+
+    def step(self) -> None:
+        self.last_epoch += 1
+        self.trainer.set_lr(self.base_lr * self.gamma ** (self.last_epoch // self.step_size))
+
+    def get_last_lr(self):
+        return [self.trainer.lr]
+
+    def state_dict(self) -> dict:
+        return {"step_size": self.step_size, "gamma": self.gamma, "base_lrs": [self.base_lr], "last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self.step_size, self.gamma, self.base_lr, self.last_epoch = sd["step_size"], sd["gamma"], sd["base_lrs"][0], sd["last_epoch"]
+        self.trainer.set_lr(self.base_lr * self.gamma ** (self.last_epoch // self.step_size))
+
+
 class Trainer:
     """The train step of scripts/train_segmentation.py:117-137 on the HIP path:
     zero_grad -> logits = model(images) (train-mode BatchNorm) -> CrossEntropyLoss (mean) -> backward ->
@@ -237,8 +275,57 @@ class Trainer:
             _lib.check(L.mgu_comm_init_rank(ctx.handle, buf, rank, world), ctx.handle)
         self._rccl = True
 
-    def set_lr(self, lr: float) -> None:  # StepLR etc. live on the host (train_segmentation.py:105,143)
+    def set_lr(self, lr: float) -> None:  # schedulers live on the host (train_segmentation.py:105,143): see StepLR below
         self.lr = lr
+
+    # ---- torch.optim.Adam-compatible optimizer state (train_segmentation.py:154-164 saves optimizer.state_dict()) ------------
+    def optimizer_state_dict(self) -> dict:
+        """What torch.optim.Adam(model.parameters(), lr, weight_decay=wd).state_dict() would hold after the same steps: per
+        parameter {'step', 'exp_avg', 'exp_avg_sq'} (views of the flat moment buffers, cloned) + one param_group.  Loadable into a
+        real torch.optim.Adam, and back (load_optimizer_state_dict)."""
+        return adam_state_dict([p for _, p in self.model.named_parameters()], self.exp_avg, self.exp_avg_sq, self.step_count,
+                               self.lr, self.betas, self.eps, self.wd)
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        params = [p for _, p in self.model.named_parameters()]
+        g = sd["param_groups"][0]
+        if len(sd["param_groups"]) != 1 or list(g["params"]) != list(range(len(params))):
+            raise ValueError("expected the single param_group of optim.Adam(model.parameters(), ...) (train_segmentation.py:96)")
+        self.lr, self.betas, self.eps, self.wd = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
+        off, steps = 0, set()
+        for i, p in enumerate(params):
+            k = p.numel()
+            st = sd["state"].get(i)
+            if st is None:                                    # a parameter Adam has not stepped yet
+                self.exp_avg[off:off + k].zero_()
+                self.exp_avg_sq[off:off + k].zero_()
+            else:
+                self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+            off += k
+        if len(steps) > 1:
+            raise ValueError("parameters with different step counts cannot be represented by the fused flat Adam")
+        self.step_count = steps.pop() if steps else 0
+
+    def save_checkpoint(self, path: str, epoch: int, loss: float) -> None:
+        """The reference's checkpoint dict (train_segmentation.py:158-163): readable by its own loaders
+        (infer_segmentation.py:90-95, segmentation_performance.py:86-110) and by torch.optim.Adam."""
+        torch.save({"epoch": epoch, "model_state_dict": {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+                    "optimizer_state_dict": self.optimizer_state_dict(), "loss": loss}, path)
+
+    def load_checkpoint(self, path: str) -> dict:
+        """Resume from either layout the reference writes: the checkpoint dict or a bare state_dict (:166-168).  Returns the dict."""
+        ck = torch.load(path, map_location=self.device)
+        sd = ck["model_state_dict"] if isinstance(ck, dict) and "model_state_dict" in ck else ck
+        with torch.no_grad():
+            own = dict(self.model.state_dict())
+            for k, v in sd.items():
+                own[k].copy_(v)                               # in place: parameters stay views of the flat buffer
+        self.model.mark_parameters_changed()
+        if isinstance(ck, dict) and "optimizer_state_dict" in ck:
+            self.load_optimizer_state_dict(ck["optimizer_state_dict"])
+        return ck if isinstance(ck, dict) else {"model_state_dict": ck}
 
     def forward_backward(self, images: torch.Tensor, masks: torch.Tensor, exchange: bool = False) -> torch.Tensor:
         """Fills self.grad with d(mean CE)/d(params) of this rank's shard; returns the loss (device scalar).

@@ -17,22 +17,28 @@ from . import _lib
 
 
 def coo_to_csr_device(edge_index: torch.Tensor, num_nodes: int):
-    """Stable COO -> CSR-by-target on the tensor's device (torch index plumbing, cached by callers)."""
+    """Stable COO -> CSR-by-target on the tensor's device (mgu_coo_to_csr_device: radix sort by target, callers cache the result).
+    Ids outside [0, num_nodes) raise IndexError here, where the reference's h[edge_index[0]] would (graph_attention.py:57): ONE
+    synchronisation per new edge_index tensor, none per forward."""
     if edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise ValueError("edge_index must have shape (2, E)")
     if edge_index.dtype != torch.int64:
         raise TypeError("edge_index must be int64 (torch.long) like the reference's")
-    E = edge_index.shape[1]
-    if E:
-        lo, hi = int(edge_index.min()), int(edge_index.max())
-        if lo < 0 or hi >= num_nodes:
-            raise IndexError(f"edge_index values must be in [0, {num_nodes}); got [{lo}, {hi}]")
-    tgt = edge_index[1]
-    order = torch.argsort(tgt, stable=True)
-    col = edge_index[0][order].to(torch.int32).contiguous()
-    rowptr = torch.zeros(num_nodes + 1, dtype=torch.int32, device=edge_index.device)
-    if E:
-        rowptr[1:] = torch.cumsum(torch.bincount(tgt, minlength=num_nodes), 0).to(torch.int32)
+    if not edge_index.is_cuda:
+        raise RuntimeError("mgunet GAT runs only on a HIP device (MI355X); there is deliberately no CPU fallback")
+    dev = edge_index.device
+    ei = edge_index.contiguous()
+    E = ei.shape[1]
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(E, dtype=torch.int32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    ctx = _context(dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().mgu_coo_to_csr_device(ctx.handle, ei.data_ptr() if E else None, E, num_nodes, rowptr.data_ptr(),
+                                              col.data_ptr() if E else None, status.data_ptr(), _lib.current_stream_ptr(dev))
+    _lib.check(rc, ctx.handle)
+    if int(status.item()):
+        raise IndexError(f"edge_index values must be in [0, {num_nodes})")
     return rowptr, col
 
 

@@ -168,3 +168,40 @@ def test_host_routines_under_asan():
     exe = os.path.join(ROOT, "mingraph-unet_amd", "lib", "host_abi_check_asan")
     r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0 and "host_abi_check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_adam_state_dict_layout_loads_into_torch_adam_and_steplr():
+    """The optimizer_state_dict a Trainer writes into the reference's checkpoint dict (train_segmentation.py:158-163) must be a valid
+    torch.optim.Adam state: load it into a real Adam and take a step; StepLR follows optim.lr_scheduler.StepLR (:105, :143)."""
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4))
+    params = list(lin.parameters())
+    n = sum(p.numel() for p in params)
+    m, v = torch.rand(n) * 1e-2, torch.rand(n) * 1e-4
+    sd = mgunet.adam_state_dict(params, m, v, 5, 1e-3, (0.9, 0.999), 1e-8, 1e-4)
+    opt = torch.optim.Adam(lin.parameters(), lr=0.5, weight_decay=0.0)
+    opt.load_state_dict(sd)
+    g = opt.param_groups[0]
+    assert g["lr"] == 1e-3 and g["weight_decay"] == 1e-4 and tuple(g["betas"]) == (0.9, 0.999)
+    st = opt.state[params[1]]
+    off = params[0].numel()
+    assert float(st["step"]) == 5.0 and torch.equal(st["exp_avg"].reshape(-1), m[off:off + params[1].numel()])
+    for p in params:
+        p.grad = torch.ones_like(p)
+    opt.step()                                              # the loaded state is usable
+    assert float(opt.state[params[0]]["step"]) == 6.0
+    assert mgunet.adam_state_dict(params, m, v, 0, 1e-3, (0.9, 0.999), 1e-8, 0.0)["state"] == {}
+
+    class T:                                                # StepLR only needs .lr / .set_lr
+        lr = 1e-3
+        def set_lr(self, lr):
+            self.lr = lr
+    t = T()
+    sch = mgunet.StepLR(t, step_size=3, gamma=0.1)
+    ref_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+    ref = torch.optim.lr_scheduler.StepLR(ref_opt, step_size=3, gamma=0.1)
+    for _ in range(8):
+        ref_opt.step()
+        ref.step()
+        sch.step()
+        assert abs(sch.get_last_lr()[0] - ref.get_last_lr()[0]) <= 1e-12

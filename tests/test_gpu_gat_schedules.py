@@ -95,3 +95,22 @@ def test_ragged_random_graph_with_isolated_nodes(cuda, sched):
     got = run(ctx, cuda, X.to(cuda), rowptr, col, None, W, a, heads, Fh, 0)
     assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
     assert float(got[::9].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,E", [(203, 1500), (1, 0), (50, 0), (5000, 200000), (7, 3)])
+def test_device_coo_to_csr_matches_host_routine_bit_exact(cuda, N, E):
+    """mgu_coo_to_csr_device (stable radix sort by target) against the host routine mgu_coo_to_csr / the oracle: index maps are
+    compared bit for bit; an id outside [0, N) raises IndexError where the reference's indexing would."""
+    rng = np.random.default_rng(N + E)
+    ei = np.stack([rng.integers(0, N, size=E), rng.integers(0, N, size=E)]).astype(np.int64)
+    rowptr, col = coo_to_csr_device(torch.from_numpy(ei).to(cuda), N)
+    orp, ocol, _ = O.coo_to_csr(ei, N)
+    assert np.array_equal(rowptr.cpu().numpy(), orp) and np.array_equal(col.cpu().numpy(), ocol)
+    if E:
+        bad = ei.copy()
+        bad[1, E // 2] = N
+        with pytest.raises(IndexError):
+            coo_to_csr_device(torch.from_numpy(bad).to(cuda), N)
+        bad[1, E // 2] = -1
+        with pytest.raises(IndexError):
+            coo_to_csr_device(torch.from_numpy(bad).to(cuda), N)

@@ -201,3 +201,44 @@ def test_backward_without_forward_is_an_error(cuda):
     ctx = model._context(cuda)
     t = torch.zeros(16, device=cuda)
     assert _lib.lib().mgu_unet_backward(ctx.handle, t.data_ptr(), t.data_ptr(), None) == _lib.MGU_ERR_STATE
+
+
+def test_checkpoint_dict_resume_and_torch_adam_interchange(cuda, tmp_path):
+    """train_segmentation.py:154-168: the checkpoint dict {'epoch', 'model_state_dict', 'optimizer_state_dict', 'loss'} written by a
+    Trainer after two steps; a FRESH trainer that loads it continues exactly like the one that kept running, and the same file drives
+    torch's own Adam on the oracle to the same parameters."""
+    cfg, shape = (3, 2, 8, 2), (2, 3, 32, 32)
+    x = torch.from_numpy(O.formula_normal("ck/x", shape, seed=23)).to(cuda)
+    y = torch.from_numpy(O.formula_labels("ck/y", (2, 32, 32), 2, seed=24)).to(cuda)
+    model = build(cfg, 23, cuda)
+    tr = mgunet.Trainer(model, lr=1e-3, weight_decay=1e-4)
+    sch = mgunet.StepLR(tr, step_size=1, gamma=0.5)
+    tr.train_step(x, y)
+    tr.train_step(x, y)
+    sch.step()                                               # lr 5e-4 from here on
+    path = str(tmp_path / "unet_segmentation_epoch_1.pth")
+    tr.save_checkpoint(path, epoch=1, loss=0.5)
+    ck = torch.load(path, map_location="cpu")
+    assert sorted(ck) == ["epoch", "loss", "model_state_dict", "optimizer_state_dict"] and ck["epoch"] == 1
+    assert ck["optimizer_state_dict"]["param_groups"][0]["lr"] == 5e-4
+    assert float(ck["optimizer_state_dict"]["state"][0]["step"]) == 2.0
+    # the reference's loaders accept the file (infer_segmentation.py:92-95)
+    m2 = mgunet.UNet(*cfg)
+    m2.load_state_dict(ck["model_state_dict"])
+    # resume in a fresh trainer
+    tr2 = mgunet.Trainer(build(cfg, 99, cuda), lr=123.0, weight_decay=0.0)     # everything wrong until the checkpoint is loaded
+    tr2.load_checkpoint(path)
+    assert tr2.lr == 5e-4 and tr2.wd == 1e-4 and tr2.step_count == 2
+    l1 = tr.train_step(x, y).clone()
+    l2 = tr2.train_step(x, y).clone()
+    torch.cuda.synchronize()
+    assert abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l1))
+    assert float((tr.flat - tr2.flat).abs().max()) <= 1e-6                      # same step from the same state (fp32 atomics order aside)
+    # torch.optim.Adam resumes from the same file: one oracle step from the checkpointed weights / moments
+    p0 = {k: v.clone() for k, v in ck["model_state_dict"].items()}
+    names = [n for n, _ in m2.named_parameters()]
+    m_, v_ = ({n: ck["optimizer_state_dict"]["state"][i][key] for i, n in enumerate(names)} for key in ("exp_avg", "exp_avg_sq"))
+    _, _, p_ref, _, _, _ = O.train_step(p0, x.cpu(), y.cpu(), cfg[3], lr=5e-4, weight_decay=1e-4, step=3, exp_avg=m_, exp_avg_sq=v_)
+    sd = dict(tr.model.named_parameters())
+    d = torch.cat([(sd[k].detach().cpu() - p_ref[k]).abs().reshape(-1) for k in names])
+    assert float(torch.quantile(d, 0.999)) <= 6e-5
