@@ -4,7 +4,7 @@ set -u
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export PYTHONDONTWRITEBYTECODE=1
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass"
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile-pass --spread-windows 0 ${BENCH_ARGS:-}"
 run() { local name=$1; shift; rm -rf gpurun_out/pmc_$name
   timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_$name -- python $ARGS > gpurun_out/pmc_$name.log 2>&1 || { echo "pmc $name failed"; tail -5 gpurun_out/pmc_$name.log; exit 1; }; echo "$name ok"; }
 run s1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS
