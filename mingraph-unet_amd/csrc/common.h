@@ -26,6 +26,7 @@ struct Tuning {
   int wino_prec = 1;        // MGU_WINO_PREC: 1 = three exact bf16 pieces per fp32 operand on the bf16 MFMA (default),
                             //                0 = fp32 MFMA operands
   bool wino_cp_narrow = true;   // MGU_WINO_CP_NARROW=0: N <= 32 layers stay on wino3x3_f32_kernel<1,1> (A/B)
+  bool wino_deep = true;    // MGU_NO_WINO_DEEP=1: one chunk of load lead on the narrow Winograd layers too (A/B)
   bool wino_cp = true;      // MGU_NO_WINO_CP=1: the four-components-per-wave kernel instead of the component-pair split (A/B)
   int wino_rounds = 1;      // MGU_WINO_ROUNDS / MGU_WINO_PPB_CAP: persistence of the Winograd workgroups
   int wino_ppb_cap = 32;
@@ -77,7 +78,13 @@ inline const Tuning& tun(const IgemmDesc& d) { return d.tn ? *d.tn : default_tun
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
 bool halo_pool_fusable(const IgemmDesc& d, int dtype);   // the halo conv kernel will run: MaxPool2d(2) can ride in its epilogue
 hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s);
-const char* igemm_kernel_name(const IgemmDesc& d, int dtype);   // the kernel family launch_igemm_* will pick (profiling records)  // in / w / out point to bf16, sizes in elements
+const char* igemm_kernel_name(const IgemmDesc& d, int dtype);
+// convt_x3.hip: fp32 ConvTranspose2d(k2,s2) on the bf16 matrix cores with exact three-way operand splits (IgemmDesc::wu =
+// fragment-ordered weight pieces)
+size_t convt_x3_floats(int Cin, int Cout);
+hipError_t launch_pack_convt_x3(const float* w, float* Wx, int Cin, int Cout, hipStream_t s);
+bool convt_x3_applicable(const IgemmDesc& d);
+hipError_t launch_convt_x3(const IgemmDesc& d, hipStream_t s);   // the kernel family launch_igemm_* will pick (profiling records)  // in / w / out point to bf16, sizes in elements
 // elementwise.hip: first convolution (<= 4 input channels on the packed NHWC4 input), VALU + scalar-cache weights
 hipError_t launch_pack_first_w(const float* w, float* wf, int Cout, int Cin, hipStream_t s);
 bool first_conv_applicable(int dtype, int Cin, int Cp, int Cout, int ldout, int coff);

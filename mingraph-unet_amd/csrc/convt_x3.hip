@@ -1,0 +1,230 @@
+// ConvTranspose2d(kernel 2, stride 2) of the fp32 configuration (model/unet/unet_decoder.py:25,36) on the bf16 matrix cores
+// with EXACT three-way operand splits -- the same arithmetic as the Winograd kernels' PREC = 1 mode (wino_f32.hip):
+//   a = a0 + a1 + a2 (8 + 8 + 8 mantissa bits by truncation),  a b ~= a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a2 b0 + a1 b1),
+// six v_mfma_f32_32x32x16_bf16 per 16 input channels with fp32 accumulation; the dropped terms are below one fp32 rounding.
+//
+// Why: the four ConvTranspose layers are one GEMM each, out[(2y+dy, 2x+dx)][co] = sum_ci in[(y,x)][ci] * w[ci][co][dy][dx]
+// (M = B H W pixels, N = 4 Cout, K = Cin), 34 GFLOP per headline step.  On v_mfma_f32_32x32x2_f32 that is >= 219 us at the
+// fp32 matrix peak (measured ~400 us on the generic tile kernel) against ~150 us of HBM time for the 0.75 GB they move; the
+// six bf16 passes cost 6/16 of the fp32 MFMA time and leave the VALU free for the split (the fp32 MFMA blocks it).
+//
+// Structure: no LDS tiles and no barrier in the main loop.  Both operands reach the registers already in MFMA fragment order:
+//   A: lane (r = lane & 31, h = lane >> 5) of an m tile needs in[row r][k = 16 s + 8 h .. + 7] = 32 contiguous bytes of an NHWC
+//      pixel: two 16-byte global loads, split into three bf16x8 pieces in registers (5.5 VALU per value);
+//   B: the weights are split and laid out per lane at load time (pack_convt_x3), so a wave's six fragments of a K = 16 step are
+//      six 16-byte loads from a contiguous 6 KB block that every workgroup of the same n tile reads (L2 resident).
+// Workgroup = 4 waves on a 128 pixel x 128 column tile, wave tile 64 x 64 (2 x 2 MFMA tiles, 24 MFMAs per K = 16 step),
+// register double buffering one step ahead.  Workgroup ids are remapped so that the n tiles of one pixel tile run on the same
+// XCD back to back: the pixel rows are fetched from HBM once and re-read from that XCD's L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "common.h"
+
+namespace mgu {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+// exact three-way split of two fp32 values into packed bf16 pieces (low half: a, high half: b)
+__device__ __forceinline__ void split3_pack(const float a, const float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  p0 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+  const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
+  const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+  p1 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+  const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
+  p2 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// Wx[n / 128][k / 16][(n / 32) & 3][piece][lane = 32 * ((k / 8) & 1) + (n & 31)][k & 7]   (uint16 bf16 bit patterns)
+// n = (dy * 2 + dx) * Cout + co: the column order of the pixel-shuffle store.  w is nn.ConvTranspose2d's (Cin, Cout, 2, 2).
+__global__ void pack_convt_x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ Wx, int Cin, int Cout) {
+  const int N = 4 * Cout;
+  const int64_t total = (int64_t)Cin * N;
+  const int ksteps = Cin >> 4;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % Cin), n = (int)(idx / Cin);
+    const int q = n / Cout, co = n - q * Cout;
+    const float x = w[(((int64_t)k * Cout + co) * 2 + (q >> 1)) * 2 + (q & 1)];
+    const unsigned b0 = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(b0);            // exact
+    const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(b1);           // exact; 8 significant bits are left
+    const int lane = ((k >> 3) & 1) * 32 + (n & 31);
+    uint16_t* dst = Wx + (((((int64_t)(n >> 7) * ksteps + (k >> 4)) * 4 + ((n >> 5) & 3)) * 3) * 64 + lane) * 8 + (k & 7);
+    dst[0] = (uint16_t)(b0 >> 16);
+    dst[512] = (uint16_t)(b1 >> 16);
+    dst[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __restrict__ in, const int ldin, const uint16_t* __restrict__ Wx,
+                                                             const float* __restrict__ shift, float* __restrict__ out, const int M,
+                                                             const int H, const int W, const int Cin, const int Cout, const int ldout,
+                                                             const int coff, const int Hout, const int Wout, const int ntn,
+                                                             const int nblocks) {
+  __shared__ int rowoff[128];
+  // XCD-aware order: hardware deals consecutive workgroup ids round-robin to the 8 XCDs; logical block lb runs on XCD
+  // blockIdx % 8 and a contiguous range of logical blocks (all n tiles of a pixel tile, neighbouring pixel tiles) shares an L2
+  const int chunk = gridDim.x >> 3;
+  const int lb = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (lb >= nblocks) return;   // block-uniform, before any barrier
+  const int nt = lb % ntn, mt = lb / ntn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int bm0 = mt * 128;
+  const int HW = H * W;
+  // element offset of every row's output pixel (2y, 2x) relative to the tile's first one: decoded once per workgroup (two
+  // integer divisions per row), read back per accumulator register
+  long long pix0;
+  {
+    const int img = bm0 / HW, rem = bm0 - img * HW, y = rem / W;
+    pix0 = ((long long)img * Hout + 2 * y) * Wout + 2 * (rem - y * W);
+  }
+  if (tid < 128) {
+    const int m = bm0 + tid;
+    int off = 0;
+    if (m < M) {
+      const int img = m / HW, rem = m - img * HW, y = rem / W, x = rem - y * W;
+      off = (int)((((long long)img * Hout + 2 * y) * Wout + 2 * x - pix0) * ldout);   // a tile spans < 2^31 elements (host check)
+    }
+    rowoff[tid] = off;
+  }
+  __syncthreads();
+
+  const int ksteps = Cin >> 4;
+  const float* ap[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int row = min(bm0 + wm * 64 + mi * 32 + lr, M - 1);   // rows past the end re-read the last pixel, never stored
+    ap[mi] = in + (size_t)row * ldin + lh * 8;
+  }
+  const u32x4* const bp = reinterpret_cast<const u32x4*>(Wx) + ((size_t)nt * ksteps * 12 + wn * 6) * 64 + lane;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  f32x4 ar[2][2][2];   // [buffer][m tile][k half]
+  u32x4 br[2][6];      // [buffer][n tile * 3 + piece]
+  auto load = [&](int s, auto buf_t) {
+    constexpr int buf = decltype(buf_t)::value;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) br[buf][f] = bp[((size_t)s * 12 + f) * 64];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      ar[buf][mi][0] = *reinterpret_cast<const f32x4*>(ap[mi] + s * 16);
+      ar[buf][mi][1] = *reinterpret_cast<const f32x4*>(ap[mi] + s * 16 + 4);
+    }
+  };
+  auto compute = [&](auto buf_t) {
+    constexpr int buf = decltype(buf_t)::value;
+    u32x4 pa[2][3];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          unsigned p0, p1, p2;
+          split3_pack(ar[buf][mi][hf][2 * e], ar[buf][mi][hf][2 * e + 1], p0, p1, p2);
+          pa[mi][0][2 * hf + e] = p0, pa[mi][1][2 * hf + e] = p1, pa[mi][2][2 * hf + e] = p2;
+        }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        f32x16 t = acc[mi][ni];
+        // smallest terms first
+        t = mfma_bf16(pa[mi][2], br[buf][ni * 3 + 0], t);
+        t = mfma_bf16(pa[mi][0], br[buf][ni * 3 + 2], t);
+        t = mfma_bf16(pa[mi][1], br[buf][ni * 3 + 1], t);
+        t = mfma_bf16(pa[mi][1], br[buf][ni * 3 + 0], t);
+        t = mfma_bf16(pa[mi][0], br[buf][ni * 3 + 1], t);
+        t = mfma_bf16(pa[mi][0], br[buf][ni * 3 + 0], t);
+        acc[mi][ni] = t;
+      }
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  load(0, B0{});
+  for (int s = 0; s < ksteps; s += 2) {
+    load(min(s + 1, ksteps - 1), B1{});   // unconditional (the last trip of an odd count re-reads its own step)
+    compute(B0{});
+    if (s + 1 < ksteps) {
+      load(min(s + 2, ksteps - 1), B0{});
+      compute(B1{});
+    }
+  }
+
+  // ---- epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); 32 lanes store the 128
+  // contiguous bytes of 32 output channels of one output pixel
+  float* const tile_out = out + (size_t)pix0 * ldout + coff;
+  const bool full_m = bm0 + 128 <= M;
+  auto store_tile = [&](auto guarded_t) {
+    constexpr bool GUARDED = decltype(guarded_t)::value;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = nt * 128 + wn * 64 + ni * 32 + lr;
+      const int q = n / Cout;
+      const int ncol = ((q >> 1) * Wout + (q & 1)) * ldout + (n - q * Cout);
+      const float sh = shift ? shift[n] : 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rrow = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const unsigned idx = (unsigned)(rowoff[rrow] + ncol);
+          const float v = acc[mi][ni][r] + sh;
+          if (!GUARDED) tile_out[idx] = v;
+          else if (bm0 + rrow < M) tile_out[idx] = v;
+        }
+    }
+  };
+  if (full_m) store_tile(std::false_type{});
+  else store_tile(std::true_type{});
+}
+
+}  // namespace
+
+size_t convt_x3_floats(int Cin, int Cout) { return (size_t)Cin * Cout * 6; }   // 4 Cout columns x Cin x 3 pieces x 2 bytes
+
+hipError_t launch_pack_convt_x3(const float* w, float* Wx, int Cin, int Cout, hipStream_t s) {
+  if ((Cin & 15) || (Cout & 31)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_convt_x3_kernel, dim3((unsigned)std::min<int64_t>(4096, ((int64_t)Cin * Cout * 4 + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<uint16_t*>(Wx), Cin,
+                     Cout);
+  return hipGetLastError();
+}
+
+bool convt_x3_applicable(const IgemmDesc& d) {
+  return d.out_mode == 1 && d.wu && d.KS == 1 && d.K == d.Cp && (d.Cp & 15) == 0 && (d.ct_cout & 31) == 0 && d.N == 4 * d.ct_cout &&
+         (d.ldin & 3) == 0 && !d.scale && !d.relu && !d.split_n && tun(d).wino_prec != 0 &&
+         (9l * 128 + 8l * d.Wout) * d.ldout < (1l << 31);   // the output pixels of a tile's 128 rows span < 2^31 elements
+}
+
+hipError_t launch_convt_x3(const IgemmDesc& d, hipStream_t s) {
+  const int mtiles = (d.M + 127) / 128, ntn = d.N / 128;
+  const int nb = mtiles * ntn;
+  const int chunk = (nb + 7) / 8;
+  hipLaunchKernelGGL(convt2x2_x3_kernel, dim3(chunk * 8), dim3(256), 0, s, d.in, d.ldin, reinterpret_cast<const uint16_t*>(d.wu), d.shift, d.out,
+                     d.M, d.H, d.W, d.Cp, d.ct_cout, d.ldout, d.coff, d.Hout, d.Wout, ntn, nb);
+  return hipGetLastError();
+}
+
+}  // namespace mgu

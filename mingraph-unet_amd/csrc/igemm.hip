@@ -608,7 +608,7 @@ const char* igemm_kernel_name(const IgemmDesc& d, int dtype) {
     if (d.out_mode == 1) return "igemm_kernel<bf16> (ConvTranspose)";
     return halo_np<__bf16>(d) ? "conv3x3_halo_kernel<bf16>" : "igemm_kernel<bf16>";
   }
-  if (d.out_mode == 1) return "igemm_kernel<f32> (ConvTranspose)";
+  if (d.out_mode == 1) return convt_x3_applicable(d) ? "convt2x2_x3_kernel" : "igemm_kernel<f32> (ConvTranspose)";
   if (wino_applicable(d)) {
     const bool wide = d.N > 32 && tun(d).wino_mode != 1;
     if (tun(d).wino_prec && tun(d).wino_cp && (wide || tun(d).wino_cp_narrow) && (long)d.H * d.W * d.ldin * 4 < (1l << 31)) return wide ? "wino3x3_cp_kernel<2>" : "wino3x3_cp_kernel<1>";
@@ -624,6 +624,7 @@ hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s) {
   if ((d.Cp & 3) || (d.ldin & 3) || (d.Kp % 32) || d.K > d.Kp) return hipErrorInvalidValue;
   if (d.out_mode == 1) {
     if (d.KS != 1) return hipErrorInvalidValue;
+    if (convt_x3_applicable(d)) return launch_convt_x3(d, s);
     return launch_tiles<float, 1, 1>(d, s);
   }
   if (wino_applicable(d)) return launch_wino_f32(d, s);

@@ -47,7 +47,7 @@ WsPlan plan_ws(const mgu_ctx* c, int B, int H, int W) {
 
 extern "C" {
 
-const char* mgu_version(void) { return "mgunet 0.1 (gfx950, fp32 MFMA)"; }
+const char* mgu_version(void) { return "mgunet 0.2 (gfx950: fp32 Winograd / bf16 MFMA forward, fp32 training step, GAT, RCCL gradient exchange)"; }
 
 int mgu_create(int device_id, mgu_ctx** out) {
   if (!out) return fail(nullptr, MGU_ERR_INVALID, "out == NULL");
@@ -72,6 +72,7 @@ int mgu_create(int device_id, mgu_ctx** out) {
   t.wino_mode = num("MGU_WINO_MODE", -1);
   t.wino_prec = num("MGU_WINO_PREC", t.wino_prec) ? 1 : 0;
   t.wino_cp = !flag("MGU_NO_WINO_CP");
+  t.wino_deep = !flag("MGU_NO_WINO_DEEP");
   t.wino_cp_narrow = num("MGU_WINO_CP_NARROW", 1) != 0;
   t.wino_rounds = std::max(1, num("MGU_WINO_ROUNDS", 1));
   t.wino_ppb_cap = std::max(1, num("MGU_WINO_PPB_CAP", 32));
@@ -171,6 +172,8 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     total += (size_t)L.Np * L.Kp + 2 * (size_t)L.Np + (L.bn.empty() ? 0 : 4 * (size_t)L.Np);
     L.wino = dtype == MGU_DTYPE_F32 && !L.convt && L.KS == 3 && L.Cp % 16 == 0;   // Winograd F(2x2,3x3) layers (wino_f32.hip)
     if (L.wino) total += wino_u_floats(L.Cout, L.Cp);
+    L.ctx3 = dtype == MGU_DTYPE_F32 && L.convt && L.Cin % 16 == 0 && L.Cout % 32 == 0 && c->tn.wino_prec != 0;
+    if (L.ctx3) total += convt_x3_floats(L.Cin, L.Cout);
     L.first = !L.convt && L.KS == 3 && first_conv_applicable(dtype, L.Cin, L.Cp, L.Cout, 8, 0);
     if (L.first) total += 9 * 4 * (size_t)L.Cout;
   }
@@ -216,6 +219,7 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     p += L.Np;
     L.wu = nullptr;
     if (L.wino) L.wu = p, p += wino_u_floats(L.Cout, L.Cp);
+    if (L.ctx3) L.wu = p, p += convt_x3_floats(L.Cin, L.Cout);
     L.wf = nullptr;
     if (L.first) L.wf = p, p += 9 * 4 * (size_t)L.Cout;
     if (!L.bn.empty()) {
@@ -278,6 +282,7 @@ int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void*
       if ((rc = get(cw + ".bias", L.Cout, &b))) return rc;
       L.w_src = w, L.b_src = b;
       HIPCHK(c, launch_pack_convt_w(w, L.wp, c->dtype, L.Cin, L.Cout, L.Kp, s));
+      if (L.ctx3) HIPCHK(c, launch_pack_convt_x3(w, L.wu, L.Cin, L.Cout, s));
       HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 4, s));  // scale unused (nullptr at launch)
     } else {
       if ((rc = get(cw + ".weight", (int64_t)L.Cout * L.Cin * L.KS * L.KS, &w))) return rc;
@@ -383,6 +388,7 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
   const double alg = L.convt ? 2.0 * d.M * (double)L.Cin * L.Cout * 4.0 : 2.0 * d.M * (double)L.KS * L.KS * L.Cin * L.Cout;
   double mfma = L.convt ? alg : 2.0 * d.M * (double)L.K * L.Cout;
   int pipe = c->dtype == MGU_DTYPE_BF16 ? 1 : 0;
+  if (c->dtype == MGU_DTYPE_F32 && convt_x3_applicable(d)) mfma = 6.0 * alg, pipe = 1;
   if (c->dtype == MGU_DTYPE_F32 && wino_applicable(d)) {
     mfma = 2.0 * B * ((H + 1) / 2) * ((W + 1) / 2) * 16.0 * L.Cp * L.Cout * (c->tn.wino_prec ? 6.0 : 1.0);
     pipe = c->tn.wino_prec ? 1 : 0;
@@ -667,13 +673,16 @@ int mgu_conv_transpose2x2_nhwc(mgu_ctx* c, const void* in_dev, int B, int H, int
   hipStream_t s = (hipStream_t)hip_stream;
   const int Kp = rup(Cin, 32), N = 4 * Cout, Np = rup(N, 128);
   float *wp, *sc, *sh;
-  int rc = block_scratch(c, Np, Kp, &wp, &sc, &sh, s);
+  // the three-piece kernel (convt_x3.hip) reads 6 bytes per weight in fragment order instead of the 4-byte panel
+  const bool x3 = Cin % 16 == 0 && Cout % 32 == 0 && c->tn.wino_prec != 0;
+  int rc = block_scratch(c, Np, x3 ? rup(Kp * 3 / 2, 32) : Kp, &wp, &sc, &sh, s);
   if (rc) return rc;
-  HIPCHK(c, launch_pack_convt_w((const float*)w_dev, wp, 0, Cin, Cout, Kp, s));
+  if (x3) HIPCHK(c, launch_pack_convt_x3((const float*)w_dev, wp, Cin, Cout, s));
+  else HIPCHK(c, launch_pack_convt_w((const float*)w_dev, wp, 0, Cin, Cout, Kp, s));
   IgemmDesc d;
   memset(&d, 0, sizeof d);
   d.tn = &c->tn;
-  d.in = (const float*)in_dev, d.w = wp, d.out = (float*)out_dev;
+  d.in = (const float*)in_dev, d.w = wp, d.wu = x3 ? wp : nullptr, d.out = (float*)out_dev;
   d.M = B * H * W, d.H = H, d.W = W, d.Cp = Cin, d.ldin = Cin, d.KS = 1, d.K = Cin, d.Kp = Kp;
   d.N = N, d.ldout = ld_out, d.coff = c_off, d.out_mode = 1, d.ct_cout = Cout, d.Hout = 2 * H, d.Wout = 2 * W;
   if (bias_dev) {

@@ -653,23 +653,36 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
 // jp = 0 waves store their part of it into the exchange buffer and the jp = 1 waves add theirs with ds_add_f32 one barrier
 // later; the finishing pass (row part, epilogue, fused pool / statistics) is the one of wino3x3_f32_kernel.
 // =================================================================================================================
-template <int NTB, bool STATS>
+// floats of one raw halo buffer of wino3x3_cp_kernel (10 x 34 pixels x 20, staged in 3 x 128 slots) = its exchange buffer
+constexpr int WINO_CP_RAWF = 8192;
+
+// DEEP (narrow layers, even chunk count): the raw halo and the weight pieces are requested TWO chunks ahead instead of one.
+// A chunk of a 32-channel tile is only 24 MFMAs per wave (~0.7 us), less than an HBM round trip under load, so with one chunk
+// of lead every chunk of the 512^2 layers waited for its halo (2.5-2.8 TB/s, neither pipe busy).  The memory pipe retires a
+// wave's loads in order, so BOTH kinds of load need the longer lead: a weight piece issued behind a young halo load could not
+// complete before it.  Costs a second set of halo (12) and weight-piece (24) registers; chunk parity is static (loop unrolled
+// by two), so no register is ever moved.
+template <int NTB, bool STATS, bool DEEP>
 __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y, const int total_patches,
                         const int patches_per_block, const int ngroups, const int nitems, const int per_xcd) {
   constexpr int NWAVES = 8;
   constexpr int MT = 2;                          // both m tiles of the 8 x 32 pixel patch
   constexpr int NC = 32 * NTB;                   // output channels per workgroup
-  constexpr int ZP = NC + 8;                     // exchange-buffer pitch of a tile (floats)
-  constexpr int QPT = NC / 4;                    // channel quads per tile
-  constexpr int UPT = 64 * QPT / 512;            // (tile, channel quad) units a thread finishes per pass
+  constexpr int ZP = 32;                         // exchange-buffer pitch of a tile (floats): one n tile per pass, no padding
+                                                 // (32 lanes write 32 consecutive floats; the finishing 16-byte reads of
+                                                 // thread (tile T = t / 8, quad t % 8) fall on 64 distinct banks per lane group)
   constexpr int RH = 10, RW = 34, HPIX = RH * RW;
   constexpr int PLD = 20;
   constexpr int HSTRIDE = NWAVES * 16;
   constexpr int HR = (HPIX + HSTRIDE - 1) / HSTRIDE;
   constexpr int S1 = 17 * PLD, S2 = PLD, S3 = 17 * PLD + PLD;   // LDS offsets of tile columns 1..3 (parity planes)
-  constexpr int RAWF = HR * HSTRIDE / RW * 34 * PLD + 34 * PLD;
+  // A raw buffer also serves as the exchange buffer of the inverse transform ([4 rows i][64 tiles][32 channels] = 8192 floats):
+  // at the end of a patch the buffer of the chunk just consumed is free (the other one already holds the next patch's first
+  // chunk) and is the first of the four exchange regions; three more follow the raw buffers (epilogue comment).  One workgroup
+  // per CU either way: the 128 / 64 accumulators plus operands of eight waves fill the register file.
+  constexpr int RAWF = WINO_CP_RAWF;
+  static_assert(RAWF >= HR * HSTRIDE / RW * 34 * PLD + 34 * PLD && RAWF >= 4 * 64 * ZP, "raw buffer too small");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Zx = smem + 2 * RAWF;      // [4 rows i][64 tiles][ZP]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -734,40 +747,50 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
     }
     hmask_next = mk;
   };
-  f32x4 hreg[HR];
-  auto load_halo = [&](int c) {
-    hmask = hmask_next;
+  constexpr int NSET = DEEP ? 2 : 1;   // register sets of halo / weight pieces in flight (set of chunk g = g & 1 when DEEP)
+  f32x4 hreg[NSET][HR];
+  unsigned hmask_set[NSET];
+  (void)hmask;
+  auto load_halo = [&](int c, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    hmask_set[set] = hmask_next;
 #pragma unroll
     for (int i = 0; i < HR; ++i)
-      hreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, hoff[i], c * 64, 0));
+#if defined(MGU_DIAG) && MGU_DIAG == 3   // diagnostic build: no halo loads
+      hreg[set][i] = f32x4{1.f, 1.f, 1.f, 1.f};
+#else
+      hreg[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, hoff[i], c * 64, 0));
+#endif
   };
-  auto store_halo = [&](float* Hs) {
+  auto store_halo = [&](float* Hs, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
       const int hp = hp0 + HSTRIDE * i;
       const int r = hp / RW, cc = hp - r * RW;
       *reinterpret_cast<f32x4*>(Hs + ((r * 2 + (cc & 1)) * 17 + (cc >> 1)) * PLD + kq * 4) =
-          ((hmask >> i) & 1u) ? hreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+          ((hmask_set[set] >> i) & 1u) ? hreg[set][i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   int lp = 0, lc = 0;
   auto prep_next = [&]() {
     if (lc == 0 && lp < npatch) setup_load(p_begin + lp);
   };
-  auto load_next = [&]() {
-    load_halo(lc);
+  auto load_next = [&](auto set_c) {
+    load_halo(lc, set_c);
     lc = lc + 1 == nC ? 0 : lc + 1;
     lp += lc == 0 ? 1 : 0;
   };
 
   const bool fast_n = (d.N % NC == 0) && (d.ldout % 4 == 0) && (d.coff % 4 == 0) && (!d.pool || d.ldpool % 4 == 0);   // uniform
-  u32x4 bx[2][NTB][3];   // the three pieces of this wave's two components, every n tile, one 16-channel chunk
-  auto load_bx = [&](int jj, int chunk) {
+  u32x4 bx[NSET][2][NTB][3];   // the three pieces of this wave's two components, every n tile, one 16-channel chunk (per set)
+  auto load_bx = [&](int jj, int chunk, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
 #pragma unroll
     for (int nt = 0; nt < NTB; ++nt)
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc)
-        bx[jj][nt][pc] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+        bx[set][jj][nt][pc] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
             u_rsrc, lane16, (unsigned)(nt * nt_stride + ((unsigned)chunk * (16 * 192) + jj * 192 + pc * 64) * 16u), 0));
   };
 
@@ -808,19 +831,32 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
 
   // Issue order = the steady state's (vmcnt retires in order and hipcc merges the pending-load state of the loop's two
   // predecessors): the oldest pending loads at the top of a chunk are the halo of the next chunk, then the weight pieces.
+  using S0 = std::integral_constant<int, 0>;
+  using S1c = std::integral_constant<int, DEEP ? 1 : 0>;
   prep_next();
-  load_next();
-  store_halo(smem);
+  load_next(S0{});
+  store_halo(smem, S0{});
   prep_next();
-  load_next();
-  load_bx(0, 0);
-  load_bx(1, 0);
+  load_next(S1c{});
+  load_bx(0, 0, S0{});
+  load_bx(1, 0, S0{});
+  if constexpr (DEEP) {   // chunk 2 -> halo set 0, chunk 1 -> weight set 1 (nC is even, >= 2)
+    prep_next();
+    load_next(S0{});
+    load_bx(0, 1, S1c{});
+    load_bx(1, 1, S1c{});
+  }
   lds_barrier();
   form(smem, 0, 0, 0);      // step 0 of the first chunk
-  f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 st1[NTB], st2[NTB];   // (STATS) per-thread sums of its channel quad of every n tile
+#pragma unroll
+  for (int nt = 0; nt < NTB; ++nt) st1[nt] = f32x4{0.f, 0.f, 0.f, 0.f}, st2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   int buf = 0;
   for (int pi = 0; pi < npatch; ++pi) {
-    for (int c = 0; c < nC; ++c) {
+    auto chunk_body = [&](const int c, auto par_c) {
+      constexpr int P = decltype(par_c)::value;                  // DEEP: parity of the chunk = its register set
+      using SetNext = std::integral_constant<int, DEEP ? (P ^ 1) : 0>;   // set holding chunk c + 1 (stored now, then refilled)
+      using SetCur = std::integral_constant<int, DEEP ? P : 0>;          // weight pieces of this chunk
       // Software pipeline WITHOUT a lead-in or a tail: the MFMAs of every step run beside the LDS reads, transform and
       // three-way split of the NEXT step -- and the last step's partner is step 0 of the next chunk, whose raw data (parked
       // in the other buffer at the top of this chunk) become visible at the mid-chunk barrier B1.  So a wave's VALU work
@@ -832,9 +868,9 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
       lds_barrier();                                     // B0
       const float* Hs = smem + buf * RAWF;               // chunk c
       const float* Hn = smem + (buf ^ 1) * RAWF;         // chunk c + 1 (or the next patch's first)
-      store_halo(smem + (buf ^ 1) * RAWF);
-      load_next();
-      const int cn = c + 1 == nC ? 0 : c + 1;
+      store_halo(smem + (buf ^ 1) * RAWF, SetNext{});
+      load_next(SetNext{});                              // DEEP: chunk c + 3 (else c + 2)
+      const int cn = DEEP ? (c + 2 >= nC ? c + 2 - nC : c + 2) : (c + 1 == nC ? 0 : c + 1);   // chunk whose weight pieces are requested
       static_for<0, 4>([&](auto st_c) {
         constexpr int st = decltype(st_c)::value;
         constexpr int jj = st >> 1, mi = st & 1, slot = st & 1;
@@ -842,17 +878,17 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
 #pragma unroll
         for (int nt = 0; nt < NTB; ++nt) {
           f32x16 t = acc[jj][nt][mi];
-          t = mfma_bf16(pc[slot][2], bx[jj][nt][0], t);
-          t = mfma_bf16(pc[slot][0], bx[jj][nt][2], t);
-          t = mfma_bf16(pc[slot][1], bx[jj][nt][1], t);
-          t = mfma_bf16(pc[slot][1], bx[jj][nt][0], t);
-          t = mfma_bf16(pc[slot][0], bx[jj][nt][1], t);
-          t = mfma_bf16(pc[slot][0], bx[jj][nt][0], t);
+          t = mfma_bf16(pc[slot][2], bx[SetCur::value][jj][nt][0], t);
+          t = mfma_bf16(pc[slot][0], bx[SetCur::value][jj][nt][2], t);
+          t = mfma_bf16(pc[slot][1], bx[SetCur::value][jj][nt][1], t);
+          t = mfma_bf16(pc[slot][1], bx[SetCur::value][jj][nt][0], t);
+          t = mfma_bf16(pc[slot][0], bx[SetCur::value][jj][nt][1], t);
+          t = mfma_bf16(pc[slot][0], bx[SetCur::value][jj][nt][0], t);
           acc[jj][nt][mi] = t;
         }
         if constexpr (st < 3) form(Hs, (st + 1) >> 1, (st + 1) & 1, slot ^ 1);
         else form(Hn, 0, 0, slot ^ 1);
-        if constexpr (mi == 1) load_bx(jj, cn);   // this component's pieces of the next chunk (or the next patch's first)
+        if constexpr (mi == 1) load_bx(jj, cn, SetCur{});   // this component's pieces of the next chunk using this set
         constexpr int NM = 6 * NTB;                               // MFMAs of the step
         constexpr int per = (72 + NM - 1) / NM;                   // transform (24) + split (44) + addresses of the next step
 #pragma unroll
@@ -865,6 +901,14 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
         __builtin_amdgcn_sched_barrier(0);
       });
       buf ^= 1;
+    };
+    if constexpr (DEEP) {
+      for (int c = 0; c < nC; c += 2) {
+        chunk_body(c, std::integral_constant<int, 0>{});
+        chunk_body(c + 1, std::integral_constant<int, 1>{});
+      }
+    } else {
+      for (int c = 0; c < nC; ++c) chunk_body(c, std::integral_constant<int, 0>{});
     }
     // ---- inverse transform + epilogue of patch pi ----
     int img, y0, x0;
@@ -874,127 +918,140 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
     const bool interior = (y0 + 8 <= d.H) && (x0 + 32 <= d.W) && fast_n;
     float* pool_out = nullptr;
     if (d.pool) pool_out = d.pool + (size_t)img * (d.H >> 1) * (d.W >> 1) * d.ldpool;
-    f32x4 pmax[UPT];
-    // exchange-buffer slot of this lane's accumulator register 0; register r of (m tile mi, n tile nt) sits a COMPILE-TIME
-    // constant away.  The asm makes the base opaque per patch: otherwise hipcc hoists all 64 addresses out of the patch loop
-    // (they are loop invariant), keeps them live across the main loop at the 256-register limit and spills every one of
-    // them -- each reload then waited vmcnt(0) in the middle of the epilogue (2.2x on the whole kernel)
     // Everything per-lane the epilogue needs is re-derived here from an OPAQUE copy of the thread id, so that none of it is
-    // live across the main loop.
+    // live across the main loop (hipcc otherwise hoists the loop-invariant exchange-buffer addresses out of the patch loop,
+    // keeps them live through the main loop at the register limit and spills them: each reload then waited vmcnt(0) in the
+    // middle of the epilogue, 2.2x on the whole kernel).
     int et = threadIdx.x;
     asm volatile("" : "+v"(et));
-    const int cq = et % QPT;
-    const int n0 = nblock * NC + cq * 4;
+    const int cq = et & 7, T = et >> 3;              // finishing unit of this thread: (tile, channel quad of the pass's n tile)
     int zb = (wi * 64 + 4 * ((et >> 5) & 1)) * ZP + (et & 31);
     asm volatile("" : "+v"(zb));
-    // per-channel scale / shift of this thread's channel quad: (re)loaded per patch from L1/L2 rather than held in eight
-    // registers through the main loop (the loop runs at the 256-register limit)
-    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    lds_barrier();   // every wave has finished reading the consumed raw buffer, which is exchange region 0 from here on
+    // Exchange regions Z[q][jp] ([4 rows i][64 tiles][32 channels] each): the column part of Z[i][q] = sum_j M[i][j] A[j][q]
+    // (A^T = [1 1 1 0; 0 1 -1 -1]) is split over the two component-pair waves of a row,
+    //   jp = 0 (M0, M1): q = 0: M0 + M1, q = 1: M1;      jp = 1 (M2, M3): q = 0: M2, q = 1: -M2 - M3,
+    // and every wave writes its two shares to regions of its OWN; the finishing pass adds the two shares while it reads.  (An
+    // earlier version had the jp = 1 waves read-add-write the jp = 0 waves' region: a serialised LDS round trip per group of
+    // four slots with half the waves idle, and three barriers per (q, n tile) pass -- a quarter of the whole kernel's time.)
+    // Region (0, 0) is the raw buffer just consumed (smem + buf * RAWF holds the next patch's first chunk), the others follow
+    // the raw buffers: 64 KB + 96 KB = the CU's 160 KB.
+    float* const zreg0 = smem + (buf ^ 1) * RAWF;
+    float* const zext = smem + 2 * RAWF;
+    auto zregion = [&](const int q, const int j) { return (q | j) == 0 ? zreg0 : zext + (2 * q + j - 1) * RAWF; };
+#if defined(MGU_DIAG) && MGU_DIAG == 2   // diagnostic build: no inverse transform / epilogue at all
+    {
+      float sacc = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (n0 + e < d.N) {
-        if (d.scale) sc4[e] = d.scale[n0 + e];
-        if (d.shift) sh4[e] = d.shift[n0 + e];
-      }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      // column part, this wave's share of Z[i][q] = sum_j M[i][j] A[j][q]  (A^T = [1 1 1 0; 0 1 -1 -1]):
-      //   jp = 0 (M0, M1): q = 0: M0 + M1, q = 1: M1;      jp = 1 (M2, M3): q = 0: M2, q = 1: -M2 - M3
-      if (jp == 0) {
-#pragma unroll
-        for (int nt = 0; nt < NTB; ++nt)
-#pragma unroll
-          for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float z = q == 0 ? acc[0][nt][mi][r] + acc[1][nt][mi][r] : acc[1][nt][mi][r];
-              Zx[zb + (mi * 32 + (r & 3) + 8 * (r >> 2)) * ZP + nt * 32] = z;
-            }
-      }
-      lds_barrier();
-      if (jp == 1) {
-        // read-add-write in groups of four slots (this lane is the only one adding to a slot; ds_add_f32 was measured 2x slower
-        // on the WHOLE kernel: LDS float atomics serialise).  The fence keeps hipcc from batching all 64 reads, which needs 64
-        // more registers than the epilogue has (accumulators and the next patch's weight pieces are live).
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
         for (int nt = 0; nt < NTB; ++nt)
 #pragma unroll
           for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-              float old[4];
+            for (int r = 0; r < 16; ++r) sacc += acc[jj][nt][mi][r];
+      if (sacc == 123.456f) img_out[et] = sacc;
+    }
+#else
+    // Per-channel scale / shift ride on the WRITER side: the epilogue is linear up to the ReLU, so a wave scales its shares by
+    // the channel of its lane (one register per n tile) and the (row 1, jp 0) wave -- Z1 enters both output rows with + -- adds
+    // the shift; the finishing pass then needs no per-channel data at all.  Loaded per patch (not held through the main loop),
+    // unconditionally (clamped index) and BEFORE the first output store of the patch: the wait for a load is a wait for every
+    // older memory operation of the wave (vmcnt retires in order), so a load -- or a scratch reload of one -- behind the
+    // previous pass's stores waits for their HBM round trip (measured: the whole gain of the barrier-light exchange).
+    float scw[NTB], shw[NTB];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) old[e] = Zx[zb + (mi * 32 + e + 8 * rg) * ZP + nt * 32];
+    for (int nt = 0; nt < NTB; ++nt) {
+      const int n = min(nblock * NC + nt * 32 + (et & 31), d.N - 1);
+      scw[nt] = d.scale ? d.scale[n] : 1.f;
+      shw[nt] = (d.shift && wi == 1 && jp == 0) ? d.shift[n] : 0.f;
+    }
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int r = rg * 4 + e;
-                const float z = q == 0 ? acc[0][nt][mi][r] : -acc[0][nt][mi][r] - acc[1][nt][mi][r];
-                Zx[zb + (mi * 32 + e + 8 * rg) * ZP + nt * 32] = old[e] + z;
-              }
-              __builtin_amdgcn_sched_barrier(0);
-            }
+    for (int nt = 0; nt < NTB; ++nt) {
+      const int n0 = nblock * NC + nt * 32 + cq * 4;
+      {
+        float* const z0p = zregion(0, jp) + zb;
+        float* const z1p = zregion(1, jp) + zb;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float m0 = acc[0][nt][mi][r], m1 = acc[1][nt][mi][r];
+            const int o = (mi * 32 + (r & 3) + 8 * (r >> 2)) * ZP;
+            z0p[o] = (jp == 0 ? m0 + m1 : m0) * scw[nt] + shw[nt];
+            z1p[o] = (jp == 0 ? m1 : -m0 - m1) * scw[nt] + shw[nt];
+          }
       }
       lds_barrier();
-      // row part + epilogue: unit u = (tile, channel quad); y(2tr, .) = Z0 + Z1 + Z2, y(2tr+1, .) = Z1 - Z2 - Z3
+      // row part + epilogue of unit (T, cq): y(2tr, .) = Z0 + Z1 + Z2, y(2tr+1, .) = Z1 - Z2 - Z3, both output columns q
+      f32x4 ya[2], yb[2];
 #pragma unroll
-      for (int k = 0; k < UPT; ++k) {
-        const int u = et + k * 512;
-        const int T = u / QPT;
-        const float* zp = Zx + T * ZP + cq * 4;
-        const f32x4 z0 = *reinterpret_cast<const f32x4*>(zp);
-        const f32x4 z1 = *reinterpret_cast<const f32x4*>(zp + 64 * ZP);
-        const f32x4 z2 = *reinterpret_cast<const f32x4*>(zp + 128 * ZP);
-        const f32x4 z3 = *reinterpret_cast<const f32x4*>(zp + 192 * ZP);
-        f32x4 ya = (z0 + z1 + z2) * sc4 + sh4;
-        f32x4 yb = (z1 - z2 - z3) * sc4 + sh4;
+      for (int q = 0; q < 2; ++q) {
+        const float* za = zregion(q, 0) + T * ZP + cq * 4;
+        const float* zc = zregion(q, 1) + T * ZP + cq * 4;
+        const f32x4 z0 = *reinterpret_cast<const f32x4*>(za) + *reinterpret_cast<const f32x4*>(zc);
+        const f32x4 z1 = *reinterpret_cast<const f32x4*>(za + 64 * ZP) + *reinterpret_cast<const f32x4*>(zc + 64 * ZP);
+        const f32x4 z2 = *reinterpret_cast<const f32x4*>(za + 128 * ZP) + *reinterpret_cast<const f32x4*>(zc + 128 * ZP);
+        const f32x4 z3 = *reinterpret_cast<const f32x4*>(za + 192 * ZP) + *reinterpret_cast<const f32x4*>(zc + 192 * ZP);
+        ya[q] = z0 + z1 + z2;
+        yb[q] = z1 - z2 - z3;
         if (d.relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) ya[e] = fmaxf(ya[e], 0.f), yb[e] = fmaxf(yb[e], 0.f);
+          for (int e = 0; e < 4; ++e) ya[q][e] = fmaxf(ya[q][e], 0.f), yb[q][e] = fmaxf(yb[q][e], 0.f);
         }
-        const int oy = y0 + 2 * (T >> 4), ox = x0 + 2 * (T & 15) + q;
-        if (STATS) {
-          const float ma = (interior || (ox < d.W && oy < d.H)) ? 1.f : 0.f;
-          const float mb = (interior || (ox < d.W && oy + 1 < d.H)) ? 1.f : 0.f;
-          st1 += ma * ya + mb * yb;
-          st2 += ma * ya * ya + mb * yb * yb;
-        }
-        const unsigned idx = (unsigned)((oy * d.W + ox) * d.ldout + n0);
-        if (interior) {
-          *reinterpret_cast<f32x4*>(img_out + idx) = ya;
-          *reinterpret_cast<f32x4*>(img_out + idx + sW) = yb;
-        } else if (ox < d.W) {
+      }
+      const int oy = y0 + 2 * (T >> 4), ox = x0 + 2 * (T & 15);
+      if (STATS) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n0 + e < d.N) {
-              if (oy < d.H) img_out[idx + e] = ya[e];
-              if (oy + 1 < d.H) img_out[idx + sW + e] = yb[e];
-            }
+        for (int q = 0; q < 2; ++q) {
+          const float ma = (interior || (ox + q < d.W && oy < d.H)) ? 1.f : 0.f;
+          const float mb = (interior || (ox + q < d.W && oy + 1 < d.H)) ? 1.f : 0.f;
+          st1[nt] += ma * ya[q] + mb * yb[q];
+          st2[nt] += ma * ya[q] * ya[q] + mb * yb[q] * yb[q];
         }
-        if (d.pool) {
-          f32x4 m;
+      }
+      const unsigned idx = (unsigned)((oy * d.W + ox) * d.ldout + n0);
+#if defined(MGU_DIAG) && MGU_DIAG == 1   // diagnostic build: the output stores only if a value is a magic number
+      if (ya[0][0] == 123.456f) {
+#else
+      if (interior) {
+#endif
+        *reinterpret_cast<f32x4*>(img_out + idx) = ya[0];
+        *reinterpret_cast<f32x4*>(img_out + idx + d.ldout) = ya[1];
+        *reinterpret_cast<f32x4*>(img_out + idx + sW) = yb[0];
+        *reinterpret_cast<f32x4*>(img_out + idx + sW + d.ldout) = yb[1];
+      } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) m[e] = fmaxf(ya[e], yb[e]);
-          if (q == 0) {
-            pmax[k] = m;
+        for (int q = 0; q < 2; ++q)
+          if (ox + q < d.W) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n0 + e < d.N) {
+                if (oy < d.H) img_out[idx + q * d.ldout + e] = ya[q][e];
+                if (oy + 1 < d.H) img_out[idx + q * d.ldout + sW + e] = yb[q][e];
+              }
+          }
+      }
+      if (d.pool) {
+        // the 2x2 output tile IS a pooling window (floor semantics: only complete windows)
+        f32x4 m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(ya[0][e], yb[0][e]), fmaxf(ya[1][e], yb[1][e]));
+        const int py = oy >> 1, px = ox >> 1;
+        if (oy + 1 < d.H && ox + 1 < d.W) {
+          float* pp = pool_out + (size_t)(py * (d.W >> 1) + px) * d.ldpool + n0;
+          if (fast_n) {
+            *reinterpret_cast<f32x4*>(pp) = m;
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], pmax[k][e]);
-            const int py = oy >> 1, px = ox >> 1;
-            if (oy + 1 < d.H && ox < d.W) {
-              float* pp = pool_out + (size_t)(py * (d.W >> 1) + px) * d.ldpool + n0;
-              if (fast_n) {
-                *reinterpret_cast<f32x4*>(pp) = m;
-              } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  if (n0 + e < d.N) pp[e] = m[e];
-              }
-            }
+            for (int e = 0; e < 4; ++e)
+              if (n0 + e < d.N) pp[e] = m[e];
           }
         }
       }
-      lds_barrier();   // Zx is rewritten by the next pass / patch
+      lds_barrier();   // the regions are rewritten by the next pass / region 0 receives the next raw chunk
     }
+#endif
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -1005,29 +1062,33 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
           for (int r = 0; r < 16; ++r) acc[jj][nt][mi][r] = 0.f;
   }
   if (STATS) {
-    float* red = smem;   // [512][8]
-    const int cq = tid % QPT;
-    (void)cq;
+    // fold the per-thread sums of a channel quad (64 threads each) through LDS, then one double atomic per channel and sum into
+    // slot (workgroup % 64) of the slotted accumulator [64][2 * N] that bn_finalize_slots_kernel folds
+    float* red = smem;   // [NTB][512][8]
     lds_barrier();
-    *reinterpret_cast<f32x4*>(red + tid * 8) = st1;
-    *reinterpret_cast<f32x4*>(red + tid * 8 + 4) = st2;
+#pragma unroll
+    for (int nt = 0; nt < NTB; ++nt) {
+      *reinterpret_cast<f32x4*>(red + (nt * 512 + tid) * 8) = st1[nt];
+      *reinterpret_cast<f32x4*>(red + (nt * 512 + tid) * 8 + 4) = st2[nt];
+    }
     lds_barrier();
-    if (tid < 8 * QPT) {
-      const int which = tid / (4 * QPT), rem = tid - which * 4 * QPT, qd = rem >> 2, e = rem & 3;
+    if (tid < 64 * NTB) {   // thread -> (n tile, which sum, channel quad, element)
+      const int nt = tid >> 6, rem = tid & 63, which = rem >> 5, qd = (rem >> 2) & 7, e = rem & 3;
       double sum = 0.0;
-      for (int k = qd; k < 512; k += QPT) sum += (double)red[k * 8 + which * 4 + e];
-      const int n = nblock * NC + qd * 4 + e;
+      for (int k = qd; k < 512; k += 8) sum += (double)red[(nt * 512 + k) * 8 + which * 4 + e];
+      const int n = nblock * NC + nt * 32 + qd * 4 + e;
       if (n < d.N) atomicAdd(d.stat_slots + (size_t)(blockIdx.x & 63) * 2 * d.N + which * d.N + n, sum);
     }
   }
 }
 
-template <int NTB, bool STATS>
+template <int NTB, bool STATS, bool DEEP = false>
 static hipError_t launch_wino_cp(const IgemmDesc& d, hipStream_t s) {
   constexpr int NWAVES = 8;
   const int tiles_x = (d.W + 31) / 32, tiles_y = (d.H + 7) / 8;
   const int B = d.M / (d.H * d.W);
   const int total = tiles_x * tiles_y * B, nblk = (d.N + 32 * NTB - 1) / (32 * NTB);
+  // one workgroup per CU is resident (registers: 8 waves x ~200-256): ONE round of 256, each walking its share of the patches
   const int rounds = std::max(1, tun(d).wino_rounds), cap = std::max(1, tun(d).wino_ppb_cap);
   int ppb = (int)(((long)total * nblk) / (256 * rounds));
   if (ppb < 1) ppb = 1;
@@ -1035,13 +1096,11 @@ static hipError_t launch_wino_cp(const IgemmDesc& d, hipStream_t s) {
   const int ngroups = (total + ppb - 1) / ppb;
   const int per_xcd = (ngroups * nblk + 7) / 8;
   dim3 grid(8 * per_xcd, 1);
-  constexpr int HSTRIDE = NWAVES * 16, HR = (340 + HSTRIDE - 1) / HSTRIDE;
-  constexpr int RAWF = HR * HSTRIDE / 34 * 34 * 20 + 34 * 20;   // must match the kernel
-  const size_t lds = (size_t)(2 * RAWF + 4 * 64 * (32 * NTB + 8)) * sizeof(float);
+  const size_t lds = (size_t)(5 * WINO_CP_RAWF) * sizeof(float);   // two raw buffers + three exchange regions = the CU's 160 KB
   static bool attr_done[64] = {};
-  hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&wino3x3_cp_kernel<NTB, STATS>), lds, attr_done);
+  hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&wino3x3_cp_kernel<NTB, STATS, DEEP>), lds, attr_done);
   if (ae != hipSuccess) return ae;
-  hipLaunchKernelGGL((wino3x3_cp_kernel<NTB, STATS>), grid, dim3(64 * NWAVES), lds, s, d, tiles_x, tiles_y, total, ppb, ngroups, ngroups * nblk,
+  hipLaunchKernelGGL((wino3x3_cp_kernel<NTB, STATS, DEEP>), grid, dim3(64 * NWAVES), lds, s, d, tiles_x, tiles_y, total, ppb, ngroups, ngroups * nblk,
                      per_xcd);
   return hipGetLastError();
 }
@@ -1081,8 +1140,9 @@ hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
   const bool wide = d.N > 32 && tun(d).wino_mode != 1;
   if (tun(d).wino_prec && tun(d).wino_cp && (wide || tun(d).wino_cp_narrow) &&
       (long)d.H * d.W * d.ldin * 4 < (1l << 31)) {   // image bytes fit a buffer descriptor
-    if (d.stat_slots) return wide ? launch_wino_cp<2, true>(d, s) : launch_wino_cp<1, true>(d, s);
-    return wide ? launch_wino_cp<2, false>(d, s) : launch_wino_cp<1, false>(d, s);
+    const bool deep = !wide && ((d.Cp >> 4) & 1) == 0 && tun(d).wino_deep;   // two chunks of load lead (see the kernel's DEEP note)
+    if (d.stat_slots) return wide ? launch_wino_cp<2, true>(d, s) : deep ? launch_wino_cp<1, true, true>(d, s) : launch_wino_cp<1, true>(d, s);
+    return wide ? launch_wino_cp<2, false>(d, s) : deep ? launch_wino_cp<1, false, true>(d, s) : launch_wino_cp<1, false>(d, s);
   }
   if (tun(d).wino_prec) return wide ? launch_wino_mode<0, 1>(d, s) : launch_wino_mode<1, 1>(d, s);
   return wide ? launch_wino_mode<0, 0>(d, s) : launch_wino_mode<1, 0>(d, s);

@@ -104,7 +104,9 @@ class MinCutRefinement(nn.Module):
         N, D = f.shape
         E = ei.shape[1]
         if E:
-            lo, hi = int(ei.min()), int(ei.max())
+            # the reference raises on an out-of-range index, so this check has to complete before the call returns:
+            # ONE reduction and ONE host read (the kernel itself never reads out of range: it trusts this check)
+            lo, hi = torch.stack(torch.aminmax(ei)).tolist()
             if lo < 0 or hi >= N:
                 raise IndexError(f"edge_index values must be in [0, {N}); got [{lo}, {hi}]")
         w = torch.empty(E, device=dev, dtype=torch.float32)

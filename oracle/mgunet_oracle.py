@@ -195,6 +195,60 @@ def unet_forward(p, x, depth=4, training=False, momentum=0.1, eps=1e-5, new_stat
     return logits, skips, feats[::-1]  # :149
 
 
+def _bf16(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+def conv_block_bf16_storage(p, prefix, cur, fp32_first_weights=False, eps=1e-5):
+    """ConvBlock (model/unet/unet_encoder.py:15-25, eval) with the storage roundings of the HIP bf16 mode: bf16 weights
+    (fp32 for the first convolution when it runs on the VALU kernel), >= fp32 accumulation, BatchNorm as the folded fp32
+    scale / shift of the epilogue, each of the two outputs rounded to bf16.  `cur` holds bf16-representable values."""
+    for ci, (c, bn) in enumerate((("conv1", "bn1"), ("conv2", "bn2"))):
+        w = p[prefix + c + ".weight"]
+        if not (fp32_first_weights and ci == 0):
+            w = _bf16(w)
+        z = F.conv2d(cur, w, None, padding=1)
+        scale = p[prefix + bn + ".weight"] / torch.sqrt(p[prefix + bn + ".running_var"] + eps)
+        shift = p[prefix + bn + ".bias"] + (p[prefix + c + ".bias"] - p[prefix + bn + ".running_mean"]) * scale
+        cur = _bf16(F.relu(z * scale[None, :, None, None] + shift[None, :, None, None]))
+    return cur
+
+
+def decoder_block_bf16_storage(p, bi, cur, skip):
+    """DecoderBlock (model/unet/unet_decoder.py:30-56) with the same storage roundings: bf16 transposed-conv weights, its
+    output rounded to bf16, skip first in the concat, then the ConvBlock."""
+    pre = f"decoder.decoder_blocks.{bi}."
+    up = _bf16(F.conv_transpose2d(cur, _bf16(p[pre + "upsample.weight"]), p[pre + "upsample.bias"], stride=2))
+    dy, dx = skip.shape[2] - up.shape[2], skip.shape[3] - up.shape[3]
+    up = F.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+    return conv_block_bf16_storage(p, pre + "conv_block.", torch.cat([skip, up], dim=1))
+
+
+def unet_forward_bf16_storage(p, x, depth=4, first_fp32=True):
+    """UNet.forward (model/unet/unet_model.py:34-36, eval) with the STORAGE roundings of the HIP bf16 mode written out:
+    the input and every stored activation are rounded to bf16, the 3x3 / transposed convolution weights are rounded to
+    bf16, products accumulate in (at least) fp32, the first convolution (when it runs on the VALU kernel, `first_fp32`)
+    and the 1x1 head keep fp32 weights and the logits stay fp32.  This is not the reference's arithmetic (the reference
+    has no bf16 path of its own for this comparison); it is the yardstick that separates "bf16 storage costs this much"
+    from "the HIP bf16 kernels compute something else".  Note that two correct implementations of THIS arithmetic still
+    drift apart over 23 layers: a different fp32 summation order flips about 1 % of a layer's bf16 roundings, and every
+    flipped input perturbs all the outputs it feeds, so only short segments (one or two layers from a common input) can
+    be held to the one-ulp level -- tests/test_gpu_bf16.py does exactly that."""
+    skips = []
+    cur = _bf16(x)
+    for i in range(depth):
+        cur = conv_block_bf16_storage(p, f"encoder.encoder_blocks.{i}.", cur, first_fp32 and i == 0)
+        skips.append(cur)
+        cur = F.max_pool2d(cur, kernel_size=2, stride=2)
+    cur = conv_block_bf16_storage(p, "encoder.bottleneck.", cur)
+    feats = []
+    for bi in range(depth):
+        cur = decoder_block_bf16_storage(p, bi, cur, skips[depth - 1 - bi])
+        feats.append(cur)
+    logits = F.conv2d(cur, p["decoder.final_conv.weight"], p["decoder.final_conv.bias"])
+    return logits, skips, feats[::-1]
+
+
 def unet_flops(in_channels, num_classes, init_features, depth, H, W) -> float:
     """2*MAC count of the convolutions only, per image."""
     fl, cin, f, h, w = 0.0, in_channels, init_features, H, W

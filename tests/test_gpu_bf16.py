@@ -1,8 +1,20 @@
 """BASELINE configs[2] precision mode: bf16 storage + fp32 accumulate (inference).  The reference has no
 bf16 path of its own for this comparison (its GAT is fp32-only), so the yardstick is the fp32
 golden data with a bf16 tolerance: SURVEY 8d reports that the reference's OWN bf16 CPU run deviates 1.4 % of
-max|logit| from its fp32 run with 99.57 % argmax agreement.  Stated tolerance here: max-abs <= 3 % of max|logit|,
-mean-abs <= 0.5 % of max|logit|, argmax agreement >= 99 %."""
+max|logit| from its fp32 run with 99.57 % argmax agreement.
+
+Two yardsticks, two tolerances:
+  * against the fp32 results (what storing 23 activations per pixel in bf16 costs): every stored activation carries a
+    relative rounding error up to 2^-9 = 0.195 %, the 18 conv layers + 4 transposed convs in series add theirs
+    roughly in quadrature (sqrt(22) * 0.2 % ~ 0.9 % rms of the activation scale at the head), and the maximum over the
+    4.2 M logits of a batch sits 4-5 sigma out.  Measured on MI355X (r02): max-abs 1.86 % of max|logit|, mean-abs
+    0.21 %, 99.9th percentile below 1 %, argmax agreement 99.53 %.  Tolerance: max-abs <= 2.5 %, 99.9th percentile
+    <= 1 %, mean-abs <= 0.3 % of max|logit|, argmax agreement >= 99 %.  A max-abs bound of 1 % is not reachable by ANY
+    bf16-storage implementation of this network (the reference's own bf16 run is at 1.4 %).
+  * against the oracle's bf16-storage restatement, segment by segment from the HIP path's own stored tensors (what the
+    HIP bf16 KERNELS may add on top of the storage format: only the fp32 accumulation order, which now and then flips
+    the bf16 rounding of a stored activation by one ulp): every exposed tensor <= 1 % of its max (the 1e-2 bar),
+    >= 90 % of the values bit-equal, logits == fp32 head of the stored feature to 1e-4."""
 import numpy as np
 import pytest
 import torch
@@ -26,7 +38,11 @@ def check_bf16(lg, ref, tag):
     agree = (lg.argmax(1) == ref.argmax(1)).mean() if ref.ndim == 4 else None
     print(f"[bf16 {tag}] max-abs {d.max():.4f} ({d.max()/scale*100:.2f} % of max|logit| {scale:.2f}), mean-abs {d.mean():.5f}"
           + (f", argmax agreement {agree*100:.2f} %" if agree is not None else ""))
-    assert d.max() <= 3e-2 * scale and d.mean() <= 5e-3 * scale
+    p999 = float(np.quantile(d.reshape(-1)[:: max(1, d.size // 2_000_000)], 0.999))
+    print(f"    99.9th percentile {p999:.4f} ({p999/scale*100:.2f} %)")
+    assert d.max() <= 2.5e-2 * scale and d.mean() <= 3e-3 * scale
+    if d.size >= 100_000:
+        assert p999 <= 1e-2 * scale
     if agree is not None:
         assert agree >= 0.99
 
@@ -47,6 +63,79 @@ def test_bf16_tiny_vs_fp32_golden(cuda, golden, tag, cfg, shape):
         assert float(np.abs(ft[i].float().cpu().numpy() - ref).max()) <= 4e-2 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("tag,cfg,shape,first_fp32", [
+    ("b", (3, 3, 8, 2), (2, 3, 37, 45), False), ("c", (3, 2, 8, 3), (2, 3, 64, 48), False),
+    ("f16", (3, 2, 16, 3), (2, 3, 96, 80), True), ("c2", (3, 2, 32, 4), (2, 3, 512, 512), True)])
+def test_bf16_kernels_vs_storage_emulation(cuda, tag, cfg, shape, first_fp32):
+    """Kernel-level bf16 parity, the <= 1e-2 * max bar: every tensor the bf16 forward exposes (skips, decoder features,
+    logits) is recomputed by the oracle FROM THE HIP PATH'S OWN exposed predecessors with the same storage roundings
+    (oracle.conv_block_bf16_storage / decoder_block_bf16_storage: two to five layers per segment) and must agree to
+    1e-2 of the tensor's max with >= 90 % of the bf16 values bit-equal; the fp32 logits must equal the oracle head on the
+    HIP feature to 1e-4.  (The whole network against the whole emulation is printed and held to the storage budget only:
+    see the note in oracle.unet_forward_bf16_storage.)"""
+    depth = cfg[3]
+    m = build(cfg, 21, cuda, torch.bfloat16)
+    p = O.make_unet_params(*cfg, seed=21)
+    x = torch.from_numpy(O.formula_normal(f"bf16emu/{tag}/x", shape, seed=21))
+    lg, sk, ft = m(x.to(cuda))
+    sk = [t.float().cpu() for t in sk]
+    ft = [t.float().cpu() for t in ft]
+    F = torch.nn.functional
+    worst_all = 0.0
+
+    def seg(name, got, ref):
+        nonlocal worst_all
+        same = float((got == ref).float().mean())
+        worst = float((got - ref).abs().max() / ref.abs().max())
+        worst_all = max(worst_all, worst)
+        print(f"    [{tag}] {name}: bit-equal {same*100:.2f} %, max-abs {worst*100:.3f} % of max")
+        assert same >= 0.90 and worst <= 1e-2, name
+
+    with torch.no_grad():
+        seg("skip0 <- input", sk[0], O.conv_block_bf16_storage(p, "encoder.encoder_blocks.0.", O._bf16(x), first_fp32))
+        for i in range(1, depth):
+            seg(f"skip{i} <- skip{i-1}", sk[i], O.conv_block_bf16_storage(p, f"encoder.encoder_blocks.{i}.", F.max_pool2d(sk[i - 1], 2, 2)))
+        bott = O.conv_block_bf16_storage(p, "encoder.bottleneck.", F.max_pool2d(sk[-1], 2, 2))
+        # the bottleneck is not exposed: the deepest decoder feature is recomputed from the deepest skip (5 layers)
+        seg(f"feat{depth-1} <- skip{depth-1}", ft[depth - 1], O.decoder_block_bf16_storage(p, 0, bott, sk[depth - 1]))
+        for i in range(depth - 2, -1, -1):
+            seg(f"feat{i} <- feat{i+1}, skip{i}", ft[i], O.decoder_block_bf16_storage(p, depth - 1 - i, ft[i + 1], sk[i]))
+        head = F.conv2d(ft[0], p["decoder.final_conv.weight"], p["decoder.final_conv.bias"])
+        d = float((lg.cpu() - head).abs().max())
+        print(f"    [{tag}] logits <- feat0: max-abs {d:.2e} (fp32 head on the bf16 feature)")
+        assert d <= 1e-4 * max(1.0, float(head.abs().max()))
+        elg = O.unet_forward_bf16_storage(p, x, depth=depth, first_fp32=first_fp32)[0]
+    e = (lg.cpu() - elg).abs()
+    print(f"[bf16 {tag}] worst segment {worst_all*100:.3f} % of its max; whole network vs whole emulation: max-abs "
+          f"{float(e.max()/elg.abs().max())*100:.2f} %, mean-abs {float(e.mean()/elg.abs().max())*100:.3f} % of max|logit|")
+    assert float(e.max()) <= 2.5e-2 * float(elg.abs().max())
+
+
+def test_bf16_full_batch64_properties(cuda):
+    """BASELINE configs[2] at its FULL global batch (64 x 3 x 512 x 512) in the bf16 mode it is quoted in, all 64 images
+    on one GPU (no oracle finishes at this size): an image's logits do not depend on its batch neighbours (bit-exact
+    against the 8-image shard and the single image), two runs are bit-identical, outputs are finite, and the batch
+    statistics of the deviation from the fp32 HIP path stay inside the bf16-storage budget above."""
+    cfg = (3, 2, 32, 4)
+    mb = build(cfg, 0, cuda, torch.bfloat16)
+    gen = torch.Generator(device=cuda)
+    gen.manual_seed(11)
+    xb = torch.randn((64, 3, 512, 512), device=cuda, generator=gen)
+    lgb = mb(xb)[0]
+    assert tuple(lgb.shape) == (64, 2, 512, 512) and bool(torch.isfinite(lgb).all())
+    assert torch.equal(mb(xb)[0], lgb)
+    assert torch.equal(mb(xb[40:48])[0], lgb[40:48])
+    assert torch.equal(mb(xb[63:64])[0][0], lgb[63])
+    mf = build(cfg, 0, cuda, torch.float32)
+    lf = mf(xb[40:48])[0]
+    d = (lgb[40:48] - lf).abs()
+    scale = float(lf.abs().max())
+    agree = float((lgb[40:48].argmax(1) == lf.argmax(1)).float().mean())
+    print(f"[bf16 b64] images 40-47 vs fp32 HIP: max-abs {float(d.max())/scale*100:.2f} %, mean-abs {float(d.mean())/scale*100:.3f} % of "
+          f"max|logit| {scale:.2f}, argmax agreement {agree*100:.2f} %")
+    assert float(d.max()) <= 2.5e-2 * scale and float(d.mean()) <= 3e-3 * scale and agree >= 0.99
+
+
 def test_bf16_config3_shard_vs_fp32_path(cuda, golden):
     """8 images of 3x512x512 (one GPU's shard of configs[2]'s batch of 64) in bf16 vs the fp32 golden samples and vs
     the fp32 HIP path (full tensors: argmax agreement), plus the full forward with the fp32 GAT on bf16 features."""
@@ -62,7 +151,7 @@ def test_bf16_config3_shard_vs_fp32_path(cuda, golden):
     for b in range(8):
         got = lb[b].contiguous().reshape(-1)[torch.from_numpy(g[f"idx_{b}"]).to(cuda)].cpu().numpy()
         worst = max(worst, float(np.abs(got - g[f"logits_{b}"]).max()))
-    assert worst <= 3e-2 * 8.0
+    assert worst <= 2.5e-2 * 8.0
     gat = mgunet.GATNetwork(32, 128, 64, 4, 1)
     gat.load_state_dict(O.make_gat_params(32, 128, 64, 4, 1, seed=0))
     model = mgunet.MinGraphUNet(mb, gat.to(cuda).eval(), 16).eval()

@@ -176,7 +176,11 @@ def test_conv2d_scale_shift_relu_and_channel_slice_store(cuda):
     assert torch.all(got[..., :32] == -7.0) and torch.all(got[..., 56:] == -7.0)  # neighbours untouched
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 4, 4, 8, 4), (2, 5, 7, 32, 16), (1, 8, 8, 64, 32), (1, 3, 9, 256, 128)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [
+    (1, 4, 4, 8, 4), (2, 5, 7, 32, 16), (1, 8, 8, 64, 32), (1, 3, 9, 256, 128),
+    # the three-piece bf16-MFMA kernel (convt_x3.hip: Cin % 16 == 0, Cout % 32 == 0): odd K-step count, pixel tiles that cross
+    # image boundaries and end ragged, several n tiles, the deepest decoder shape
+    (2, 16, 24, 48, 64), (3, 11, 13, 128, 96), (2, 32, 32, 512, 256), (1, 128, 128, 64, 32)])
 def test_conv_transpose2x2_vs_torch(cuda, B, H, W, Cin, Cout):
     x = torch.from_numpy(O.formula_normal("kt/x", (B, Cin, H, W), seed=Cin))
     w = torch.from_numpy(O.formula_uniform("kt/w", (Cin, Cout, 2, 2), -0.2, 0.2, seed=Cout))
