@@ -170,7 +170,8 @@ def load_traffic(kernel, dtype):
     exact = bool(args) and all(ch.isdigit() or ch == "," for ch in args)    # literal template arguments: one instantiation
     n = b = 0
     for k, v in t.get("kernels", {}).items():
-        if base in k and (not exact or ("<" + args + ">") in k.replace(" ", "")):
+        kk = k.replace(" ", "")
+        if base in k and (not exact or ("<" + args + ">") in kk or ("<" + args + ",") in kk):   # leading template arguments
             n += v["launches"]
             b += v["launches"] * v["hbm_bytes_per_launch"]
     if not n:

@@ -5,6 +5,8 @@
 // Host orchestration only; kernels live in igemm.hip, wgrad_f32.hip, train_kernels.hip.
 #include <algorithm>
 
+#include <string>
+
 #include "ctx.h"
 #include <cstdlib>
 
@@ -158,8 +160,13 @@ int conv_dgrad(Bwd& w, const Layer& L, const float* dz, float* out, int ldout) {
     const bool wn = wino_applicable(d);
     double mfma = 2.0 * d.M * (double)d.K * d.N;
     if (wn) mfma = 2.0 * L.t_B * ((L.t_H + 1) / 2) * ((L.t_W + 1) / 2) * 16.0 * d.Cp * d.N * (c->tn.wino_prec ? 6.0 : 1.0);
-    ProfScope ps(c, w.s, wn ? (c->tn.wino_prec ? "wino3x3_f32_kernel<*,1> (dgrad)" : "wino3x3_f32_kernel<*,0> (dgrad)") : "igemm/halo (dgrad)", alg,
-                 mfma, wn && c->tn.wino_prec ? 1 : 0);
+    // record under the name of the kernel family the dispatcher will pick (the same one as a forward conv of this shape)
+    const std::string fam = std::string(igemm_kernel_name(d, 0));
+    const char* label = "igemm/halo (dgrad)";
+    if (fam == "wino3x3_cp_kernel<2>") label = "wino3x3_cp_kernel<2> (dgrad)";
+    else if (fam == "wino3x3_cp_kernel<1>") label = "wino3x3_cp_kernel<1> (dgrad)";
+    else if (wn) label = c->tn.wino_prec ? "wino3x3_f32_kernel<*,1> (dgrad)" : "wino3x3_f32_kernel<*,0> (dgrad)";
+    ProfScope ps(c, w.s, label, alg, mfma, wn && c->tn.wino_prec ? 1 : 0);
     HIPCHK(c, launch_igemm_f32(d, w.s));
   }
   return MGU_OK;

@@ -60,13 +60,25 @@ def test_backward_with_bucketed_exchange_equals_backward(cuda):
     plain, rccl = make_trainer(cuda, None), make_trainer(cuda, "rccl")
     assert rccl._rccl and not plain._rccl
     for step in range(3):
+        # Both trainers start every step from the SAME state.  Left to themselves two trainers -- with or without the exchange --
+        # do not stay within rounding distance: the small layers' weight gradients are summed with float atomics (1e-8 run-to-run
+        # noise), and once the weights differ in the last bit a MaxPool window or ReLU threshold that is a near-tie resolves the
+        # other way, which moves a whole gradient element (observed on this very input: 4.8e-5 at the second step, 7.8e-4 at the
+        # third, in whichever trainer the coin fell for, a plain one as often as the exchanging one).  That sensitivity belongs
+        # to the network, not to the exchange, so it is kept out of this comparison.
+        rccl.flat.copy_(plain.flat)
+        rccl.exp_avg.copy_(plain.exp_avg)
+        rccl.exp_avg_sq.copy_(plain.exp_avg_sq)
+        rccl.step_count = plain.step_count
+        rccl.model.mark_parameters_changed()
         l0 = plain.train_step(x, y)
         l1 = rccl.train_step(x, y)                         # backward + overlapped buckets + Adam behind the join
         torch.cuda.synchronize()
-        # mean over one rank = identity; the two trainers differ only by the float-atomic summation order of the small layers'
-        # weight-gradient tiles (run-to-run noise of ~1e-7 relative, also between two plain trainers)
+        # mean over one rank = identity: same loss, same gradient (up to the atomics' summation order), same updated parameters
         assert abs(float(l0) - float(l1)) <= 1e-6 * abs(float(l0))
         gmax = float(plain.grad.abs().max())
-        assert float((plain.grad - rccl.grad).abs().max()) <= 2e-5 * gmax * (step + 1)
+        d_rccl = float((plain.grad - rccl.grad).abs().max())
+        print(f"[rccl step {step}] max|grad diff| plain vs rccl {d_rccl:.3e}, max|grad| {gmax:.3e}")
+        assert d_rccl <= 2e-6 * gmax
         assert bool(torch.isfinite(rccl.flat).all())
     rccl.check()
