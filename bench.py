@@ -295,13 +295,17 @@ def bench_train(a, world, rank, local_rank, dev, dist):
     tr.check()
     dt = max_over_ranks(dt, dist, dev)
     roof = cpu = None
-    if rank == 0 and not a.no_profile_pass:
+    if not a.no_profile_pass:
+        # the instrumented pass steps on EVERY rank (a train step holds a collective); only rank 0 records
         ctx = model._context(dev)
         L = _lib.lib()
         nprof = min(a.steps, 5)
-        L.mgu_profile_enable(ctx.handle, 1)
+        if rank == 0:
+            L.mgu_profile_enable(ctx.handle, 1)
         for _ in range(nprof):
             tr.train_step(x, y)
+        barrier()
+    if rank == 0 and not a.no_profile_pass:
         stats = merge_stats(_lib.read_kernel_stats(ctx))
         L.mgu_profile_enable(ctx.handle, 0)
         dom = next((k for k in stats if k["pipe"] >= 0 and k["flops_mfma"] > 0), None)
