@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
 // =================================================================================================
 template <typename T, int NP, int TH, int WAVES_M, int WAVES_N, int WMT, int WNT, int TPS>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y,
-                                                           const int total_patches, const int patches_per_block) {
+                                                           const int total_patches, const int patches_per_block, const int yfast) {
   constexpr int VEC = Elem<T>::VEC;      // elements per 16-byte chunk
   constexpr int CK = NP * VEC;           // channels per chunk (NP 16-byte pieces per pixel)
   constexpr int LDS_LD = CK + VEC;       // LDS row pitch in elements
@@ -336,9 +336,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
   int hoff[HR];
   unsigned hmask = 0u, hmask_next = 0u;
   const T* load_base = in_t;
+  // y fastest inside an image: vertically adjacent patches share two halo rows, and walked back to back those rows are still in
+  // the XCD's L2 (as in wino3x3_cp_kernel)
   auto setup_patch = [&](int p, int& img, int& y0, int& x0) {
-    const int tx = p % tiles_x;
-    const int ty = (p / tiles_x) % tiles_y;
+    const int ty = yfast ? p % tiles_y : (p / tiles_x) % tiles_y;
+    const int tx = yfast ? (p / tiles_y) % tiles_x : p % tiles_x;
     img = p / (tiles_x * tiles_y);
     y0 = ty * TH;
     x0 = tx * TW;
@@ -557,7 +559,7 @@ static hipError_t launch_halo(const IgemmDesc& d, hipStream_t s) {
   hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, NP, TH, WAVES_M, WAVES_N, WMT, WNT, TPS>), lds, attr_done);
   if (ae != hipSuccess) return ae;
   hipLaunchKernelGGL((conv3x3_halo_kernel<T, NP, TH, WAVES_M, WAVES_N, WMT, WNT, TPS>), grid, dim3(256), lds, s, d, tiles_x,
-                     tiles_y, total, ppb);
+                     tiles_y, total, ppb, tun(d).wino_yfast ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -611,7 +613,8 @@ const char* igemm_kernel_name(const IgemmDesc& d, int dtype) {
   if (d.out_mode == 1) return convt_x3_applicable(d) ? "convt2x2_x3_kernel" : "igemm_kernel<f32> (ConvTranspose)";
   if (wino_applicable(d)) {
     const bool wide = d.N > 32 && tun(d).wino_mode != 1;
-    if (tun(d).wino_prec && tun(d).wino_cp && (wide || tun(d).wino_cp_narrow) && (long)d.H * d.W * d.ldin * 4 < (1l << 31)) return wide ? "wino3x3_cp_kernel<2>" : "wino3x3_cp_kernel<1>";
+    if (tun(d).wino_prec && tun(d).wino_cp && (wide || tun(d).wino_cp_narrow) && (long)d.H * d.W * d.ldin * 4 < (1l << 31))
+      return wide ? "wino3x3_cp_kernel<2>" : "wino3x3_cp_kernel<1>";
     if (tun(d).wino_prec) return wide ? "wino3x3_f32_kernel<0,1>" : "wino3x3_f32_kernel<1,1>";
     return wide ? "wino3x3_f32_kernel<0,0>" : "wino3x3_f32_kernel<1,0>";
   }

@@ -664,7 +664,7 @@ constexpr int WINO_CP_RAWF = 8192;
 // by two), so no register is ever moved.
 template <int NTB, bool STATS, bool DEEP>
 __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y, const int total_patches,
-                        const int patches_per_block, const int ngroups, const int nitems, const int per_xcd) {
+                        const int patches_per_block, const int ngroups, const int nitems, const int per_xcd, const int yfast) {
   constexpr int NWAVES = 8;
   constexpr int MT = 2;                          // both m tiles of the 8 x 32 pixel patch
   constexpr int NC = 32 * NTB;                   // output channels per workgroup
@@ -722,9 +722,12 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
   unsigned hmask = 0u, hmask_next = 0u;
   auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.in), 0, 0x7ffffff0, 0x00020000);
   const int img_bytes = d.H * d.W * d.ldin * (int)sizeof(float);   // the launcher guarantees H*W*ldin < 2^31 elements ... and bytes fit below
+  // Patch order inside an image: y fastest.  A workgroup walks consecutive patches, and vertically adjacent 8-row patches share
+  // two of their ten halo rows: walked one after the other the shared rows are still in the XCD's L2 (x fastest, the reuse
+  // distance is a whole patch row of every workgroup of the XCD: the halo was fetched from HBM 1.33 x).
   auto setup_patch = [&](int p, int& img, int& y0, int& x0) {
-    const int px = p % tiles_x;
-    const int py = (p / tiles_x) % tiles_y;
+    const int py = yfast ? p % tiles_y : (p / tiles_x) % tiles_y;
+    const int px = yfast ? (p / tiles_y) % tiles_x : p % tiles_x;
     img = p / (tiles_x * tiles_y);
     y0 = py * 8;
     x0 = px * 32;
@@ -1106,7 +1109,7 @@ static hipError_t launch_wino_cp(const IgemmDesc& d, hipStream_t s) {
   hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&wino3x3_cp_kernel<NTB, STATS, DEEP>), lds, attr_done);
   if (ae != hipSuccess) return ae;
   hipLaunchKernelGGL((wino3x3_cp_kernel<NTB, STATS, DEEP>), grid, dim3(64 * NWAVES), lds, s, d, tiles_x, tiles_y, total, ppb, ngroups, ngroups * nblk,
-                     per_xcd);
+                     per_xcd, tun(d).wino_yfast ? 1 : 0);
   return hipGetLastError();
 }
 
