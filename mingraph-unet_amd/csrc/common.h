@@ -26,7 +26,7 @@ struct Tuning {
   int wino_prec = 1;        // MGU_WINO_PREC: 1 = three exact bf16 pieces per fp32 operand on the bf16 MFMA (default),
                             //                0 = fp32 MFMA operands
   bool wino_cp_narrow = true;   // MGU_WINO_CP_NARROW=0: N <= 32 layers stay on wino3x3_f32_kernel<1,1> (A/B)
-  bool wino_yfast = true;   // MGU_WINO_XFAST=1: Winograd workgroups walk their patches x fastest (A/B)
+  bool wino_yfast = false;  // MGU_WINO_YFAST=1: Winograd / halo workgroups walk their patches y fastest inside an image (A/B)
   bool wino_deep = true;    // MGU_NO_WINO_DEEP=1: one chunk of load lead on the narrow Winograd layers too (A/B)
   bool wino_cp = true;      // MGU_NO_WINO_CP=1: the four-components-per-wave kernel instead of the component-pair split (A/B)
   int wino_rounds = 1;      // MGU_WINO_ROUNDS / MGU_WINO_PPB_CAP: persistence of the Winograd workgroups

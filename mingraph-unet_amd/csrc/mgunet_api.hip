@@ -73,7 +73,7 @@ int mgu_create(int device_id, mgu_ctx** out) {
   t.wino_prec = num("MGU_WINO_PREC", t.wino_prec) ? 1 : 0;
   t.wino_cp = !flag("MGU_NO_WINO_CP");
   t.wino_deep = !flag("MGU_NO_WINO_DEEP");
-  t.wino_yfast = !flag("MGU_WINO_XFAST");
+  t.wino_yfast = flag("MGU_WINO_YFAST");
   t.wino_cp_narrow = num("MGU_WINO_CP_NARROW", 1) != 0;
   t.wino_rounds = std::max(1, num("MGU_WINO_ROUNDS", 1));
   t.wino_ppb_cap = std::max(1, num("MGU_WINO_PPB_CAP", 32));

@@ -722,9 +722,9 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
   unsigned hmask = 0u, hmask_next = 0u;
   auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.in), 0, 0x7ffffff0, 0x00020000);
   const int img_bytes = d.H * d.W * d.ldin * (int)sizeof(float);   // the launcher guarantees H*W*ldin < 2^31 elements ... and bytes fit below
-  // Patch order inside an image: y fastest.  A workgroup walks consecutive patches, and vertically adjacent 8-row patches share
-  // two of their ten halo rows: walked one after the other the shared rows are still in the XCD's L2 (x fastest, the reuse
-  // distance is a whole patch row of every workgroup of the XCD: the halo was fetched from HBM 1.33 x).
+  // Patch order inside an image: x fastest by default.  y fastest (MGU_WINO_YFAST=1) lets vertically adjacent patches, which
+  // share two of their ten halo rows, follow each other while those rows are still in the XCD's L2 -- measured with alternating
+  // runs on one box: 1 % SLOWER on the headline step (the HBM read volume is not what bounds these kernels).
   auto setup_patch = [&](int p, int& img, int& y0, int& x0) {
     const int py = yfast ? p % tiles_y : (p / tiles_x) % tiles_y;
     const int px = yfast ? (p / tiles_y) % tiles_x : p % tiles_x;
