@@ -30,3 +30,13 @@ for (name, fl), r in zip(layers, last):
     print(f"{name:9s} {kn:22s} grid={r['Grid_Size_X']:>9s}x{r['Grid_Size_Y']:>4s} {d:8.1f} us {fl/d/1e6:7.1f} TF/s vgpr={r['VGPR_Count']}+{r['Accum_VGPR_Count']} lds={r['LDS_Block_Size']}")
 print("total us", round(tot, 1))
 oth = [r for r in rows if r not in ig]
+
+# idle time between consecutive kernels of the last step (dispatch gaps), including the kernels that are not convolutions
+allk = sorted(rows, key=lambda r: int(r["Start_Timestamp"]))
+i1 = allk.index(last[-1])
+i0 = allk.index(last[0])
+seg = allk[i0:i1 + 1]                  # first conv .. head of the last forward
+gaps = [(int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3 for a, b in zip(seg, seg[1:])]
+span = (int(seg[-1]["End_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e3
+busy = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in seg)
+print(f"step span {span:.1f} us over {len(seg)} kernels: busy {busy:.1f} us, gaps {sum(gaps):.1f} us (mean {sum(gaps)/max(1,len(gaps)):.2f}, max {max(gaps):.1f})")
