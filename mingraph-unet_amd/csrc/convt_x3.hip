@@ -163,15 +163,23 @@ __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __rest
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
+  // two K steps per trip, both unconditional: a conditional half makes hipcc merge the pending-load state of the two paths at
+  // the loop top into s_waitcnt vmcnt(0) -- every step then waited for the NEXT step's loads and the double buffer hid nothing
   load(0, B0{});
-  for (int s = 0; s < ksteps; s += 2) {
-    load(min(s + 1, ksteps - 1), B1{});   // unconditional (the last trip of an odd count re-reads its own step)
+  int s = 0;
+  for (; s + 2 <= ksteps; s += 2) {
+    // sched_barrier: hipcc otherwise sinks the loads of the next step behind the MFMAs of this one (next to their uses), i.e.
+    // undoes the double buffer
+    load(s + 1, B1{});
+    __builtin_amdgcn_sched_barrier(0);
     compute(B0{});
-    if (s + 1 < ksteps) {
-      load(min(s + 2, ksteps - 1), B0{});
-      compute(B1{});
-    }
+    __builtin_amdgcn_sched_barrier(0);
+    load(min(s + 2, ksteps - 1), B0{});   // (the last trip of an even count re-reads its own step)
+    __builtin_amdgcn_sched_barrier(0);
+    compute(B1{});
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (s < ksteps) compute(B0{});          // odd count: the last step was loaded by the previous trip (or is step 0)
 
   // ---- epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); 32 lanes store the 128
   // contiguous bytes of 32 output channels of one output pixel
