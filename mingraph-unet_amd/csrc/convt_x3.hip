@@ -205,8 +205,21 @@ __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __rest
         }
     }
   };
+#if defined(MGU_DIAG) && MGU_DIAG == 7   // diagnostic build: no output stores (accumulators kept live)
+  {
+    float sacc = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[mi][ni][r];
+    if (sacc == 123.456f) tile_out[tid] = sacc;
+  }
+#else
   if (full_m) store_tile(std::false_type{});
   else store_tile(std::true_type{});
+#endif
 }
 
 }  // namespace

@@ -530,8 +530,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
             }
           }
         };
+#if defined(MGU_DIAG) && MGU_DIAG == 7   // diagnostic build: no output stores (accumulators kept live)
+        {
+          float sacc = 0.f;
+#pragma unroll
+          for (int mi = 0; mi < WMT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WNT; ++ni)
+#pragma unroll
+              for (int rr = 0; rr < 16; ++rr) sacc += acc[mi][ni][rr], acc[mi][ni][rr] = 0.f;
+          if (sacc == 123.456f) img_out[tid] = (T)sacc;
+        }
+#else
         if (interior) store_patch(std::false_type{});
         else store_patch(std::true_type{});
+#endif
         c = 0;
         ++pi;
       } else {
