@@ -27,6 +27,7 @@ struct Tuning {
                             //                0 = fp32 MFMA operands
   bool wino_cp_narrow = true;   // MGU_WINO_CP_NARROW=0: N <= 32 layers stay on wino3x3_f32_kernel<1,1> (A/B)
   bool wino_yfast = false;  // MGU_WINO_YFAST=1: Winograd / halo workgroups walk their patches y fastest inside an image (A/B)
+  bool convt_frag = true;   // MGU_NO_CONVT_FRAG=1: ConvTranspose on the generic tile kernel instead of convt_x3.hip's kernels (A/B)
   bool wino_deep = true;    // MGU_NO_WINO_DEEP=1: one chunk of load lead on the narrow Winograd layers too (A/B)
   bool wino_cp = true;      // MGU_NO_WINO_CP=1: the four-components-per-wave kernel instead of the component-pair split (A/B)
   int wino_rounds = 1;      // MGU_WINO_ROUNDS / MGU_WINO_PPB_CAP: persistence of the Winograd workgroups
@@ -85,7 +86,8 @@ const char* igemm_kernel_name(const IgemmDesc& d, int dtype);
 size_t convt_x3_floats(int Cin, int Cout);
 hipError_t launch_pack_convt_x3(const float* w, float* Wx, int Cin, int Cout, hipStream_t s);
 bool convt_x3_applicable(const IgemmDesc& d);
-hipError_t launch_convt_x3(const IgemmDesc& d, hipStream_t s);   // the kernel family launch_igemm_* will pick (profiling records)  // in / w / out point to bf16, sizes in elements
+hipError_t launch_convt_x3(const IgemmDesc& d, hipStream_t s);
+  // the kernel family launch_igemm_* will pick (profiling records)  // in / w / out point to bf16, sizes in elements
 // elementwise.hip: first convolution (<= 4 input channels on the packed NHWC4 input), VALU + scalar-cache weights
 hipError_t launch_pack_first_w(const float* w, float* wf, int Cout, int Cin, hipStream_t s);
 bool first_conv_applicable(int dtype, int Cin, int Cp, int Cout, int ldout, int coff);

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __rest
 
 size_t convt_x3_floats(int Cin, int Cout) { return (size_t)Cin * Cout * 6; }   // 4 Cout columns x Cin x 3 pieces x 2 bytes
 
+
 hipError_t launch_pack_convt_x3(const float* w, float* Wx, int Cin, int Cout, hipStream_t s) {
   if ((Cin & 15) || (Cout & 31)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(pack_convt_x3_kernel, dim3((unsigned)std::min<int64_t>(4096, ((int64_t)Cin * Cout * 4 + 255) / 256)), dim3(256), 0, s, w, reinterpret_cast<uint16_t*>(Wx), Cin,

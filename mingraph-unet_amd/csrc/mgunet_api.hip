@@ -73,6 +73,7 @@ int mgu_create(int device_id, mgu_ctx** out) {
   t.wino_prec = num("MGU_WINO_PREC", t.wino_prec) ? 1 : 0;
   t.wino_cp = !flag("MGU_NO_WINO_CP");
   t.wino_deep = !flag("MGU_NO_WINO_DEEP");
+  t.convt_frag = !flag("MGU_NO_CONVT_FRAG");
   t.wino_yfast = flag("MGU_WINO_YFAST");
   t.wino_cp_narrow = num("MGU_WINO_CP_NARROW", 1) != 0;
   t.wino_rounds = std::max(1, num("MGU_WINO_ROUNDS", 1));
@@ -173,7 +174,10 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     total += (size_t)L.Np * L.Kp + 2 * (size_t)L.Np + (L.bn.empty() ? 0 : 4 * (size_t)L.Np);
     L.wino = dtype == MGU_DTYPE_F32 && !L.convt && L.KS == 3 && L.Cp % 16 == 0;   // Winograd F(2x2,3x3) layers (wino_f32.hip)
     if (L.wino) total += wino_u_floats(L.Cout, L.Cp);
-    L.ctx3 = dtype == MGU_DTYPE_F32 && L.convt && L.Cin % 16 == 0 && L.Cout % 32 == 0 && c->tn.wino_prec != 0;
+    // fp32 ConvTranspose on fragment-ordered three-piece weights (convt_x3.hip).  (A bf16-storage sibling of that kernel -- one
+    // fragment per operand straight from global memory -- was measured SLOWER than the LDS-tiled generic kernel, 0.178 vs 0.163 ms per
+    // step: 32-byte row segments per K slice; not kept.)
+    L.ctx3 = dtype == MGU_DTYPE_F32 && L.convt && L.Cin % 16 == 0 && L.Cout % 32 == 0 && c->tn.wino_prec != 0 && c->tn.convt_frag;
     if (L.ctx3) total += convt_x3_floats(L.Cin, L.Cout);
     L.first = !L.convt && L.KS == 3 && first_conv_applicable(dtype, L.Cin, L.Cp, L.Cout, 8, 0);
     if (L.first) total += 9 * 4 * (size_t)L.Cout;
@@ -755,7 +759,7 @@ double mgu_unet_mfma_flops(mgu_ctx* c, int B, int H, int W) {
   std::vector<int> hs, wsz;
   level_dims(H, W, c->depth, hs, wsz);
   auto conv = [&](const Layer& L, int h, int w) {
-    if (L.wu && c->tn.use_wino) return 2.0 * ((h + 1) / 2) * ((w + 1) / 2) * 16.0 * L.Cp * L.Cout;   // per 2x2 tile: 16 products
+    if (L.wino && L.wu && c->tn.use_wino) return 2.0 * ((h + 1) / 2) * ((w + 1) / 2) * 16.0 * L.Cp * L.Cout;   // per 2x2 tile: 16 products
     return 2.0 * h * w * 9.0 * L.Cin * L.Cout;
   };
   double fl = 0;
