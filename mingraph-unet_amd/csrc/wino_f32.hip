@@ -817,23 +817,36 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
   //   jp = 0: V0 = r0 - r2 (x = col 0, y = col 2, w = -1),  V1 = r1 + r2 (x = col 1, y = col 2, w = +1)
   //   jp = 1: V2 = r2 - r1 (x = col 2, y = col 1, w = -1),  V3 = r1 - r3 (x = col 1, y = col 3, w = -1)
   u32x4 pc[2][3];   // the three bf16 pieces of a step's A operand, double buffered
-  auto form = [&](const float* Hs, const int jj, const int mi, const int slot) {
+  // RPF (narrow layers): the raw LDS operands of step k + 2 are requested during step k and transformed during step k + 1, so
+  // no LDS round trip sits between a read and the VALU work that consumes it.  With only 6 MFMAs per step a wave has ~190 cycles
+  // of MFMA time to hide behind, and the one-step pipeline (reads and their transform in the same step) left ~6 exposed
+  // lgkmcnt(0) waits per step: the 32-channel layers ran the VALU a third of the time.  Costs 32 registers (a second raw set).
+  constexpr bool RPF = NTB == 1;
+  f32x4 raw[RPF ? 2 : 1][2][4];   // [set][hf][ax, bx, ay, by]
+  auto fetch_raw = [&](const float* Hs, const int jj, const int mi, const int set) {
     const int cx = jj == 0 ? (jp ? S2 : 0) : S1;
     const int cy = jj == 0 ? (jp ? S1 : S2) : (jp ? S3 : S2);
-    const float w = (jj == 1 && jp == 0) ? 1.f : -1.f;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       const float* pa = Hs + offA[mi] + hf * 4;
       const float* pb = Hs + offB[mi] + hf * 4;
-      const f32x4 ax = *reinterpret_cast<const f32x4*>(pa + cx), bxr = *reinterpret_cast<const f32x4*>(pb + cx);
-      const f32x4 ay = *reinterpret_cast<const f32x4*>(pa + cy), byr = *reinterpret_cast<const f32x4*>(pb + cy);
+      raw[set][hf][0] = *reinterpret_cast<const f32x4*>(pa + cx);
+      raw[set][hf][1] = *reinterpret_cast<const f32x4*>(pb + cx);
+      raw[set][hf][2] = *reinterpret_cast<const f32x4*>(pa + cy);
+      raw[set][hf][3] = *reinterpret_cast<const f32x4*>(pb + cy);
+    }
+  };
+  auto form_from = [&](const int jj, const int set, const int slot) {
+    const float w = (jj == 1 && jp == 0) ? 1.f : -1.f;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
       // element by element with scalar FMAs: on <4 x float> values the backend selects v_pk_fma_f32, and a packed fp32
       // instruction beside the MFMAs costs ~22 cycles more than the two v_fma_f32 it replaces (MI355X_MICROARCH.md)
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float qx = scalar_fma(sgn, bxr[e], ax[e]);
-        const float qy = scalar_fma(sgn, byr[e], ay[e]);
+        const float qx = scalar_fma(sgn, raw[set][hf][1][e], raw[set][hf][0][e]);
+        const float qy = scalar_fma(sgn, raw[set][hf][3][e], raw[set][hf][2][e]);
         v[e] = scalar_fma(w, qy, qx);
       }
 #pragma unroll
@@ -843,6 +856,10 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
         pc[slot][0][hf * 2 + e] = p0, pc[slot][1][hf * 2 + e] = p1, pc[slot][2][hf * 2 + e] = p2;
       }
     }
+  };
+  auto form = [&](const float* Hs, const int jj, const int mi, const int slot) {
+    fetch_raw(Hs, jj, mi, 0);
+    form_from(jj, 0, slot);
   };
 
   // Issue order = the steady state's (vmcnt retires in order and hipcc merges the pending-load state of the loop's two
@@ -864,6 +881,7 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
   }
   lds_barrier();
   form(smem, 0, 0, 0);      // step 0 of the first chunk
+  if constexpr (RPF) fetch_raw(smem, 0, 1, 1);   // raw operands of step 1 (set = step & 1)
   f32x4 st1[NTB], st2[NTB];   // (STATS) per-thread sums of its channel quad of every n tile
 #pragma unroll
   for (int nt = 0; nt < NTB; ++nt) st1[nt] = f32x4{0.f, 0.f, 0.f, 0.f}, st2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -902,8 +920,16 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
           t = mfma_bf16(pc[slot][0], bx[SetCur::value][jj][nt][0], t);
           acc[jj][nt][mi] = t;
         }
-        if constexpr (st < 3) form(Hs, (st + 1) >> 1, (st + 1) & 1, slot ^ 1);
-        else form(Hn, 0, 0, slot ^ 1);
+        if constexpr (RPF) {
+          // transform the raw operands of step st + 1 (read one step ago), request those of step st + 2 (the next chunk's after
+          // B1: steps 2 and 3 read chunk c + 1)
+          form_from(((st + 1) >> 1) & 1, (st + 1) & 1, slot ^ 1);
+          if constexpr (st < 2) fetch_raw(Hs, (st + 2) >> 1, (st + 2) & 1, st & 1);
+          else fetch_raw(Hn, (st - 2) >> 1, (st - 2) & 1, st & 1);
+        } else {
+          if constexpr (st < 3) form(Hs, (st + 1) >> 1, (st + 1) & 1, slot ^ 1);
+          else form(Hn, 0, 0, slot ^ 1);
+        }
         if constexpr (mi == 1) load_bx(jj, cn, SetCur{});   // this component's pieces of the next chunk using this set
         constexpr int NM = 6 * NTB;                               // MFMAs of the step
         constexpr int per = (72 + NM - 1) / NM;                   // transform (24) + split (44) + addresses of the next step
@@ -1162,7 +1188,9 @@ hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
   const bool wide = d.N > 32 && tun(d).wino_mode != 1;
   if (tun(d).wino_prec && tun(d).wino_cp && (wide || tun(d).wino_cp_narrow) &&
       (long)d.H * d.W * d.ldin * 4 < (1l << 31)) {   // image bytes fit a buffer descriptor
-    const bool deep = !wide && ((d.Cp >> 4) & 1) == 0 && tun(d).wino_deep;   // two chunks of load lead (see the kernel's DEEP note)
+    // narrow layers: raw-operand prefetch always (RPF in the kernel) + the two-chunk load lead (DEEP) for an even chunk count; the
+    // training forward (fused statistics) keeps the one-chunk lead (DEEP + RPF + statistics spills 4 registers)
+    const bool deep = !wide && ((d.Cp >> 4) & 1) == 0 && tun(d).wino_deep && !d.stat_slots;
     if (d.stat_slots) return wide ? launch_wino_cp<2, true>(d, s) : deep ? launch_wino_cp<1, true, true>(d, s) : launch_wino_cp<1, true>(d, s);
     return wide ? launch_wino_cp<2, false>(d, s) : deep ? launch_wino_cp<1, false, true>(d, s) : launch_wino_cp<1, false>(d, s);
   }
