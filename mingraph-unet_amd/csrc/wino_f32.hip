@@ -909,6 +909,13 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
         constexpr int st = decltype(st_c)::value;
         constexpr int jj = st >> 1, mi = st & 1, slot = st & 1;
         if constexpr (st == 2) lds_barrier();            // B1
+#if defined(MGU_DIAG) && MGU_DIAG == 11   // diagnostic build: no MFMAs in the chunk loop (operands folded into one register each)
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+          for (int q3 = 0; q3 < 3; ++q3)
+            acc[jj][nt][mi][q3] += __uint_as_float(pc[slot][q3][0] ^ pc[slot][q3][1] ^ pc[slot][q3][2] ^ pc[slot][q3][3] ^ bx[SetCur::value][jj][nt][q3][0]);
+#else
 #pragma unroll
         for (int nt = 0; nt < NTB; ++nt) {
           f32x16 t = acc[jj][nt][mi];
@@ -920,15 +927,22 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
           t = mfma_bf16(pc[slot][0], bx[SetCur::value][jj][nt][0], t);
           acc[jj][nt][mi] = t;
         }
+#endif
+#if defined(MGU_DIAG) && MGU_DIAG == 10   // diagnostic build: no input transform / split in the chunk loop (pieces stay constant)
+        if constexpr (false) {
+#else
         if constexpr (RPF) {
+#endif
           // transform the raw operands of step st + 1 (read one step ago), request those of step st + 2 (the next chunk's after
           // B1: steps 2 and 3 read chunk c + 1)
           form_from(((st + 1) >> 1) & 1, (st + 1) & 1, slot ^ 1);
           if constexpr (st < 2) fetch_raw(Hs, (st + 2) >> 1, (st + 2) & 1, st & 1);
           else fetch_raw(Hn, (st - 2) >> 1, (st - 2) & 1, st & 1);
         } else {
+#if !(defined(MGU_DIAG) && MGU_DIAG == 10)
           if constexpr (st < 3) form(Hs, (st + 1) >> 1, (st + 1) & 1, slot ^ 1);
           else form(Hn, 0, 0, slot ^ 1);
+#endif
         }
         if constexpr (mi == 1) load_bx(jj, cn, SetCur{});   // this component's pieces of the next chunk using this set
         constexpr int NM = 6 * NTB;                               // MFMAs of the step
