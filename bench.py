@@ -39,6 +39,7 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: bf16 MFMA dense (never the 2:1-sparse figure)
 PEAK_HBM_TBS = 8.0              # same guide: HBM3E spec peak (6.3 TB/s achievable by a streaming copy)
+ARITH_3PIECE = "3xbf16 split (fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMA products per fp32 product), fp32 accumulate"
 PIPE = {0: ("fp32 MFMA (v_mfma_f32_32x32x2_f32)", PEAK_F32_MFMA_TFLOPS), 1: ("bf16 MFMA (v_mfma_f32_32x32x16_bf16)", PEAK_BF16_MFMA_TFLOPS)}
 
 
@@ -145,6 +146,7 @@ def roofline_from(stats, nprof, arithmetic, traffic=None):
             "issued_flop_per_launch": round(dom["flops_mfma"] / dom["launches"]),
             "algorithmic_flop_per_launch": round(dom["flops_alg"] / dom["launches"]),
             "algorithmic_tflops": round(dom["flops_alg"] / t / 1e12, 2),
+            "algorithmic_frac": round(dom["flops_alg"] / t / 1e12 / peak, 4),
             "fp32_equivalent_tflops": round(fp32_equiv / t / 1e12, 2),
             "fp32_equivalent_frac_of_fp32_mfma_peak": round(fp32_equiv / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic[0] if traffic else None, "traffic_unit": "HBM bytes per launch of this kernel (PMC FETCH_SIZE x2 + WRITE_SIZE)",
@@ -156,13 +158,14 @@ def roofline_from(stats, nprof, arithmetic, traffic=None):
             "note": ("achieved = FLOPs ISSUED on the kernel's matrix pipe per launch / average launch duration (HIP events on the launch "
                      "stream, instrumented pass); frac = achieved / that pipe's dense peak.  algorithmic_* count the direct-convolution "
                      "2*MAC of the operator (Winograd executes 16/36 of them); fp32_equivalent_* count the Winograd multiplies once "
-                     "(not x6 for the three bf16 pieces) against the fp32 MFMA peak -- neither is `frac`.")}
+                     "(not x6 for the three bf16 pieces) against the fp32 MFMA peak -- neither is `frac`.  algorithmic_frac = "
+                     "algorithmic_tflops / the peak of the pipe used (SURVEY 8d's definition of MFMA utilisation).")}
 
 
 def load_traffic(kernel, dtype):
     """HBM bytes per launch of `kernel` from this round's committed PMC passes (rocprofv3 cannot run inside this process)."""
-    tj = os.path.join(ROOT, "profiles", f"r02_traffic_{dtype}.json")
-    if not os.path.exists(tj):
+    tj = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_traffic_{dtype}.json") for r in ("r03", "r02")) if os.path.exists(q)), None)
+    if tj is None:
         return None
     t = json.load(open(tj))
     base = kernel.split("<")[0].split(" ")[0]
@@ -176,7 +179,7 @@ def load_traffic(kernel, dtype):
             b += v["launches"] * v["hbm_bytes_per_launch"]
     if not n:
         return None
-    return round(b / n), f"profiles/r02_traffic_{dtype}.json ({t.get('correction', '')})"
+    return round(b / n), f"profiles/{os.path.basename(tj)} ({t.get('correction', '')})"
 
 
 def gat_record(dev, L, _lib):
@@ -333,6 +336,21 @@ def bench_train(a, world, rank, local_rank, dev, dist):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """Run this script with n ranks of ONE node as child processes (never exec: see the GPU-box rules) and exit with their code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,15 +366,20 @@ def main():
                          "(configs[2]'s precision; reported as its own config, never as the fp32 number)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="length of the one long window reported as `sustained` (0 = off); `value` stays the K timed steps")
     ap.add_argument("--spread-windows", type=int, default=4, help="extra timed windows of --steps steps for the min/median/max record")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this parent has not touched the GPU (nothing above initialises HIP); it starts the N
+        # ranks as fresh children under torch.distributed.run and relays their output -- rank 0 prints the one JSON line
+        return self_launch(a.gpus)
     if a.gpus != world:
-        if a.gpus > 1:
-            sys.exit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus}` (WORLD_SIZE={world})")
+        sys.exit(f"--gpus {a.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the hot path has no CPU fallback")
     # MGU_BENCH_REHEARSAL=1: several ranks share GPU 0 over gloo -- only to rehearse the torchrun plumbing on a
@@ -419,6 +442,18 @@ def main():
                 out = model(x)
             torch.cuda.synchronize(dev)
             windows.append((time.perf_counter() - t1) / a.steps * 1e3)
+        # sustained: ONE window of >= --sustained-seconds of back-to-back steps (the clock the chip holds under seconds of load)
+        sustained = None
+        if a.sustained_seconds > 0:
+            nsus = max(a.steps, int(a.sustained_seconds * 1e3 / max(min(windows), 1e-3)) + 1)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(nsus):
+                out = model(x)
+            torch.cuda.synchronize(dev)
+            sdt = time.perf_counter() - t1
+            sustained = {"steps": nsus, "seconds": round(sdt, 3), "ms_per_step": round(sdt / nsus * 1e3, 4),
+                         "mpix_per_s_per_gpu": round(B * H * W * nsus / sdt / 1e6, 2)}
     assert bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[3]).all())
     dt = max_over_ranks(dt, dist, dev)
     ms_step = dt / a.steps * 1e3
@@ -443,10 +478,10 @@ def main():
             L.mgu_profile_enable(uctx.handle, 0)
             L.mgu_profile_enable(gctx.handle, 0)
         stats = merge_stats(ustats, gstats)
-        arithmetic = ("bf16 storage, fp32 accumulate" if a.dtype == "bf16" else
-                      ("fp32 operands split exactly into 3 bf16 pieces (6 bf16 MFMA products per fp32 product), fp32 accumulate"
-                       if any("wino3x3_f32_kernel<0,1>" in k["name"] for k in stats) else "exact fp32 MFMA operands"))
         dom = next((k for k in stats if k["pipe"] >= 0 and k["flops_mfma"] > 0), None)
+        # the label describes the DOMINANT record itself: an fp32 result computed on the bf16 pipe is the three-piece split
+        arithmetic = ("bf16 storage, fp32 accumulate" if a.dtype == "bf16" else
+                      (ARITH_3PIECE if dom is not None and dom["pipe"] == 1 else "exact fp32 MFMA operands"))
         traffic = load_traffic(dom["name"], a.dtype) if dom and (B, H, W) == (8, 512, 512) else None
         roof = roofline_from(stats, nprof, arithmetic, traffic)
         ksum = sum(k["ms"] for k in stats) / nprof
@@ -479,7 +514,7 @@ def main():
                 "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / a.steps, 4),
                 "spread": {"windows": len(windows), "steps_per_window": a.steps, "min_ms": round(min(windows), 4),
                            "median_ms": round(statistics.median(windows), 4), "max_ms": round(max(windows), 4)},
-                "timing": timing, "roofline": roof, "gat": gatrec, "cpu_baseline": cpu}
+                "sustained": sustained, "timing": timing, "roofline": roof, "gat": gatrec, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
