@@ -445,7 +445,7 @@ def main():
         # sustained: ONE window of >= --sustained-seconds of back-to-back steps (the clock the chip holds under seconds of load)
         sustained = None
         if a.sustained_seconds > 0:
-            nsus = max(a.steps, int(a.sustained_seconds * 1e3 / max(min(windows), 1e-3)) + 1)
+            nsus = max(a.steps, int(1.08 * a.sustained_seconds * 1e3 / max(min(windows), 1e-3)) + 1)   # >= the asked-for seconds
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             for _ in range(nsus):

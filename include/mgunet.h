@@ -291,6 +291,28 @@ int mgu_dice_loss(mgu_ctx* ctx, const void* logits_dev, const int64_t* labels_de
  * contiguous, y (B,N) fp32 (the reference casts y.float()): mean_b sum_n [ y d^2 + (1-y) relu(margin - sqrt(d^2 + 1e-8))^2 ]. */
 int mgu_feature_consistency_loss(mgu_ctx* ctx, const void* f_unet_dev, const void* f_graph_dev, const void* y_dev, int B, int N, int D,
                                  float margin, float* loss_dev, void* hip_stream);
+/* ---- gradients of the differentiable auxiliary losses ---------------------------------------------------------------------------
+ * The reference obtains them from autograd (loss.backward(): scripts/train_segmentation.py:133, scripts/train_end_to_end.py:478).
+ * Each entry multiplies the gradient of the scalar loss by grad_scale and, when grad_scale_dev is not NULL, by that device float
+ * too (an autograd grad_output never has to visit the host).  EllipticalShapeLoss has no gradient w.r.t. its input: it is a
+ * function of the arg-max pixel COORDINATES (shape_loss.py:61-98) -- and the reference loop pins loss_shape to 0 (:287). */
+/* d TVLoss / dx into dx_dev, element (n,c,y,x) at dx_dev[n*ds_n + c*ds_c + y*ds_h + x*ds_w]. */
+int mgu_tv_loss_backward(mgu_ctx* ctx, const void* x_dev, int B, int C, int H, int W, int64_t xs_n, int64_t xs_c, int64_t xs_h,
+                         int64_t xs_w, float weight, float grad_scale, const float* grad_scale_dev, void* dx_dev, int64_t ds_n,
+                         int64_t ds_c, int64_t ds_h, int64_t ds_w, void* hip_stream);
+/* d dice_loss / d logits (through the softmax), element (b, c, p) at dlogits_dev[b*ds_n + c*ds_c + p*ds_p]; accumulate != 0 ADDS to
+ * what is there -- the trainer's `loss_ce + loss_dice` (scripts/train_segmentation.py:126-133) is mgu_cross_entropy followed by this
+ * call on the same dlogits.  loss_dev (optional) receives the loss value of the same pass. */
+int mgu_dice_loss_backward(mgu_ctx* ctx, const void* logits_dev, const int64_t* labels_dev, int B, int64_t HW, int num_classes,
+                           int64_t ls_n, int64_t ls_c, int64_t ls_p, float smooth, float grad_scale, const float* grad_scale_dev,
+                           void* dlogits_dev, int64_t ds_n, int64_t ds_c, int64_t ds_p, int accumulate, float* loss_dev, void* hip_stream);
+/* d FeatureConsistencyLoss / d f_unet and / d f_graph ((B,N,D) contiguous each; either may be NULL). */
+int mgu_feature_consistency_loss_backward(mgu_ctx* ctx, const void* f_unet_dev, const void* f_graph_dev, const void* y_dev, int B, int N,
+                                          int D, float margin, float grad_scale, const float* grad_scale_dev, void* d_f_unet_dev,
+                                          void* d_f_graph_dev, void* hip_stream);
+/* Synchronise the stream and report (MGU_ERR_INVALID) a label outside [0, num_classes) met by mgu_dice_loss[_backward] on this
+ * context since the last check: the place F.one_hot would have raised. */
+int mgu_loss_sync_check(mgu_ctx* ctx, void* hip_stream);
 /* EllipticalShapeLoss.forward (model/unet/shape_loss.py:17-180).  _masks: the object_masks_list form, all masks of the batch
  * stacked (num_objects, H, W) uint8 (non-zero = object pixel).  _probs: the form without masks -- per image, the pixels whose
  * arg-max class is 1 are ONE object (:61-98); probabilities (B,C,H,W) at probs_dev[b*ps_n + c*ps_c + p*ps_p].  Objects under 10

@@ -1,4 +1,4 @@
-// Auxiliary losses of the training loops, forward values on the device:
+// Auxiliary losses of the training loops, forward values and gradients on the device:
 //   mgu_tv_loss                    TVLoss.forward                      scripts/train_end_to_end.py:73-89
 //   mgu_dice_loss                  dice_loss                           scripts/train_segmentation.py:29-40
 //   mgu_feature_consistency_loss   FeatureConsistencyLoss.forward      model/unet/feature_loss.py:88-125
@@ -156,6 +156,131 @@ __global__ void sum_final_kernel(const double* __restrict__ part, int nb, double
   double s = 0;
   for (int i = 0; i < nb; ++i) s += part[i];
   *out = (float)(s * scale);
+}
+
+
+// ---- gradients of the differentiable losses (the reference obtains them from autograd: loss.backward() at
+// scripts/train_segmentation.py:133, scripts/train_end_to_end.py:478) ---------------------------------------------------------
+// Every backward kernel multiplies by gs = grad_scale * (*grad_scale_dev if given): the upstream gradient of the scalar loss,
+// as a host number, a device scalar (an autograd grad_output: no host synchronisation) or both.
+__device__ __forceinline__ float up_scale(float gs, const float* __restrict__ gs_dev) { return gs_dev ? gs * *gs_dev : gs; }
+
+// d TVLoss / dx (scripts/train_end_to_end.py:84-88): each squared difference feeds its two end points
+__global__ __launch_bounds__(256) void tv_bwd_kernel(const float* __restrict__ x, int B, int Cc, int H, int W, int64_t sn, int64_t sc,
+                                                     int64_t sh_, int64_t sw, float kh, float kw, float gs, const float* __restrict__ gs_dev,
+                                                     float* __restrict__ dx, int64_t dn, int64_t dc, int64_t dh, int64_t dw) {
+  const float g = up_scale(gs, gs_dev);
+  const int64_t total = (int64_t)B * Cc * H * W;
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int xw = (int)(i % W);
+    int64_t r = i / W;
+    const int y = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % Cc), n = (int)(r / Cc);
+    const float* p = x + n * sn + c * sc + y * sh_ + xw * sw;
+    const float a = *p;
+    float v = 0.f, h = 0.f;
+    if (y > 0) v += a - p[-sh_];
+    if (y + 1 < H) v -= p[sh_] - a;
+    if (xw > 0) h += a - p[-sw];
+    if (xw + 1 < W) h -= p[sw] - a;
+    dx[n * dn + c * dc + y * dh + xw * dw] = g * (kh * v + kw * h);
+  }
+}
+
+// dice: q[b][c] = dL/dp_c of a pixel of image b = coef[b][0][c] * [y == c] + coef[b][1][c]
+//   L = 1 - mean_{b,c} (2 I + s) / (P + T + s)  ->  dL/dI = -2 / (B C U),  dL/dP = (2 I + s) / (B C U^2),  U = P + T + s
+template <int NC>
+__global__ void dice_coef_kernel(const double* __restrict__ part, int B, int nb, int Cc, double smooth, float* __restrict__ coef) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * NC) return;
+  const int b = t / NC, c = t - b * NC;
+  float c0 = 0.f, c1 = 0.f;
+  if (c < Cc) {
+    double I = 0, P = 0, T = 0;
+    for (int k = 0; k < nb; ++k) {
+      const double* p = part + ((size_t)b * nb + k) * 3 * NC;
+      I += p[c], P += p[NC + c], T += p[2 * NC + c];
+    }
+    const double U = P + T + smooth, inv = 1.0 / ((double)B * Cc);
+    c0 = (float)(-2.0 * inv / U);
+    c1 = (float)((2.0 * I + smooth) * inv / (U * U));
+  }
+  coef[(b * 2 + 0) * NC + c] = c0;
+  coef[(b * 2 + 1) * NC + c] = c1;
+}
+// softmax backward: dlogit_k = p_k (q_k - sum_c q_c p_c); written (or added: the trainer's CE + dice) to dlogits (B*HW, ldd)
+template <int NC>
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int64_t HW,
+                                                       int Cc, int64_t ls_n, int64_t ls_c, int64_t ls_p, const float* __restrict__ coef,
+                                                       float gs, const float* __restrict__ gs_dev, float* __restrict__ dlogits,
+                                                       int64_t ds_n, int64_t ds_c, int64_t ds_p, int accumulate) {
+  const int b = blockIdx.y;
+  const float g = up_scale(gs, gs_dev);
+  float c0[NC], c1[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) c0[c] = coef[(b * 2 + 0) * NC + c], c1[c] = coef[(b * 2 + 1) * NC + c];
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
+    const float* p = logits + b * ls_n + i * ls_p;
+    float l[NC], mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      l[c] = c < Cc ? p[c * ls_c] : -INFINITY;
+      mx = fmaxf(mx, l[c]);
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      l[c] = c < Cc ? expf(l[c] - mx) : 0.f;
+      se += l[c];
+    }
+    const float inv = 1.f / se;
+    const long long y = labels[b * HW + i];
+    float q[NC], dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      l[c] *= inv;
+      q[c] = (y == c ? c0[c] : 0.f) + c1[c];
+      dot += q[c] * l[c];
+    }
+    float* d = dlogits + b * ds_n + i * ds_p;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      if (c < Cc) {
+        const float v = g * l[c] * (q[c] - dot);
+        d[c * ds_c] = accumulate ? d[c * ds_c] + v : v;
+      }
+  }
+}
+
+// feature consistency: d/df_unet = k (a - b) / B,  k = 2 y - 2 (1 - y) relu(m - dist) / dist;  d/df_graph = -that   (:106-123)
+__global__ __launch_bounds__(256) void featcons_bwd_kernel(const float* __restrict__ fu, const float* __restrict__ fg,
+                                                           const float* __restrict__ y, int64_t rows, int D, float margin, float gs,
+                                                           const float* __restrict__ gs_dev, float* __restrict__ dfu,
+                                                           float* __restrict__ dfg) {
+  const float g = up_scale(gs, gs_dev);
+  const int q = threadIdx.x & 15;
+  const int64_t grp = (blockIdx.x * (int64_t)256 + threadIdx.x) >> 4, ngrp = ((int64_t)gridDim.x * 256) >> 4;
+  for (int64_t r = grp; r < rows; r += ngrp) {
+    float d2 = 0.f;
+    for (int c = 4 * q; c < D; c += 64) {
+      const float4 a = *reinterpret_cast<const float4*>(fu + r * D + c), b = *reinterpret_cast<const float4*>(fg + r * D + c);
+      const float e0 = a.x - b.x, e1 = a.y - b.y, e2 = a.z - b.z, e3 = a.w - b.w;
+      d2 += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) d2 += __shfl_xor(d2, off);
+    const float yp = y[r];
+    const float dist = sqrtf(d2 + 1e-8f);
+    const float hinge = fmaxf(margin - dist, 0.f);
+    const float k = g * (2.f * yp - 2.f * (1.f - yp) * hinge / dist);
+    for (int c = 4 * q; c < D; c += 64) {
+      const float4 a = *reinterpret_cast<const float4*>(fu + r * D + c), b = *reinterpret_cast<const float4*>(fg + r * D + c);
+      const float4 o = make_float4(k * (a.x - b.x), k * (a.y - b.y), k * (a.z - b.z), k * (a.w - b.w));
+      if (dfu) *reinterpret_cast<float4*>(dfu + r * D + c) = o;
+      if (dfg) *reinterpret_cast<float4*>(dfg + r * D + c) = make_float4(-o.x, -o.y, -o.z, -o.w);
+    }
+  }
 }
 
 // ---- elliptical shape -----------------------------------------------------------------------------------------------------
@@ -325,6 +450,83 @@ int mgu_dice_loss(mgu_ctx* c, const void* logits_dev, const int64_t* labels_dev,
     hipLaunchKernelGGL(dice_final_kernel<8>, dim3(1), dim3(1), 0, s, ws, B, nb, num_classes, (double)smooth, loss_dev);
   }
   HIPCHK(c, hipGetLastError());
+  return MGU_OK;
+}
+
+int mgu_tv_loss_backward(mgu_ctx* c, const void* x_dev, int B, int Cc, int H, int W, int64_t xs_n, int64_t xs_c, int64_t xs_h,
+                         int64_t xs_w, float weight, float grad_scale, const float* grad_scale_dev, void* dx_dev, int64_t ds_n, int64_t ds_c,
+                         int64_t ds_h, int64_t ds_w, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!x_dev || !dx_dev || B < 1 || Cc < 1 || H < 2 || W < 2) return fail(c, MGU_ERR_INVALID, "bad tv_loss_backward args (H, W >= 2)");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int nb = nblocks((int64_t)B * Cc * H * W);
+  // weight * (h_tv / count_h + w_tv / count_w) / B, each difference d contributing 2 d to its end points
+  const float kh = (float)(2.0 * weight / ((double)(H - 1) * W) / B), kw = (float)(2.0 * weight / ((double)H * (W - 1)) / B);
+  hipLaunchKernelGGL(tv_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)hip_stream, (const float*)x_dev, B, Cc, H, W, xs_n, xs_c, xs_h,
+                     xs_w, kh, kw, grad_scale, grad_scale_dev, (float*)dx_dev, ds_n, ds_c, ds_h, ds_w);
+  HIPCHK(c, hipGetLastError());
+  return MGU_OK;
+}
+
+int mgu_dice_loss_backward(mgu_ctx* c, const void* logits_dev, const int64_t* labels_dev, int B, int64_t HW, int num_classes,
+                           int64_t ls_n, int64_t ls_c, int64_t ls_p, float smooth, float grad_scale, const float* grad_scale_dev,
+                           void* dlogits_dev, int64_t ds_n, int64_t ds_c, int64_t ds_p, int accumulate, float* loss_dev, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!logits_dev || !labels_dev || !dlogits_dev || B < 1 || HW < 1 || num_classes < 1 || num_classes > 8)
+    return fail(c, MGU_ERR_INVALID, "bad dice_loss_backward args (1 <= num_classes <= 8)");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int nb = std::min(128, nblocks(HW));
+  double* ws;
+  int rc = loss_scratch(c, (size_t)B * nb * 24 + (size_t)B * 8, &ws);   // partial records + the coefficient table (floats)
+  if (rc) return rc;
+  float* coef = (float*)(ws + (size_t)B * nb * 24);
+  if (!c->err_word) {
+    HIPCHK(c, hipHostMalloc((void**)&c->err_word, sizeof(int), hipHostMallocMapped));
+    *c->err_word = 0;
+  }
+  int* err_dev = nullptr;
+  HIPCHK(c, hipHostGetDevicePointer((void**)&err_dev, c->err_word, 0));
+#define MGU_DICE_BWD(NC)                                                                                                             \
+  hipLaunchKernelGGL(dice_partial_kernel<NC>, dim3(nb, B), dim3(256), 0, s, (const float*)logits_dev, labels_dev, HW, num_classes, ls_n, \
+                     ls_c, ls_p, ws, err_dev);                                                                                       \
+  if (loss_dev) hipLaunchKernelGGL(dice_final_kernel<NC>, dim3(1), dim3(1), 0, s, ws, B, nb, num_classes, (double)smooth, loss_dev);   \
+  hipLaunchKernelGGL(dice_coef_kernel<NC>, dim3((B * NC + 63) / 64), dim3(64), 0, s, ws, B, nb, num_classes, (double)smooth, coef);    \
+  hipLaunchKernelGGL(dice_bwd_kernel<NC>, dim3(nb, B), dim3(256), 0, s, (const float*)logits_dev, labels_dev, HW, num_classes, ls_n,   \
+                     ls_c, ls_p, coef, grad_scale, grad_scale_dev, (float*)dlogits_dev, ds_n, ds_c, ds_p, accumulate)
+  if (num_classes <= 4) {
+    MGU_DICE_BWD(4);
+  } else {
+    MGU_DICE_BWD(8);
+  }
+#undef MGU_DICE_BWD
+  HIPCHK(c, hipGetLastError());
+  return MGU_OK;
+}
+
+int mgu_feature_consistency_loss_backward(mgu_ctx* c, const void* f_unet_dev, const void* f_graph_dev, const void* y_dev, int B, int N,
+                                          int D, float margin, float grad_scale, const float* grad_scale_dev, void* d_f_unet_dev,
+                                          void* d_f_graph_dev, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!f_unet_dev || !f_graph_dev || !y_dev || (!d_f_unet_dev && !d_f_graph_dev) || B < 1 || N < 1 || D < 4 || (D & 3))
+    return fail(c, MGU_ERR_INVALID, "bad feature_consistency_loss_backward args (D a multiple of 4)");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t rows = (int64_t)B * N;
+  hipLaunchKernelGGL(featcons_bwd_kernel, dim3(nblocks(rows * 16)), dim3(256), 0, (hipStream_t)hip_stream, (const float*)f_unet_dev,
+                     (const float*)f_graph_dev, (const float*)y_dev, rows, D, margin, grad_scale / (float)B, grad_scale_dev,
+                     (float*)d_f_unet_dev, (float*)d_f_graph_dev);
+  HIPCHK(c, hipGetLastError());
+  return MGU_OK;
+}
+
+int mgu_loss_sync_check(mgu_ctx* c, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize((hipStream_t)hip_stream));
+  if (c->err_word && *(volatile int*)c->err_word) {
+    *(volatile int*)c->err_word = 0;
+    return fail(c, MGU_ERR_INVALID, "a label outside [0, num_classes) reached a loss kernel of this context (F.one_hot / CrossEntropyLoss raise on it)");
+  }
   return MGU_OK;
 }
 

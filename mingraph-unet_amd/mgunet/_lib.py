@@ -116,6 +116,14 @@ _PROTOS = {
                                 C.c_float, C.c_void_p, C.c_void_p]),
     "mgu_feature_consistency_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
                                                C.c_void_p, C.c_void_p]),
+    "mgu_tv_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "mgu_dice_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int64, C.c_int64, C.c_int64,
+                                         C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_void_p,
+                                         C.c_void_p]),
+    "mgu_feature_consistency_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                                        C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mgu_loss_sync_check": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgu_elliptical_shape_loss_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "mgu_elliptical_shape_loss_probs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                                   C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),

@@ -211,8 +211,12 @@ class Trainer:
     a single kernel and the gradient exchange a single collective.  Each rank normalises BatchNorm over its
     own shard (DDP semantics)."""
 
-    def __init__(self, model: UNet, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None, comm="auto"):
-        """comm: "auto" -- when torch.distributed runs the "nccl" backend with more than one rank, the gradient exchange is
+    def __init__(self, model: UNet, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None, comm="auto",
+                 loss="ce", dice_smooth=1.0):
+        """loss: "ce" -- nn.CrossEntropyLoss() alone (train_segmentation.py:91,127); "ce+dice" -- the sum the script forms at
+        :126-130, `criterion_ce(logits, masks) + dice_loss(logits, masks)`: the Dice gradient (through the softmax) is added to
+        the cross-entropy gradient in the same dlogits buffer (mgu_dice_loss_backward, accumulate) before the one backward pass.
+        comm: "auto" -- when torch.distributed runs the "nccl" backend with more than one rank, the gradient exchange is
         libmgunet's own RCCL communicator (mgu_comm_init_rank; torch.distributed only carries the 128-byte id) and is
         overlapped with backward (mgu_unet_backward_allreduce); a gloo group (CPU rehearsal of the plumbing) falls back to
         torch.distributed.all_reduce on a host copy.  "rccl": always create the communicator, also for a single process
@@ -245,7 +249,11 @@ class Trainer:
         model.mark_parameters_changed()
         model._slots = None
         self.step_count = 0
+        if loss not in ("ce", "ce+dice"):
+            raise ValueError(f"unknown loss {loss!r}: 'ce' or 'ce+dice'")
+        self.loss_kind, self.dice_smooth = loss, float(dice_smooth)
         self._loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._dice = torch.zeros(1, device=dev, dtype=torch.float32)
         self._rccl = False
         if comm == "rccl" or (comm == "auto" and self._dist_backend() == "nccl" and self._dist_world() > 1):
             self.attach_rccl()
@@ -345,14 +353,21 @@ class Trainer:
         assert nhwc.is_contiguous()
         masks = masks.contiguous()
         npix = B * H * W
-        dlogits = torch.empty((npix, (Cc + 3) // 4 * 4), device=dev, dtype=torch.float32)
+        ldd = (Cc + 3) // 4 * 4
+        dlogits = torch.empty((npix, ldd), device=dev, dtype=torch.float32)
         stream = _lib.current_stream_ptr(dev)
+        loss = self._loss
         with torch.cuda.device(dev):
             _lib.check(L.mgu_cross_entropy(ctx.handle, nhwc.data_ptr(), masks.data_ptr(), npix, Cc, 1.0 / npix,
                                            dlogits.data_ptr(), self._loss.data_ptr(), stream), ctx.handle)
+            if self.loss_kind == "ce+dice":   # loss = loss_ce + loss_dice (:130): d(dice)/d(logits) is ADDED to the CE gradient
+                _lib.check(L.mgu_dice_loss_backward(ctx.handle, nhwc.data_ptr(), masks.data_ptr(), B, H * W, Cc, H * W * Cc, 1, Cc,
+                                                    self.dice_smooth, 1.0, None, dlogits.data_ptr(), H * W * ldd, 1, ldd, 1,
+                                                    self._dice.data_ptr(), stream), ctx.handle)
+                loss = self._loss + self._dice
             bwd = L.mgu_unet_backward_allreduce if exchange else L.mgu_unet_backward
             _lib.check(bwd(ctx.handle, dlogits.data_ptr(), self.grad.data_ptr(), stream), ctx.handle)
-        return self._loss
+        return loss
 
     def check(self) -> None:
         """Synchronise and raise ValueError if a kernel of this trainer met invalid data (a label outside [0, C) other than

@@ -7,7 +7,7 @@ weights / inputs of oracle/mgunet_oracle.py, checks that the oracle restatement 
 stores the reference's outputs as small fixtures.  Fixtures hold data only (inputs that are
 not formula-derivable, expected outputs, sample indices) -- never reference source text.
 
-Usage:  python oracle/make_golden.py [--only tiny,gat,graph,mincut,region,dethead,losses,c1,c2,c4,c5]
+Usage:  python oracle/make_golden.py [--only tiny,gat,graph,mincut,region,dethead,losses,scriptlosses,c1,c2,c4,c5]
 """
 import argparse
 import os
@@ -376,6 +376,110 @@ def gen_losses():
     save("losses.npz", **out)
 
 
+def ref_script_symbol(rel_path, name):
+    """TVLoss / dice_loss live in script modules whose import needs cv2 (absent).  Neither definition uses cv2: take the
+    class / function node out of the reference file's syntax tree and execute just that node with torch, nn, F in scope --
+    the reference's own code, run here in the build container only; nothing of it is stored (fixtures hold numbers)."""
+    import ast
+    import torch.nn as nn
+    import torch.nn.functional as F
+    src = open(os.path.join(REF, rel_path)).read()
+    node = next(n for n in ast.parse(src).body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name == name)
+    ns = {"torch": torch, "nn": nn, "F": F}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), rel_path, "exec"), ns)
+    return ns[name]
+
+
+def gen_scriptlosses():
+    print("[scriptlosses] TVLoss (scripts/train_end_to_end.py:73-89), dice_loss (scripts/train_segmentation.py:29-40): values and "
+          "gradients from the reference definitions (syntax-tree extraction, see ref_script_symbol)")
+    RefTV = ref_script_symbol("scripts/train_end_to_end.py", "TVLoss")
+    ref_dice = ref_script_symbol("scripts/train_segmentation.py", "dice_loss")
+    out = {}
+    for tag, (shape, weight, seed) in {"tv_a": ((2, 1, 17, 23), 1.0, 1), "tv_b": ((3, 2, 64, 48), 0.37, 2), "tv_c": ((1, 1, 2, 2), 1.0, 3),
+                                       "tv_d": ((8, 1, 128, 128), 0.1, 4)}.items():
+        x = torch.from_numpy(O.formula_normal(f"sloss/{tag}/x", shape, seed=seed)).requires_grad_(True)
+        ref = RefTV(weight)(x)
+        ref.backward()
+        xo = x.detach().clone().requires_grad_(True)
+        mine = O.tv_loss(xo, weight)
+        mine.backward()
+        check(tag, mine.detach().reshape(1), ref.detach().reshape(1), tol=1e-6 * max(1.0, float(ref)))
+        check(tag + ".grad", xo.grad, x.grad, tol=1e-7)
+        out[tag] = np.float32(float(ref))
+        out[tag + "_grad"] = x.grad.numpy()
+        print(f"   {tag}: loss {float(ref):.6f}")
+    for tag, (B, C, H, W, smooth, scale, seed) in {"dice_a": (2, 2, 16, 16, 1.0, 2.0, 5), "dice_b": (3, 4, 33, 20, 0.5, 1.0, 6),
+                                                   "dice_c": (1, 2, 128, 128, 1.0, 3.0, 7), "dice_d": (2, 3, 8, 8, 1e-3, 8.0, 8)}.items():
+        lg = (torch.from_numpy(O.formula_normal(f"sloss/{tag}/x", (B, C, H, W), seed=seed)) * scale).requires_grad_(True)
+        y = torch.from_numpy(O.formula_labels(f"sloss/{tag}/y", (B, H, W), C, seed=seed + 10))
+        if tag == "dice_d":
+            y[0] = 0                                         # a class absent from an image: intersection 0, the smooth term decides
+        ref = ref_dice(lg, y, smooth)
+        ref.backward()
+        lo = lg.detach().clone().requires_grad_(True)
+        mine = O.dice_loss(lo, y, smooth)
+        mine.backward()
+        check(tag, mine.detach().reshape(1), ref.detach().reshape(1), tol=1e-6)
+        check(tag + ".grad", lo.grad, lg.grad, tol=1e-8)
+        out[tag] = np.float32(float(ref))
+        out[tag + "_grad"] = lg.grad.numpy()
+        if tag == "dice_d":
+            out[tag + "_y"] = y.numpy()
+        # the trainer's combined loss (scripts/train_segmentation.py:126-133): CrossEntropyLoss + dice_loss, one backward
+        l2 = lg.detach().clone().requires_grad_(True)
+        tot = torch.nn.CrossEntropyLoss()(l2, y) + ref_dice(l2, y, smooth)
+        tot.backward()
+        out[tag + "_cedice"] = np.float32(float(tot))
+        out[tag + "_cedice_grad"] = l2.grad.numpy()
+        print(f"   {tag}: dice {float(ref):.6f}  ce+dice {float(tot):.6f}")
+    # ---- gradients of FeatureConsistencyLoss (importable class; the inputs are those of gen_losses) ----
+    for tag, (B, N, D, margin, scale) in {"fc_a": (2, 64, 64, 1.0, 0.1), "fc_b": (3, 1024, 32, 2.5, 0.3), "fc_c": (1, 7, 20, 0.5, 1.0)}.items():
+        fu = torch.from_numpy(O.formula_normal(f"loss/{tag}/u", (B, N, D), seed=1)) * scale
+        fg = fu + torch.from_numpy(O.formula_normal(f"loss/{tag}/g", (B, N, D), seed=2)) * scale * 0.5
+        y = torch.from_numpy(O.formula_labels(f"loss/{tag}/y", (B, N), 2, seed=3))
+        fg[0, 0] = fu[0, 0] + 1e-3                            # (gen_losses uses an identical pair; its gradient is 0/0-prone: keep it apart here)
+        fu.requires_grad_(True), fg.requires_grad_(True)
+        ref = RefFeatLoss(margin=margin)(fu, fg, y)
+        ref.backward()
+        a, b = fu.detach().clone().requires_grad_(True), fg.detach().clone().requires_grad_(True)
+        O.feature_consistency_loss(a, b, y, margin).backward()
+        check(tag + ".grad_u", a.grad, fu.grad, tol=1e-7)
+        check(tag + ".grad_g", b.grad, fg.grad, tol=1e-7)
+        idx = sample_idx(f"sloss/{tag}/idx", fu.numel(), 2048)
+        out[tag + "_val"] = np.float32(float(ref))
+        out[tag + "_idx"] = idx
+        out[tag + "_grad_u"] = fu.grad.reshape(-1)[idx].numpy()
+        out[tag + "_grad_g"] = fg.grad.reshape(-1)[idx].numpy()
+    # ---- one train step with CE + dice (scripts/train_segmentation.py:121-134) on the reference UNet, train mode ----
+    cfg = (3, 2, 8, 2)
+    p = O.make_unet_params(*cfg, seed=21)
+    x = torch.from_numpy(O.formula_normal("sloss/tr/x", (2, 3, 32, 32), seed=22))
+    y = torch.from_numpy(O.formula_labels("sloss/tr/y", (2, 32, 32), 2, seed=23))
+    m = ref_unet(cfg, p, train=True)
+    lg, _, _ = m(x)
+    loss = torch.nn.CrossEntropyLoss()(lg, y) + ref_dice(lg, y)
+    loss.backward()
+    grads = {k: v.grad.detach().clone() for k, v in m.named_parameters()}
+    oloss, og, _, _, _, _ = O.train_step(p, x, y, cfg[3], loss_kind="ce+dice")
+    assert abs(float(oloss) - float(loss)) <= 1e-6 * abs(float(loss)), (float(oloss), float(loss))
+    names = list(grads.keys())
+    for k in names:
+        assert float((og[k] - grads[k]).norm()) <= 2e-3 * float(grads[k].norm()) + 1e-7, k
+    m64 = ref_unet(cfg, p, train=True).double()
+    lg64, _, _ = m64(x.double())
+    (torch.nn.CrossEntropyLoss()(lg64, y) + ref_dice(lg64, y)).backward()
+    g64 = {k: v.grad.detach() for k, v in m64.named_parameters()}
+    out["tr_loss"] = np.float64(float(loss))
+    out["tr_names"] = np.array(names)
+    out["tr_grad_norms"] = np.array([float(grads[k].norm()) for k in names], dtype=np.float64)
+    out["tr_grad_norms64"] = np.array([float(g64[k].norm()) for k in names], dtype=np.float64)
+    out["tr_cond"] = np.array([float((grads[k].double() - g64[k]).norm() / (g64[k].norm() + 1e-300)) for k in names])
+    out["tr_grad_flat64"] = torch.cat([g64[k].reshape(-1) for k in names]).numpy().astype(np.float32)
+    print(f"   train step CE + dice: loss {float(loss):.6f}, fp32-vs-fp64 reference gradient deviation median {np.median(out['tr_cond']):.2e}")
+    save("script_losses.npz", **out)
+
+
 def gen_graph():
     print("[graph] COO index maps: 128^2/p32, 130x140/p32, 512^2/p16, 1024^2/p16, 16x16/p16 (empty)")
     out = {}
@@ -544,11 +648,11 @@ def gen_c5():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,gat,graph,mincut,region,dethead,losses,c1,c2,c4,c5")
+    ap.add_argument("--only", default="tiny,gat,graph,mincut,region,dethead,losses,scriptlosses,c1,c2,c4,c5")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    fns = {"tiny": gen_tiny, "gat": gen_gat, "graph": gen_graph, "mincut": gen_mincut, "region": gen_region, "dethead": gen_dethead, "losses": gen_losses, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
+    fns = {"tiny": gen_tiny, "gat": gen_gat, "graph": gen_graph, "mincut": gen_mincut, "region": gen_region, "dethead": gen_dethead, "losses": gen_losses, "scriptlosses": gen_scriptlosses, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
     for k in a.only.split(","):
         t0 = time.time()
         fns[k]()

@@ -785,16 +785,21 @@ def eval_step(p, x, depth=4):
 
 
 def train_step(p, x, y, depth=4, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, step=1,
-               exp_avg=None, exp_avg_sq=None):
-    """zero_grad -> fwd -> CrossEntropyLoss (mean) -> backward -> Adam(lr, wd as L2-in-grad).
+               exp_avg=None, exp_avg_sq=None, loss_kind="ce"):
+    """zero_grad -> fwd -> CrossEntropyLoss (mean) [+ dice_loss] -> backward -> Adam(lr, wd as L2-in-grad).
 
-    train_segmentation.py:91,96,121-134 with torch.optim.Adam semantics.  Returns
+    train_segmentation.py:91,96,121-134 with torch.optim.Adam semantics; loss_kind "ce+dice" is the sum the script forms at
+    :126-130 (its dice term cannot run there: `F` is never imported).  Returns
     (loss, grads, new_params, new_bn_stats, exp_avg, exp_avg_sq)."""
     names = [k for k, v in p.items() if v.dtype.is_floating_point and "running_" not in k]
     q = OrderedDict((k, (v.clone().requires_grad_(True) if k in names else v.clone())) for k, v in p.items())
     stats = {}
     logits, _, _ = unet_forward(q, x, depth, training=True, new_stats=stats)
     loss = F.cross_entropy(logits, y)
+    if loss_kind == "ce+dice":
+        loss = loss + dice_loss(logits, y)  # :128-130
+    elif loss_kind != "ce":
+        raise ValueError(loss_kind)
     grads = torch.autograd.grad(loss, [q[k] for k in names])
     grads = OrderedDict(zip(names, grads))
     new_p = OrderedDict((k, v.detach().clone()) for k, v in q.items())

@@ -2,7 +2,9 @@
 the HIP path, through the mirrors of the reference's classes:
   * FeatureConsistencyLoss, EllipticalShapeLoss, FeatureFusion: against fixtures the reference's own classes produced
     (tests/golden/losses.npz) and against the oracle;
-  * TVLoss, dice_loss: hand-computed answers + the oracle (their script modules need cv2: not importable);
+  * TVLoss, dice_loss: values AND gradients against what the reference's own definitions produced (tests/golden/script_losses.npz:
+    oracle/make_golden.py executes the class / function nodes of the reference scripts), hand-computed answers, the oracle;
+  * the gradients of TVLoss / dice_loss / FeatureConsistencyLoss (HIP backward kernels behind torch.autograd.Function nodes);
   * ImagePreprocessor / EdgeDetector / HistogramEqualizer / patch means / colour map: BIT-EXACT against the oracle's PIL / numpy
     restatement (byte and integer work)."""
 import numpy as np
@@ -43,6 +45,78 @@ def test_dice_loss(cuda):
     lg7 = torch.from_numpy(O.formula_normal("dice/l7", (2, 7, 20, 20), seed=4))
     y7 = torch.from_numpy(O.formula_labels("dice/y7", (2, 20, 20), 7, seed=5))
     assert close(mgunet.dice_loss(lg7.to(cuda), y7.to(cuda)), O.dice_loss(lg7.double(), y7), 1e-6)
+
+
+def test_tv_dice_featcons_values_and_gradients_vs_reference_fixture(cuda, golden):
+    """Values and autograd gradients of the HIP losses against the reference definitions' own outputs (script_losses.npz)."""
+    from test_oracle_golden import SCRIPT_DICE, SCRIPT_FC, SCRIPT_TV, script_dice_inputs, script_fc_inputs
+    g = golden["script_losses"]
+    for tag, (shape, weight, seed) in SCRIPT_TV.items():
+        x = torch.from_numpy(O.formula_normal(f"sloss/{tag}/x", shape, seed=seed)).to(cuda).requires_grad_(True)
+        v = mgunet.TVLoss(weight)(x)
+        assert close(v, g[tag], 2e-6), (tag, float(v), float(g[tag]))
+        (3.0 * v).backward()                                      # an upstream factor: the grad_output path
+        ref = 3.0 * g[tag + "_grad"]
+        assert np.abs(x.grad.cpu().numpy() - ref).max() <= 2e-6 * max(1e-3, np.abs(ref).max()) + 1e-9, tag
+    for tag in SCRIPT_DICE:
+        lg, y, smooth = script_dice_inputs(g, tag)
+        for nhwc in (False, True):                                # NCHW storage and the NHWC storage mgunet.UNet returns
+            l = lg.to(cuda)
+            if nhwc:
+                l = l.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+            l.requires_grad_(True)
+            v = mgunet.dice_loss(l, y.to(cuda), smooth)
+            assert close(v, g[tag], 2e-6), (tag, float(v), float(g[tag]))
+            v.backward()
+            ref = g[tag + "_grad"]
+            assert np.abs(l.grad.cpu().numpy() - ref).max() <= 5e-6 * np.abs(ref).max() + 1e-10, (tag, nhwc)
+    for tag in SCRIPT_FC:
+        fu, fg, y, margin = script_fc_inputs(tag)
+        a, b = fu.to(cuda).requires_grad_(True), fg.to(cuda).requires_grad_(True)
+        v = mgunet.FeatureConsistencyLoss(margin)(a, b, y.to(cuda))
+        assert close(v, g[tag + "_val"], 2e-6), tag
+        v.backward()
+        idx = torch.from_numpy(g[tag + "_idx"])
+        for got, key in ((a.grad, "_grad_u"), (b.grad, "_grad_g")):
+            ref = g[tag + key]
+            assert np.abs(got.cpu().reshape(-1)[idx].numpy() - ref).max() <= 1e-5 * np.abs(ref).max() + 1e-9, (tag, key)
+    # an out-of-range label: F.one_hot raises in the reference; here the next check_labels() does
+    lg, y, _ = script_dice_inputs(g, "dice_a")
+    y = y.clone()
+    y[0, 0, 0] = 5
+    mgunet.dice_loss(lg.to(cuda), y.to(cuda))
+    with pytest.raises(ValueError, match="label outside"):
+        mgunet.losses.check_labels(cuda)
+    mgunet.losses.check_labels(cuda)                              # reported once
+
+
+def test_trainer_ce_plus_dice_vs_reference_fixture(cuda, golden):
+    """Trainer(loss="ce+dice") = `loss = loss_ce + loss_dice; loss.backward()` of scripts/train_segmentation.py:126-133 against
+    the step the reference UNet + the reference's dice_loss definition took under torch autograd (script_losses.npz, float64
+    gradients as the yardstick; contract: per-parameter gradient norm within 2 * cond + 1e-3 of float64, cond = the deviation
+    of the reference's own fp32 gradients from float64, and the flat gradient within 2e-3 relative L2)."""
+    g = golden["script_losses"]
+    cfg = (3, 2, 8, 2)
+    model = mgunet.UNet(*cfg)
+    model.load_state_dict(O.make_unet_params(*cfg, seed=21))
+    model = model.to(cuda)
+    x = torch.from_numpy(O.formula_normal("sloss/tr/x", (2, 3, 32, 32), seed=22)).to(cuda)
+    y = torch.from_numpy(O.formula_labels("sloss/tr/y", (2, 32, 32), 2, seed=23)).to(cuda)
+    tr = mgunet.Trainer(model, loss="ce+dice", comm=None)
+    loss = tr.forward_backward(x, y)
+    assert abs(float(loss) - float(g["tr_loss"])) <= 1e-5 * float(g["tr_loss"]), (float(loss), float(g["tr_loss"]))
+    names = [str(n) for n in g["tr_names"]]
+    params = dict(model.named_parameters())
+    assert list(params.keys()) == names
+    gn = np.array([float(params[k].grad.norm()) for k in names])
+    ref, cond = g["tr_grad_norms64"], g["tr_cond"]
+    big = ref > 1e-4 * ref.max()
+    assert np.all(np.abs(gn[big] / ref[big] - 1) <= 2 * cond[big] + 1e-3)
+    flat = tr.grad.cpu().numpy()
+    r64 = g["tr_grad_flat64"]
+    assert np.linalg.norm(flat - r64) <= 2e-3 * np.linalg.norm(r64)
+    with pytest.raises(ValueError):
+        mgunet.Trainer(model, loss="dice")
 
 
 def test_feature_consistency_loss_vs_reference_fixture(cuda, golden):

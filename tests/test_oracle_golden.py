@@ -233,9 +233,83 @@ def test_aux_losses_and_feature_fusion_branches_vs_reference_fixtures(golden):
     assert torch.equal(O.feature_fusion_full([fu0, fu1], fg2, 12, region_to_pixel_map=rmap), torch.from_numpy(g["ff_regions"]))
 
 
+SCRIPT_TV = {"tv_a": ((2, 1, 17, 23), 1.0, 1), "tv_b": ((3, 2, 64, 48), 0.37, 2), "tv_c": ((1, 1, 2, 2), 1.0, 3), "tv_d": ((8, 1, 128, 128), 0.1, 4)}
+SCRIPT_DICE = {"dice_a": (2, 2, 16, 16, 1.0, 2.0, 5), "dice_b": (3, 4, 33, 20, 0.5, 1.0, 6), "dice_c": (1, 2, 128, 128, 1.0, 3.0, 7),
+               "dice_d": (2, 3, 8, 8, 1e-3, 8.0, 8)}
+SCRIPT_FC = {"fc_a": (2, 64, 64, 1.0, 0.1), "fc_b": (3, 1024, 32, 2.5, 0.3), "fc_c": (1, 7, 20, 0.5, 1.0)}
+
+
+def script_dice_inputs(g, tag):
+    B, C, H, W, smooth, scale, seed = SCRIPT_DICE[tag]
+    lg = torch.from_numpy(O.formula_normal(f"sloss/{tag}/x", (B, C, H, W), seed=seed)) * scale
+    y = torch.from_numpy(g[tag + "_y"]) if tag + "_y" in g.files else torch.from_numpy(O.formula_labels(f"sloss/{tag}/y", (B, H, W), C, seed=seed + 10))
+    return lg, y, smooth
+
+
+def script_fc_inputs(tag):
+    B, N, D, margin, scale = SCRIPT_FC[tag]
+    fu = torch.from_numpy(O.formula_normal(f"loss/{tag}/u", (B, N, D), seed=1)) * scale
+    fg = fu + torch.from_numpy(O.formula_normal(f"loss/{tag}/g", (B, N, D), seed=2)) * scale * 0.5
+    y = torch.from_numpy(O.formula_labels(f"loss/{tag}/y", (B, N), 2, seed=3))
+    fg[0, 0] = fu[0, 0] + 1e-3
+    return fu, fg, y, margin
+
+
+def test_tv_dice_featcons_values_and_gradients_vs_reference_fixture(golden):
+    """tests/golden/script_losses.npz holds what the reference's OWN TVLoss (scripts/train_end_to_end.py:73-89) and dice_loss
+    (scripts/train_segmentation.py:29-40) definitions returned -- executed from the reference files' syntax trees by
+    oracle/make_golden.py, their modules need cv2 -- with the gradients torch autograd gave them, and the gradients of
+    FeatureConsistencyLoss: the restatements are pinned by them, values and gradients."""
+    g = golden["script_losses"]
+    for tag, (shape, weight, seed) in SCRIPT_TV.items():
+        x = torch.from_numpy(O.formula_normal(f"sloss/{tag}/x", shape, seed=seed)).requires_grad_(True)
+        v = O.tv_loss(x, weight)
+        v.backward()
+        assert abs(float(v) - float(g[tag])) <= 1e-6 * max(1.0, float(g[tag])), tag
+        assert np.abs(x.grad.numpy() - g[tag + "_grad"]).max() <= 1e-7, tag
+    for tag in SCRIPT_DICE:
+        lg, y, smooth = script_dice_inputs(g, tag)
+        lg.requires_grad_(True)
+        v = O.dice_loss(lg, y, smooth)
+        v.backward()
+        assert abs(float(v) - float(g[tag])) <= 1e-6, tag
+        assert np.abs(lg.grad.numpy() - g[tag + "_grad"]).max() <= 1e-8, tag
+        l2 = lg.detach().clone().requires_grad_(True)
+        tot = torch.nn.functional.cross_entropy(l2, y) + O.dice_loss(l2, y, smooth)
+        tot.backward()
+        assert abs(float(tot) - float(g[tag + "_cedice"])) <= 1e-6 * float(g[tag + "_cedice"]), tag
+        assert np.abs(l2.grad.numpy() - g[tag + "_cedice_grad"]).max() <= 1e-7, tag
+    for tag in SCRIPT_FC:
+        fu, fg, y, margin = script_fc_inputs(tag)
+        fu.requires_grad_(True), fg.requires_grad_(True)
+        v = O.feature_consistency_loss(fu, fg, y, margin)
+        v.backward()
+        idx = torch.from_numpy(g[tag + "_idx"])
+        assert abs(float(v) - float(g[tag + "_val"])) <= 1e-6 * max(1.0, float(g[tag + "_val"])), tag
+        assert np.abs(fu.grad.reshape(-1)[idx].numpy() - g[tag + "_grad_u"]).max() <= 1e-7, tag
+        assert np.abs(fg.grad.reshape(-1)[idx].numpy() - g[tag + "_grad_g"]).max() <= 1e-7, tag
+
+
+def test_train_step_ce_plus_dice_vs_reference_fixture(golden):
+    """`loss = loss_ce + loss_dice; loss.backward()` (scripts/train_segmentation.py:126-133) on the reference UNet with the
+    reference's dice_loss definition: the oracle's train_step(loss_kind="ce+dice") reproduces loss and gradients."""
+    g = golden["script_losses"]
+    cfg = (3, 2, 8, 2)
+    p = O.make_unet_params(*cfg, seed=21)
+    x = torch.from_numpy(O.formula_normal("sloss/tr/x", (2, 3, 32, 32), seed=22))
+    y = torch.from_numpy(O.formula_labels("sloss/tr/y", (2, 32, 32), 2, seed=23))
+    loss, grads, _, _, _, _ = O.train_step(p, x, y, cfg[3], loss_kind="ce+dice")
+    assert abs(float(loss) - float(g["tr_loss"])) <= 1e-6 * float(g["tr_loss"])
+    names = [str(n) for n in g["tr_names"]]
+    assert list(grads.keys()) == names
+    gn = np.array([float(grads[k].norm()) for k in names])
+    big = g["tr_grad_norms"] > 1e-4 * g["tr_grad_norms"].max()
+    assert np.all(np.abs(gn[big] / g["tr_grad_norms"][big] - 1) <= 2e-3)
+
+
 def test_tv_and_dice_known_answers():
-    """TVLoss / dice_loss live in script modules that need cv2 (not importable here): their restatements are pinned by answers worked
-    out by hand from scripts/train_end_to_end.py:84-88 and scripts/train_segmentation.py:30-40."""
+    """Hand-computed answers from scripts/train_end_to_end.py:84-88 and scripts/train_segmentation.py:30-40 (kept beside the
+    reference-generated fixtures of the test above)."""
     x = torch.arange(24.0).reshape(1, 1, 4, 6)              # vertical steps 6, horizontal steps 1
     assert float(O.tv_loss(x)) == 37.0                      # 18*36/18 + 20*1/20
     assert float(O.tv_loss(torch.cat([x, x]), weight=0.5)) == 18.5     # sums double, / batch 2, * weight
