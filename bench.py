@@ -274,7 +274,10 @@ def bench_train(a, world, rank, local_rank, dev, dist):
     # the gradient exchange is libmgunet's own RCCL communicator (mgu_unet_backward_allreduce: buckets overlapped with backward);
     # at one rank it is created too, so that the single-GPU number contains the (degenerate) collective calls
     rehearsal = dist is not None and dist.get_backend() != "nccl"
-    tr = mgunet.Trainer(model, lr=1e-3, weight_decay=1e-4, comm="auto" if rehearsal else "rccl")
+    # one rank: libmgunet's own communicator (degenerate collective, so the single-GPU number contains the calls); several ranks:
+    # torch.distributed's RCCL all-reduce after backward unless --comm rccl opts in to the overlapped in-library exchange
+    comm = a.comm or ("rccl" if (world == 1 and not rehearsal) else "auto")
+    tr = mgunet.Trainer(model, lr=1e-3, weight_decay=1e-4, comm="auto" if rehearsal else comm)
     gen = torch.Generator(device=dev)
     gen.manual_seed(4321 + rank)
     x = torch.randn((B, 3, H, W), device=dev, generator=gen)
@@ -328,7 +331,8 @@ def bench_train(a, world, rank, local_rank, dev, dist):
                            "images_per_gpu": B, "global_batch": B * world,
                            "parallelism": (f"dp{world}: mean all-reduce of the flat {tr.flat.numel() * 4 / 1e6:.1f} MB fp32 gradient on "
                                            f"libmgunet's own RCCL communicator, in >= 4 MB buckets overlapped with backward"
-                                           if tr._rccl else f"dp{world}: gloo rehearsal (host all-reduce)")},
+                                           if tr._rccl else f"dp{world}: torch.distributed all-reduce of the flat gradient after backward "
+                                                            f"({dist.get_backend() if dist is not None else 'single process'})")},
                 "final_loss": round(float(loss), 6),
                 "approx_tflops": round(flops * a.steps / dt / 1e12, 2), "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
@@ -364,6 +368,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: fp32 results (BASELINE configs[1], the headline); bf16: bf16 storage + fp32 accumulate "
                          "(configs[2]'s precision; reported as its own config, never as the fp32 number)")
+    ap.add_argument("--comm", choices=["auto", "rccl"], default=None,
+                    help="train mode, gradient exchange: auto = torch.distributed all-reduce after backward (default for N > 1); "
+                         "rccl = libmgunet's bucketed RCCL exchange overlapped with backward (default for N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--sustained-seconds", type=float, default=2.0,

@@ -383,7 +383,8 @@ int mgu_profile_enable(mgu_ctx* ctx, int on);
 /* Per kernel family, summed over the launches recorded since mgu_profile_enable(ctx, 1) (U-Net forward / backward convolutions,
  * GAT kernels): time between HIP events recorded on the launch stream right around each launch, algorithmic FLOPs (2*MAC of the
  * operator) and the FLOPs actually issued on the matrix pipe (`pipe`: 0 fp32 MFMA, 1 bf16 MFMA, -1 none).  `name` is the kernel's
- * name as rocprofv3 --kernel-trace prints it (template arguments included where two instantiations are used). */
+ * name as rocprofv3 --kernel-trace prints it (template arguments included where two instantiations are used).  A read CONSUMES the
+ * records: with profiling left on, the next read covers the launches since this one. */
 typedef struct {
   const char* name;
   double ms, flops_alg, flops_mfma;

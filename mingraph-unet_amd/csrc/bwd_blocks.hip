@@ -141,7 +141,7 @@ int mgu_conv_transpose2x2_wgrad_nhwc(mgu_ctx* c, const void* in_dev, const void*
   g.M = B * H * W, g.H = H, g.W = W, g.Hs = 2 * H, g.Ws = 2 * W;
   g.N = Cin, g.K = Kt, g.Kp = Kpt, g.dw = sc.dwp, g.dw_capacity = sc.dwp_floats;
   HIPCHK(c, launch_wgrad_f32(g, s));
-  HIPCHK(c, launch_unpack_convt_grad(sc.dwp, (float*)dw_iohw_dev, Cin, Cout, Kpt, s));
+  HIPCHK(c, launch_unpack_convt_grad(sc.dwp, g.groups, (size_t)g.N * g.Kp, (float*)dw_iohw_dev, Cin, Cout, Kpt, s));
   if (dbias_dev)
     HIPCHK(c, launch_colsum((const float*)dout_dev + c_off, ld_d, (int64_t)B * H * W * 4, Cout, sc.red, (float*)dbias_dev, s));
   return MGU_OK;

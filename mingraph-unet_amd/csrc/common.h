@@ -68,7 +68,7 @@ struct IgemmDesc {
   float* pool;
   int ldpool;
   // optional (Winograd kernel, training forward): per-channel sum / sum of squares of the stored output accumulated into the
-  // slotted double accumulator [64][2 * N] (train_kernels.hip), folded by launch_bn_finalize_slots
+  // row-per-workgroup double accumulator [STAT_ROWS][2 * N] (train_kernels.hip), folded by launch_bn_finalize_slots
   double* stat_slots;
   // optional split epilogue (out_mode 0): columns n >= split_n go to out2[m*ld2 + (n - split_n)] (0 = off)
   int split_n;
@@ -110,9 +110,8 @@ struct WgradDesc {
   int M, H, W;      // rows enumerate (img, y, x) over H x W
   int Hs, Ws;       // KS == 2 source grid
   int N, K, Kp;     // Dw panel [>=N][Kp]
-  float* dw;        // [groups][>=N][Kp] partial panels; the launcher sets `groups`.  groups == 1: accumulated with
-                    // float atomics into ONE panel (zeroed by the launcher); groups > 1: plain stores, every element of
-                    // every partial panel written (no zeroing needed), the caller sums the panels
+  float* dw;        // [groups][>=N][Kp] partial panels; the launcher sets `groups`.  Plain stores, every element (n < N, k < K)
+                    // of every partial panel written (no zeroing needed, no atomics); the caller sums the panels in order
   size_t dw_capacity;  // floats available at dw
   int groups;          // set by the launcher
   int rows_per_split;  // set by the launcher
@@ -127,6 +126,13 @@ bool wgrad_thin_applicable(const WgradDesc& d);
 hipError_t launch_wgrad_thin(WgradDesc& d, hipStream_t s);
 
 // train_kernels.hip
+// Per-channel reductions meet in a table of double rows [rows][2 * C]; every workgroup adds into a row of its OWN (row =
+// blockIdx.x: one adder per element, onto zero), and the reader folds the rows in a fixed order and clears them -- so a sum is
+// bitwise reproducible from run to run (64 shared slots with several adders each were not: the order of double atomics moved
+// the last bit of a BatchNorm statistic about once in a thousand steps).  STAT_ROWS bounds the grid of the Winograd kernels
+// that accumulate statistics in their epilogue (one round of <= 2 x 256 workgroups + rounding).
+constexpr int STAT_ROWS = 576;
+inline int chan_reduce_rows(int C) { int r = (1 << 19) / (2 * C); return r < 64 ? 64 : (r > 4096 ? 4096 : r); }
 size_t chan_reduce_work_bytes(int Cmax);
 hipError_t launch_bn_stats(const float* z, int ldz, int64_t M, int C, double* work, double* sums, hipStream_t s);
 hipError_t launch_bn_finalize(const double* sum, const double* sumsq, int64_t M, float eps, float momentum,
@@ -153,7 +159,7 @@ hipError_t launch_pack_dgrad_w(const float* w, float* wp, int Cout, int Cin, int
 hipError_t launch_pack_convt_dgrad_w(const float* w, float* wp, int Cin, int Cout, int Kp, hipStream_t s);
 hipError_t launch_unpack_conv_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cout, int Cin, int Cp, int KS,
                                    int Kp, hipStream_t s);
-hipError_t launch_unpack_convt_grad(const float* dwp, float* g, int Cin, int Cout, int Kp, hipStream_t s);
+hipError_t launch_unpack_convt_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cin, int Cout, int Kp, hipStream_t s);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                        float wd, int step, float grad_scale, hipStream_t s);
 

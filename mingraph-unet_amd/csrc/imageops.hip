@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256) void mask_nearest_kernel(const uint8_t* __rest
 
 // ---- Sobel edge magnitude (edge_detection.py:28-44): RGB2GRAY (14-bit fixed point), 3x3 Sobel with reflect-101 borders in exact
 // integers, sqrt(gx^2 + gy^2) / max * 255 in double, truncated to uint8 -------------------------------------------------------------------
-__device__ __forceinline__ int cv_gray(const uint8_t* p) { return (p[0] * 4899 + p[1] * 9617 + p[2] * 1868 + (1 << 13)) >> 14; }
+// cv2.COLOR_RGB2GRAY on 8-bit data: OpenCV 3.4 / 4.x use 15-bit coefficients (RY15 9798, GY15 19235, BY15 3735, gray_shift 15); only
+// the YUV / YCrCb conversions below keep the 14-bit ones (yuv_shift 14)
+__device__ __forceinline__ int cv_gray(const uint8_t* p) { return (p[0] * 9798 + p[1] * 19235 + p[2] * 3735 + (1 << 14)) >> 15; }
 __device__ __forceinline__ int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 __global__ __launch_bounds__(256) void sobel_mag2_kernel(const uint8_t* __restrict__ rgb, int H, int W, int* __restrict__ mag2,
                                                          unsigned* __restrict__ max2) {

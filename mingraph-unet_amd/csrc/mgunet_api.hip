@@ -678,21 +678,33 @@ int mgu_conv_transpose2x2_nhwc(mgu_ctx* c, const void* in_dev, int B, int H, int
   hipStream_t s = (hipStream_t)hip_stream;
   const int Kp = rup(Cin, 32), N = 4 * Cout, Np = rup(N, 128);
   float *wp, *sc, *sh;
-  // the three-piece kernel (convt_x3.hip) reads 6 bytes per weight in fragment order instead of the 4-byte panel
-  const bool x3 = Cin % 16 == 0 && Cout % 32 == 0 && c->tn.wino_prec != 0;
-  int rc = block_scratch(c, Np, x3 ? rup(Kp * 3 / 2, 32) : Kp, &wp, &sc, &sh, s);
+  // Two packed forms, each in a region of its own: the direct [4 Cout][Cin] panel the tile kernel reads (always built), and -- when
+  // the layer shape is eligible and the context's switches allow it (MGU_NO_CONVT_FRAG, MGU_WINO_PREC) -- the fragment-order
+  // three-piece weights of convt2x2_x3_kernel.  Which kernel runs is decided by the dispatcher (convt_x3_applicable) on the
+  // COMPLETE descriptor; a launch it rejects falls back to the tile kernel, which then finds a real panel in d.w.
+  const bool x3_shape = Cin % 16 == 0 && Cout % 32 == 0 && c->tn.wino_prec != 0 && c->tn.convt_frag;
+  const size_t panel = (size_t)Np * Kp + 2 * (size_t)Np;
+  int rc = ensure(c, &c->gws, &c->gws_bytes, (panel + (x3_shape ? convt_x3_floats(Cin, Cout) : 0)) * sizeof(float));
   if (rc) return rc;
-  if (x3) HIPCHK(c, launch_pack_convt_x3((const float*)w_dev, wp, Cin, Cout, s));
-  else HIPCHK(c, launch_pack_convt_w((const float*)w_dev, wp, 0, Cin, Cout, Kp, s));
+  wp = (float*)c->gws, sc = wp + (size_t)Np * Kp, sh = sc + Np;
+  (void)sc;
+  HIPCHK(c, hipMemsetAsync(c->gws, 0, panel * sizeof(float), s));
+  HIPCHK(c, launch_pack_convt_w((const float*)w_dev, wp, 0, Cin, Cout, Kp, s));
   IgemmDesc d;
   memset(&d, 0, sizeof d);
   d.tn = &c->tn;
-  d.in = (const float*)in_dev, d.w = wp, d.wu = x3 ? wp : nullptr, d.out = (float*)out_dev;
+  d.in = (const float*)in_dev, d.w = wp, d.out = (float*)out_dev;
   d.M = B * H * W, d.H = H, d.W = W, d.Cp = Cin, d.ldin = Cin, d.KS = 1, d.K = Cin, d.Kp = Kp;
   d.N = N, d.ldout = ld_out, d.coff = c_off, d.out_mode = 1, d.ct_cout = Cout, d.Hout = 2 * H, d.Wout = 2 * W;
   if (bias_dev) {
     HIPCHK(c, launch_bias_tile((const float*)bias_dev, sh, Cout, 4, s));
     d.shift = sh;
+  }
+  if (x3_shape) {
+    float* wx = wp + panel;
+    d.wu = wx;
+    if (convt_x3_applicable(d)) HIPCHK(c, launch_pack_convt_x3((const float*)w_dev, wx, Cin, Cout, s));
+    else d.wu = nullptr;
   }
   ProfScope ps(c, s);
   HIPCHK(c, launch_igemm_f32(d, s));
@@ -801,6 +813,7 @@ int mgu_profile_read_kernels(mgu_ctx* c, mgu_kernel_stat* out, int cap, int* n_o
     out[k].ms += ms, out[k].flops_alg += r.alg, out[k].flops_mfma += r.mfma, out[k].launches += 1;
   }
   *n_out = n;
+  c->ev_used = 0;   // a read consumes the records: with profiling left on, the next window starts from an empty table
   return MGU_OK;
 }
 

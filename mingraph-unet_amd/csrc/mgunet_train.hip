@@ -276,7 +276,7 @@ extern "C" {
 static int pending_data_error(mgu_ctx* c) {
   if (c->err_word && *(volatile int*)c->err_word) {
     *(volatile int*)c->err_word = 0;
-    return fail(c, MGU_ERR_INVALID, "a label outside [0, num_classes) (and != ignore_index -100) reached mgu_cross_entropy");
+    return fail(c, MGU_ERR_INVALID, "a label outside [0, num_classes) (and != ignore_index -100) reached a loss kernel of this context (mgu_cross_entropy / mgu_dice_loss)");
   }
   return MGU_OK;
 }
@@ -315,7 +315,7 @@ int mgu_sync_check(mgu_ctx* c, void* hip_stream) {
 // blocks below it are still being differentiated.  Blocks finish in reverse parameter order (final conv, decoder shallow ->
 // deep, bottleneck, encoder deep -> shallow), so the finished part of the flat vector is a suffix that grows downwards;
 // it is flushed whenever >= 4 MB are pending (xGMI collectives are latency-bound below that) and once at the end.
-static int backward_impl(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream, int exchange) {
+static int backward_body(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream, int exchange) {
   if (!c) return MGU_ERR_INVALID;
   if (!c->have_train_fwd) return fail(c, MGU_ERR_STATE, "mgu_unet_backward needs a preceding mgu_unet_forward(training=1)");
   if (!dlogits_dev || !flat_grad_dev) return fail(c, MGU_ERR_INVALID, "NULL buffer");
@@ -397,7 +397,7 @@ static int backward_impl(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_de
       g.M = U.t_B * U.t_H * U.t_W, g.H = U.t_H, g.W = U.t_W, g.Hs = hs[i], g.Ws = ws[i];
       g.N = U.Cin, g.K = Kt, g.Kp = Kpt, g.dw = w.dwp, g.dw_capacity = w.dwp_floats;
       HIPCHK(c, launch_wgrad_f32(g, s));
-      HIPCHK(c, launch_unpack_convt_grad(w.dwp, w.flat + U.off_w, U.Cin, C, Kpt, s));
+      HIPCHK(c, launch_unpack_convt_grad(w.dwp, g.groups, (size_t)g.N * g.Kp, w.flat + U.off_w, U.Cin, C, Kpt, s));
     }
     HIPCHK(c, launch_pack_convt_dgrad_w(U.w_src, w.dgp, U.Cin, C, Kpt, s));
     IgemmDesc q;
@@ -427,6 +427,18 @@ static int backward_impl(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_de
   }
   if (exchange && (rc = comm_join(c, s))) return rc;   // the caller's stream continues after the last bucket
   return MGU_OK;
+}
+
+static int backward_impl(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream, int exchange) {
+  const int rc = backward_body(c, dlogits_dev, flat_grad_dev, hip_stream, exchange);
+  if (rc != MGU_OK && exchange && c && c->comm) {
+    // an error return after some buckets were issued: the caller's stream must still be ordered behind the communicator
+    // stream (the buckets read and write flat_grad_dev), or the caller could free / reuse the buffer under a running collective
+    const std::string keep = c->err;
+    (void)comm_join(c, (hipStream_t)hip_stream);
+    c->err = keep;
+  }
+  return rc;
 }
 
 extern "C" {

@@ -28,7 +28,6 @@ static inline int nblk(int64_t work, int threads, int cap = 256 * 8) {
 //   mode 2: acc0 = sum z (column sums: bias gradients)
 //   mode 3: BN backward apply: dz = gamma*invstd*(g - sum_g/M - xh*sum_gx/M) written to `dz`, acc0 = sum dz
 // ------------------------------------------------------------------------------------------------
-constexpr int RED_SLOTS = 64;
 
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ dy,
@@ -94,7 +93,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
     if (TWO) *reinterpret_cast<f32x4*>(red + (npl + pl) * C + cq * 4) = a1;
   }
   __syncthreads();
-  double* slot = slots + (size_t)(blockIdx.x % RED_SLOTS) * 2 * C;
+  double* slot = slots + (size_t)blockIdx.x * 2 * C;   // a row of this workgroup's own (the launcher keeps the grid <= chan_reduce_rows(C))
   for (int c = t; c < C; c += 256) {
     double s0 = 0.0, s1 = 0.0;
     for (int i = 0; i < npl; ++i) {
@@ -108,15 +107,24 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
 
 // outd[j] = sum over slots (j < n, slot pitch = pitch); optional fp32 copies: outf0[j] for j < n0, outf1[j-n0] beyond
 // The slots it read are cleared again, so the NEXT reduction needs no memset (the workspace is zeroed once, at allocation).
-__global__ void slot_reduce_kernel(double* __restrict__ slots, int n, int pitch, double* __restrict__ outd,
-                                   float* __restrict__ outf0, int n0, float* __restrict__ outf1) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+// block = 32 columns x 8 row lanes: lane r adds rows r, r + 8, ... (coalesced 256-byte reads), the 8 partial sums meet in LDS in
+// a fixed order
+__global__ __launch_bounds__(256) void slot_reduce_kernel(double* __restrict__ slots, int nrows, int n, int pitch, double* __restrict__ outd,
+                                                          float* __restrict__ outf0, int n0, float* __restrict__ outf1) {
+  __shared__ double part[8][32];
+  const int e = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + e;
   double s = 0.0;
-  for (int k = 0; k < RED_SLOTS; ++k) {
-    s += slots[(size_t)k * pitch + j];
-    slots[(size_t)k * pitch + j] = 0.0;
-  }
+  if (j < n)
+    for (int k = rl; k < nrows; k += 8) {
+      s += slots[(size_t)k * pitch + j];
+      slots[(size_t)k * pitch + j] = 0.0;
+    }
+  part[rl][e] = s;
+  __syncthreads();
+  if (rl != 0 || j >= n) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) s += part[k][e];
   if (outd) outd[j] = s;
   if (j < n0) {
     if (outf0) outf0[j] = (float)s;
@@ -125,7 +133,10 @@ __global__ void slot_reduce_kernel(double* __restrict__ slots, int n, int pitch,
   }
 }
 
-size_t chan_reduce_work_bytes(int Cmax) { return (size_t)RED_SLOTS * 2 * Cmax * sizeof(double); }
+size_t chan_reduce_work_bytes(int Cmax) {
+  const size_t a = (size_t)STAT_ROWS * 2 * Cmax, b = (size_t)1 << 19, c = (size_t)64 * 2 * Cmax;
+  return std::max(a, std::max(b, c)) * sizeof(double);
+}
 
 // work: chan_reduce_work_bytes(C) of scratch.  Results: outd[0..n) doubles (n = 2C for modes 0/1, C for 2/3).
 static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const float* dy, int lddy, const float* fsc, const float* fsh,
@@ -134,7 +145,7 @@ static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const fl
                                      float* outf1, hipStream_t s) {
   if ((C & 3) || C < 4 || C > 1024 || (ldz & 3) || M < 1) return hipErrorInvalidValue;
   int64_t blocks = (M + 63) / 64;   // `work` is zero on entry and on exit (slot_reduce_kernel cleans up)
-  if (blocks > 4096) blocks = 4096;
+  if (blocks > chan_reduce_rows(C)) blocks = chan_reduce_rows(C);   // one row of the table per workgroup
   const int rows = (int)((M + blocks - 1) / blocks);
   blocks = (M + rows - 1) / rows;
   const int npl = 256 / (C >> 2);
@@ -147,7 +158,7 @@ static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const fl
   else MGU_CR(3);
 #undef MGU_CR
   const int n = (mode == 0 || mode == 1) ? 2 * C : C;
-  hipLaunchKernelGGL(slot_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, work, n, 2 * C, outd, outf0, n0, outf1);
+  hipLaunchKernelGGL(slot_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, work, (int)blocks, n, 2 * C, outd, outf0, n0, outf1);
   return hipGetLastError();
 }
 
@@ -206,22 +217,30 @@ hipError_t launch_bn_finalize(const double* sum, const double* sumsq, int64_t M,
 }
 
 // ---- finalize straight from the slotted accumulator (statistics accumulated by the conv epilogue) -----------------
-// Folds the 64 slots of channel c (sum at [k][c], sum of squares at [k][C + c]), clears them, and finishes BatchNorm2d
-// exactly as bn_finalize_kernel does: one launch instead of reduction + slot fold + finalize.
-__global__ void bn_finalize_slots_kernel(double* __restrict__ slots, double* __restrict__ sums, double M, float eps, float momentum,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean,
-                                         float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
-                                         float* __restrict__ run_mean, float* __restrict__ run_var, int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C) return;
+// Folds the STAT_ROWS rows of channel c (sum at [k][c], sum of squares at [k][C + c]) in a fixed order, clears them, and
+// finishes BatchNorm2d exactly as bn_finalize_kernel does: one launch instead of reduction + row fold + finalize.
+// Block = 32 channels x 8 row lanes.
+__global__ __launch_bounds__(256) void bn_finalize_slots_kernel(double* __restrict__ slots, double* __restrict__ sums, double M, float eps,
+                                         float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                         float* __restrict__ shift, float* __restrict__ run_mean, float* __restrict__ run_var, int C) {
+  __shared__ double part[2][8][32];
+  const int e = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + e;
   double s0 = 0.0, s1 = 0.0;
-  for (int k = 0; k < RED_SLOTS; ++k) {
-    double* sp = slots + (size_t)k * 2 * C;
-    s0 += sp[i];
-    s1 += sp[C + i];
-    sp[i] = 0.0;
-    sp[C + i] = 0.0;
-  }
+  if (i < C)
+    for (int k = rl; k < STAT_ROWS; k += 8) {
+      double* sp = slots + (size_t)k * 2 * C;
+      s0 += sp[i];
+      s1 += sp[C + i];
+      sp[i] = 0.0;
+      sp[C + i] = 0.0;
+    }
+  part[0][rl][e] = s0, part[1][rl][e] = s1;
+  __syncthreads();
+  if (rl != 0 || i >= C) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) s0 += part[0][k][e], s1 += part[1][k][e];
   if (sums) sums[i] = s0, sums[C + i] = s1;
   const double mu = s0 / M;
   double var = s1 / M - mu * mu;
@@ -242,7 +261,7 @@ __global__ void bn_finalize_slots_kernel(double* __restrict__ slots, double* __r
 hipError_t launch_bn_finalize_slots(double* slots, double* sums, int64_t M, float eps, float momentum, const float* gamma,
                                     const float* beta, float* mean, float* invstd, float* scale, float* shift, float* run_mean,
                                     float* run_var, int C, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_slots_kernel, dim3((C + 63) / 64), dim3(64), 0, s, slots, sums, (double)M, eps, momentum, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_slots_kernel, dim3((C + 31) / 32), dim3(256), 0, s, slots, sums, (double)M, eps, momentum, gamma, beta,
                      mean, invstd, scale, shift, run_mean, run_var, C);
   return hipGetLastError();
 }
@@ -485,18 +504,29 @@ hipError_t launch_unpack_conv_grad(const float* dwp, int groups, size_t panel_st
                      Cp, KS, Kp);
   return hipGetLastError();
 }
-// convT: panel [Cin][Kp], k = q*Cout + co  ->  (Cin, Cout, 2, 2)
-__global__ void unpack_convt_grad_kernel(const float* __restrict__ dwp, float* __restrict__ g, int Cin, int Cout, int Kp) {
-  const int64_t total = (int64_t)Cin * Cout * 4;
+// convT: partial panels [groups][Cin][Kp], k = q*Cout + co  ->  (Cin, Cout, 2, 2), the panels added in a fixed order.
+// Thread -> panel element (ci, k) with k fastest, so the reads of every partial panel are coalesced.
+__global__ void unpack_convt_grad_kernel(const float* __restrict__ dwp, int groups, size_t panel_stride, float* __restrict__ g, int Cin,
+                                         int Cout, int Kp) {
+  const int K = 4 * Cout;
+  const int64_t total = (int64_t)Cin * K;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int q = (int)(i & 3);
-    const int64_t r = i >> 2;
-    const int co = (int)(r % Cout), ci = (int)(r / Cout);
-    g[i] = dwp[(int64_t)ci * Kp + q * Cout + co];
+    const int k = (int)(i % K), ci = (int)(i / K);
+    const float* p = dwp + (int64_t)ci * Kp + k;
+    float s0 = 0.f, s1 = 0.f;
+    int q = 0;
+    for (; q + 1 < groups; q += 2) {
+      s0 += p[(size_t)q * panel_stride];
+      s1 += p[(size_t)(q + 1) * panel_stride];
+    }
+    if (q < groups) s0 += p[(size_t)q * panel_stride];
+    const int tap = k / Cout, co = k - tap * Cout;
+    g[((int64_t)ci * Cout + co) * 4 + tap] = s0 + s1;
   }
 }
-hipError_t launch_unpack_convt_grad(const float* dwp, float* g, int Cin, int Cout, int Kp, hipStream_t s) {
-  hipLaunchKernelGGL(unpack_convt_grad_kernel, dim3(nblk((int64_t)Cin * Cout * 4, 256)), dim3(256), 0, s, dwp, g, Cin, Cout, Kp);
+hipError_t launch_unpack_convt_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cin, int Cout, int Kp, hipStream_t s) {
+  hipLaunchKernelGGL(unpack_convt_grad_kernel, dim3(nblk((int64_t)Cin * Cout * 4, 256)), dim3(256), 0, s, dwp, groups, panel_stride, g, Cin,
+                     Cout, Kp);
   return hipGetLastError();
 }
 

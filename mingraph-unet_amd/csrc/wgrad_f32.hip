@@ -7,9 +7,11 @@
 // PIXEL index m, which is the slow (row) index of both operands in NHWC memory; with the 32x32x2 fp32
 // MFMA a lane supplies ONE float per operand (A[i = lane&31][kk = lane>>5]), so operands are fetched
 // from m-major LDS tiles with conflict-free ds_read_b32 -- no transpose anywhere.
-// The pixel range is split over blockIdx.y; partial tiles are combined with no-return
-// global_atomic_add_f32 (each wave instruction adds two contiguous 128-byte row segments, the
-// full-rate shape in MI355X_MICROARCH.md "Global float atomics").
+// The pixel range is split over blockIdx.y; every split writes a PRIVATE partial panel with plain stores (two contiguous
+// 128-byte row segments per wave instruction) and the unpack kernel adds the panels in a fixed order: float atomics retire at
+// only ~1.3 TB/s chip-wide (MI355X_MICROARCH.md "Global float atomics") and their summation order changed the last bit of a
+// weight gradient from run to run -- with train-mode BatchNorm + MaxPool near-ties downstream, that made two identical train
+// steps diverge (round-2 review); now the whole backward is bitwise reproducible.
 #include "common.h"
 
 namespace mgu {
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradDesc d) {
     __syncthreads();
   }
 
+  float* const dwp = d.dw + (size_t)blockIdx.y * d.N * d.Kp;
 #pragma unroll
   for (int i = 0; i < WNT; ++i)
 #pragma unroll
@@ -151,29 +154,33 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradDesc d) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + (wn * WNT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < d.N && kk < d.K) atomicAdd(d.dw + (size_t)n * d.Kp + kk, acc[i][j][r]);
+        // plain stores into the PRIVATE partial panel of this pixel split (blockIdx.y): no float atomics, so the summed
+        // gradient (unpack_conv*_grad_kernel adds the panels in a fixed order) is bitwise reproducible from run to run
+        if (n < d.N && kk < d.K) dwp[(size_t)n * d.Kp + kk] = acc[i][j][r];
       }
     }
 }
 
 template <int KS, int WAVES_N, int WAVES_K, int WNT, int WKT>
-static hipError_t launch_wg(const WgradDesc& d0, hipStream_t s) {
+static hipError_t launch_wg(WgradDesc& d, hipStream_t s) {
   constexpr int BN = WAVES_N * WNT * 32;
-  WgradDesc d = d0;
   const int ntiles = (d.N + BN - 1) / BN, ktiles = (d.K + WG_BK - 1) / WG_BK;
-  // split the pixel range so the grid has ~4 workgroups per CU, >= 8 steps per split
+  // split the pixel range so the grid has ~4 workgroups per CU, >= 8 steps per split; one partial panel per split
   int splits = (1024 + ntiles * ktiles - 1) / (ntiles * ktiles);
+  const size_t cap = d.dw_capacity / ((size_t)d.N * d.Kp);
+  if ((size_t)splits > cap) splits = (int)cap;
   int rows = (d.M + splits - 1) / splits;
   if (rows < 8 * WG_MK) rows = 8 * WG_MK;
   rows = (rows + WG_MK - 1) / WG_MK * WG_MK;
-  splits = (d.M + rows - 1) / rows;
+  splits = (d.M + rows - 1) / rows;           // every split has >= 1 row and writes every (n < N, k < K) of its panel
   d.rows_per_split = rows;
+  d.groups = splits;
   hipLaunchKernelGGL((wgrad_f32_kernel<KS, WAVES_N, WAVES_K, WNT, WKT>), dim3(ntiles * ktiles, splits), dim3(256), 0, s, d);
   return hipGetLastError();
 }
 
 template <int KS>
-static hipError_t launch_wg_tiles(const WgradDesc& d, hipStream_t s) {
+static hipError_t launch_wg_tiles(WgradDesc& d, hipStream_t s) {
   if (d.N > 64) return launch_wg<KS, 2, 2, 2, 2>(d, s);   // 128 (n) x 128 (k), wave 64x64
   if (d.N > 32) return launch_wg<KS, 2, 2, 1, 2>(d, s);   // 64 x 128, wave 32x64
   return launch_wg<KS, 1, 4, 1, 1>(d, s);                 // 32 x 128, wave 32x32
@@ -348,7 +355,7 @@ static hipError_t launch_wg_halo(WgradDesc& d, hipStream_t s) {
 
 
 hipError_t launch_wgrad_f32(WgradDesc& d, hipStream_t s) {
-  d.groups = 1;   // atomic paths accumulate into ONE panel, which the caller must have zeroed
+  d.groups = 1;   // every path sets the number of partial panels it wrote (the caller sums them: unpack_conv*_grad_kernel)
   if (d.M <= 0 || d.N <= 0 || d.K <= 0) return hipSuccess;
   if ((d.N & 3) || (d.ldz & 3) || (d.zoff & 3) || (d.Cp & 3) || (d.ldin & 3) || (d.inoff & 3) || d.K > d.Kp)
     return hipErrorInvalidValue;
@@ -361,8 +368,6 @@ hipError_t launch_wgrad_f32(WgradDesc& d, hipStream_t s) {
     return launch_wg_halo<1>(d, s);
   }
   if (d.dw_capacity < (size_t)d.N * d.Kp) return hipErrorInvalidValue;
-  hipError_t e = hipMemsetAsync(d.dw, 0, (size_t)d.N * d.Kp * sizeof(float), s);   // the tile kernels accumulate with atomics
-  if (e != hipSuccess) return e;
   if (d.KS == 3) return launch_wg_tiles<3>(d, s);
   if (d.KS == 2) return launch_wg_tiles<2>(d, s);
   if (d.KS == 1) return launch_wg_tiles<1>(d, s);

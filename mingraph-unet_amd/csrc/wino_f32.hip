@@ -629,7 +629,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
   }
   if (d.stat_slots) {
     // fold the per-thread sums of a channel quad (512 / QPT threads each) through LDS, then one double atomic per channel
-    // and sum into slot (workgroup % 64) of the slotted accumulator [64][2 * N] that bn_finalize_slots_kernel folds
+    // and sum into row (workgroup) of the accumulator table [STAT_ROWS][2 * N] that bn_finalize_slots_kernel folds
     float* red = smem;   // [512][8]
     lds_barrier();
     *reinterpret_cast<f32x4*>(red + tid * 8) = st1;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(512) void wino3x3_f32_kernel(const IgemmDesc d, con
       double sum = 0.0;
       for (int k = qd; k < 512; k += QPT) sum += (double)red[k * 8 + which * 4 + e];
       const int n = nblock * NC + qd * 4 + e;
-      if (n < d.N) atomicAdd(d.stat_slots + (size_t)(blockIdx.x & 63) * 2 * d.N + which * d.N + n, sum);
+      if (n < d.N) atomicAdd(d.stat_slots + (size_t)(blockIdx.x % STAT_ROWS) * 2 * d.N + which * d.N + n, sum);
     }
   }
 }
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
   }
   if (STATS) {
     // fold the per-thread sums of a channel quad (64 threads each) through LDS, then one double atomic per channel and sum into
-    // slot (workgroup % 64) of the slotted accumulator [64][2 * N] that bn_finalize_slots_kernel folds
+    // row (workgroup) of the accumulator table [STAT_ROWS][2 * N] that bn_finalize_slots_kernel folds (one adder per element)
     float* red = smem;   // [NTB][512][8]
     lds_barrier();
 #pragma unroll
@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
       double sum = 0.0;
       for (int k = qd; k < 512; k += 8) sum += (double)red[(nt * 512 + k) * 8 + which * 4 + e];
       const int n = nblock * NC + nt * 32 + qd * 4 + e;
-      if (n < d.N) atomicAdd(d.stat_slots + (size_t)(blockIdx.x & 63) * 2 * d.N + which * d.N + n, sum);
+      if (n < d.N) atomicAdd(d.stat_slots + (size_t)(blockIdx.x % STAT_ROWS) * 2 * d.N + which * d.N + n, sum);
     }
   }
 }
@@ -1158,6 +1158,7 @@ static hipError_t launch_wino_cp(const IgemmDesc& d, hipStream_t s) {
   const int ngroups = (total + ppb - 1) / ppb;
   const int per_xcd = (ngroups * nblk + 7) / 8;
   dim3 grid(8 * per_xcd, 1);
+  if (d.stat_slots && grid.x > (unsigned)STAT_ROWS) return hipErrorInvalidValue;   // one accumulator row per workgroup (common.h)
   const size_t lds = (size_t)(5 * WINO_CP_RAWF) * sizeof(float);   // two raw buffers + three exchange regions = the CU's 160 KB
   static bool attr_done[64] = {};
   hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&wino3x3_cp_kernel<NTB, STATS, DEEP>), lds, attr_done);
@@ -1182,6 +1183,7 @@ static hipError_t launch_wino_mode(const IgemmDesc& d, hipStream_t s) {
   const int ngroups = (total + ppb - 1) / ppb;
   const int per_xcd = (ngroups * nblk + 7) / 8;
   dim3 grid(8 * per_xcd, 1);
+  if (d.stat_slots && grid.x > (unsigned)STAT_ROWS) return hipErrorInvalidValue;   // one accumulator row per workgroup (common.h)
   constexpr int HSTRIDE = NWAVES * 16, HR = (340 + HSTRIDE - 1) / HSTRIDE;
   constexpr int RAWF = HR * HSTRIDE / 34 * 34 * 20 + 34 * 20;   // must match the kernel
   const size_t lds = (size_t)(2 * RAWF + 4 * 64 * (32 * NTB + 8)) * sizeof(float);

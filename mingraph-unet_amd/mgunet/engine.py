@@ -213,14 +213,14 @@ class Trainer:
 
     def __init__(self, model: UNet, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None, comm="auto",
                  loss="ce", dice_smooth=1.0):
-        """loss: "ce" -- nn.CrossEntropyLoss() alone (train_segmentation.py:91,127); "ce+dice" -- the sum the script forms at
+        """comm: "auto" (default) -- with more than one rank the gradient is mean-all-reduced by torch.distributed (RCCL when the
+        backend is "nccl") after backward: the path exercised with two ranks.  "rccl" -- opt in to libmgunet's own RCCL
+        communicator with the bucketed exchange overlapped with backward (mgu_unet_backward_allreduce); tests/test_gpu_rccl.py
+        runs it with two ranks on a box that has two GPUs and with one rank elsewhere.  None -- no exchange.
+        loss: "ce" -- nn.CrossEntropyLoss() alone (train_segmentation.py:91,127); "ce+dice" -- the sum the script forms at
         :126-130, `criterion_ce(logits, masks) + dice_loss(logits, masks)`: the Dice gradient (through the softmax) is added to
         the cross-entropy gradient in the same dlogits buffer (mgu_dice_loss_backward, accumulate) before the one backward pass.
-        comm: "auto" -- when torch.distributed runs the "nccl" backend with more than one rank, the gradient exchange is
-        libmgunet's own RCCL communicator (mgu_comm_init_rank; torch.distributed only carries the 128-byte id) and is
-        overlapped with backward (mgu_unet_backward_allreduce); a gloo group (CPU rehearsal of the plumbing) falls back to
-        torch.distributed.all_reduce on a host copy.  "rccl": always create the communicator, also for a single process
-        (world size 1: the collective degenerates to a copy, which is what the 1-GPU test exercises).  None: no exchange."""
+        ("rccl" also creates the communicator for a single process: the collective then degenerates to a copy.)"""
         params = list(model.named_parameters())
         if not params or not params[0][1].is_cuda:
             raise RuntimeError("move the model to a HIP device before building a Trainer (no CPU fallback)")
@@ -255,7 +255,10 @@ class Trainer:
         self._loss = torch.zeros(1, device=dev, dtype=torch.float32)
         self._dice = torch.zeros(1, device=dev, dtype=torch.float32)
         self._rccl = False
-        if comm == "rccl" or (comm == "auto" and self._dist_backend() == "nccl" and self._dist_world() > 1):
+        if comm not in ("auto", "rccl", None):
+            raise ValueError(f"unknown comm {comm!r}: 'auto', 'rccl' or None")
+        self.comm = comm
+        if comm == "rccl":
             self.attach_rccl()
 
     def _dist_world(self) -> int:
@@ -277,7 +280,8 @@ class Trainer:
             _lib.check(L.mgu_comm_get_unique_id(buf), None)
         if world > 1:
             box = [bytes(buf.raw)]
-            dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            with torch.cuda.device(self.device):   # an NCCL group moves the pickled object through the CURRENT device
+                dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
             buf = C.create_string_buffer(box[0], 128)
         with torch.cuda.device(self.device):
             _lib.check(L.mgu_comm_init_rank(ctx.handle, buf, rank, world), ctx.handle)
@@ -393,6 +397,6 @@ class Trainer:
             self.optimizer_step(1.0)
             return loss
         loss = self.forward_backward(images, masks)
-        scale = allreduce_mean_(self.grad, self.group)   # gloo rehearsal / single process
+        scale = allreduce_mean_(self.grad, self.group) if self.comm is not None else 1.0   # torch.distributed (RCCL / gloo); 1 rank: no-op
         self.optimizer_step(scale)
         return loss

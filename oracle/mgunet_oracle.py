@@ -652,7 +652,7 @@ def preprocess_mask(mask_u8: np.ndarray, resize_dim, num_classes: int) -> torch.
 
 def _cv_gray(rgb: np.ndarray) -> np.ndarray:
     r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
-    return (r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14          # cv2.COLOR_RGB2GRAY, 14-bit fixed point
+    return (r * 9798 + g * 19235 + b * 3735 + (1 << 14)) >> 15         # cv2.COLOR_RGB2GRAY on uint8: 15-bit fixed point (OpenCV 3.4 / 4.x RY15, GY15, BY15, gray_shift)
 
 
 def sobel_edges(rgb_u8: np.ndarray) -> np.ndarray:

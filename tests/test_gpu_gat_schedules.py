@@ -114,3 +114,27 @@ def test_device_coo_to_csr_matches_host_routine_bit_exact(cuda, N, E):
         bad[1, E // 2] = -1
         with pytest.raises(IndexError):
             coo_to_csr_device(torch.from_numpy(bad).to(cuda), N)
+
+
+@pytest.mark.parametrize("tag,H,W,p", [("g128", 128, 128, 32), ("g130", 130, 140, 32), ("g512", 512, 512, 16), ("g1024", 1024, 1024, 16)])
+def test_patch_graph_index_maps_bit_exact_vs_reference_fixtures(cuda, golden, tag, H, W, p):
+    """The index maps the GPU path really consumes, against the COO fixtures the reference's own PatchGraphConstructor produced
+    (tests/golden/patch_graph.npz; preprocessing/graph_construction/patch_graph_construction.py:49-102): mgu_patch_graph_build's
+    COO as handed to the device, the device-side stable COO -> CSR of it, and the block-diagonal batched CSR the forward uses --
+    all bit-exact (the CPU tier checks the host builder; this one runs on the GPU box)."""
+    ref = golden["patch_graph"][tag]
+    pgc = mgunet.PatchGraphConstructor(p)
+    nph, npw = O.patch_grid(H, W, p)
+    N = nph * npw
+    _, ei = pgc.construct_patch_graph(torch.zeros(1, H, W), torch.zeros(N, 4, device=cuda))
+    assert ei.is_cuda and ei.dtype == torch.int64 and np.array_equal(ei.cpu().numpy(), ref)
+    rowptr, col = coo_to_csr_device(ei, N)
+    orp, ocol, _ = O.coo_to_csr(ref, N)
+    assert np.array_equal(rowptr.cpu().numpy(), orp) and np.array_equal(col.cpu().numpy(), ocol)
+    B = 3
+    brp, bcol, gp, n1, e1 = pgc.batched_csr(H, W, B, cuda)
+    assert (n1, e1) == (N, ref.shape[1]) and gp.cpu().tolist() == [0, N, 2 * N, 3 * N]
+    big = np.concatenate([ref + N * b for b in range(B)], axis=1)
+    orp, ocol, _ = O.coo_to_csr(big, B * N)
+    assert np.array_equal(brp.cpu().numpy(), orp) and np.array_equal(bcol.cpu().numpy(), ocol)
+    assert np.array_equal(pgc.edge_index(H, W, cuda, B).cpu().numpy(), big)
