@@ -37,6 +37,9 @@ struct Tuning {
   bool wgrad_thin = true;   // MGU_NO_THIN_WGRAD=1
   bool wino_dgrad = true;   // MGU_NO_WINO_DGRAD=1
   bool gat_fused = true;    // MGU_NO_GAT_FUSED=1
+  bool wino_ures = true;    // MGU_NO_WINO_URES=1: the 32-input-channel narrow layers reload their weight pieces every chunk (A/B)
+  bool wino_prio = false;   // MGU_WINO_PRIO=1: s_setprio 1 for waves 4-7 of the component-pair Winograd kernels (A/B)
+  bool wino_head = true;    // MGU_NO_WINO_HEAD=1: the 1x1 head / patch means as kernels of their own instead of in the last conv's epilogue (A/B)
 };
 const Tuning& default_tuning();
 // The >64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: set it once per (kernel, device).
@@ -70,6 +73,16 @@ struct IgemmDesc {
   // optional (Winograd kernel, training forward): per-channel sum / sum of squares of the stored output accumulated into the
   // row-per-workgroup double accumulator [STAT_ROWS][2 * N] (train_kernels.hip), folded by launch_bn_finalize_slots
   double* stat_slots;
+  // optional fused consumers of a 32-output-channel Winograd layer (the last decoder conv, unet_decoder.py:141-143): the final 1x1
+  // conv on the output still in registers -> head_out (M, head_ncls) fp32, and -- pm_out != nullptr, H and W multiples of 16 --
+  // the 16 x 16 patch means pm_out (B * pm_nph * pm_npw, 32) (a workgroup walks the two 8-row patches of a band back to back
+  // and stores their sum: no atomics, nothing to clear).  The 32-channel feature is stored as always but never read back.
+  const float* head_w;   // (head_ncls, 32), the reference's final_conv.weight
+  const float* head_b;
+  float* head_out;
+  int head_ncls;         // 1..4
+  float* pm_out;
+  int pm_nph, pm_npw;
   // optional split epilogue (out_mode 0): columns n >= split_n go to out2[m*ld2 + (n - split_n)] (0 = off)
   int split_n;
   float* out2;
@@ -78,6 +91,8 @@ struct IgemmDesc {
 
 inline const Tuning& tun(const IgemmDesc& d) { return d.tn ? *d.tn : default_tuning(); }
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
+int wino_grid_blocks(const IgemmDesc& d);   // wino_f32.hip: workgroups of the Winograd launch for d (= accumulator rows of its statistics)
+bool wino_head_fusable(const IgemmDesc& d, int ncls);
 bool halo_pool_fusable(const IgemmDesc& d, int dtype);   // the halo conv kernel will run: MaxPool2d(2) can ride in its epilogue
 hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s);
 const char* igemm_kernel_name(const IgemmDesc& d, int dtype);
@@ -132,13 +147,13 @@ hipError_t launch_wgrad_thin(WgradDesc& d, hipStream_t s);
 // the last bit of a BatchNorm statistic about once in a thousand steps).  STAT_ROWS bounds the grid of the Winograd kernels
 // that accumulate statistics in their epilogue (one round of <= 2 x 256 workgroups + rounding).
 constexpr int STAT_ROWS = 576;
-inline int chan_reduce_rows(int C) { int r = (1 << 19) / (2 * C); return r < 64 ? 64 : (r > 4096 ? 4096 : r); }
+constexpr int CHAN_REDUCE_ROWS = 512;   // workgroups (= table rows) of a per-channel reduction: 2 per CU, each streaming with 4 loads in flight per thread
 size_t chan_reduce_work_bytes(int Cmax);
 hipError_t launch_bn_stats(const float* z, int ldz, int64_t M, int C, double* work, double* sums, hipStream_t s);
 hipError_t launch_bn_finalize(const double* sum, const double* sumsq, int64_t M, float eps, float momentum,
                               const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
                               float* shift, float* run_mean, float* run_var, int C, hipStream_t s);
-hipError_t launch_bn_finalize_slots(double* slots, double* sums, int64_t M, float eps, float momentum, const float* gamma,
+hipError_t launch_bn_finalize_slots(double* slots, int nrows, double* sums, int64_t M, float eps, float momentum, const float* gamma,
                                     const float* beta, float* mean, float* invstd, float* scale, float* shift, float* run_mean,
                                     float* run_var, int C, hipStream_t s);
 hipError_t launch_bn_apply_relu(const float* z, const float* scale, const float* shift, float* y, int ldy, int64_t M, int C,

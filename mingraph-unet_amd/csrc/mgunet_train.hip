@@ -93,7 +93,7 @@ int conv_bn_relu_train(mgu_ctx* c, Layer& L, const float* in, int ldin, int B, i
   int rc = run_layer(c, L, in, ldin, B, H, W, z, C, 0, 0, nullptr, L.b_src, 0, 0, s, nullptr, 0, nullptr, red, &stats_done);  // unet_encoder.py:16 / :20
   if (rc) return rc;
   if (stats_done) {
-    HIPCHK(c, launch_bn_finalize_slots(red, sums, M, 1e-5f, 0.1f, L.gamma, L.beta, L.mean, L.invstd, L.tscale, L.tshift, L.run_mean,
+    HIPCHK(c, launch_bn_finalize_slots(red, c->last_stat_rows, sums, M, 1e-5f, 0.1f, L.gamma, L.beta, L.mean, L.invstd, L.tscale, L.tshift, L.run_mean,
                                        L.run_var, C, s));  // nn.BatchNorm2d defaults, unet_encoder.py:12-13
   } else {
     HIPCHK(c, launch_bn_stats(z, C, M, C, red, sums, s));

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
         k2[j] = (float)sums[C + cq * 4 + j] * invM;    // sum_gx / M
       }
     }
+#pragma unroll 4   // few, long workgroups (one table row each): several loads of a thread in flight keep the stream at HBM speed
     for (int64_t r = r_begin + pl; r < r_end; r += npl) {
       const f32x4 zv = *reinterpret_cast<const f32x4*>(z + r * ldz + cq * 4);
       if (MODE == 0) {
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
     if (TWO) *reinterpret_cast<f32x4*>(red + (npl + pl) * C + cq * 4) = a1;
   }
   __syncthreads();
-  double* slot = slots + (size_t)blockIdx.x * 2 * C;   // a row of this workgroup's own (the launcher keeps the grid <= chan_reduce_rows(C))
+  double* slot = slots + (size_t)blockIdx.x * 2 * C;   // a row of this workgroup's own (the launcher keeps the grid <= CHAN_REDUCE_ROWS)
   for (int c = t; c < C; c += 256) {
     double s0 = 0.0, s1 = 0.0;
     for (int i = 0; i < npl; ++i) {
@@ -107,24 +108,39 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const float* __restric
 
 // outd[j] = sum over slots (j < n, slot pitch = pitch); optional fp32 copies: outf0[j] for j < n0, outf1[j-n0] beyond
 // The slots it read are cleared again, so the NEXT reduction needs no memset (the workspace is zeroed once, at allocation).
-// block = 32 columns x 8 row lanes: lane r adds rows r, r + 8, ... (coalesced 256-byte reads), the 8 partial sums meet in LDS in
-// a fixed order
-__global__ __launch_bounds__(256) void slot_reduce_kernel(double* __restrict__ slots, int nrows, int n, int pitch, double* __restrict__ outd,
-                                                          float* __restrict__ outf0, int n0, float* __restrict__ outf1) {
-  __shared__ double part[8][32];
+// block = 32 columns x 32 row lanes: lane r adds rows r, r + 32, ... (coalesced 256-byte reads; the loads of a lane are all issued
+// before the rows are cleared, so they overlap), the 32 partial sums meet in LDS in a fixed order
+template <int NIT>
+__device__ __forceinline__ double fold_rows(double* __restrict__ col, int nrows, int rl, size_t pitch) {
+  double v[NIT];
+#pragma unroll
+  for (int u = 0; u < NIT; ++u) {
+    const int k = rl + 32 * u;
+    v[u] = k < nrows ? col[(size_t)k * pitch] : 0.0;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int u = 0; u < NIT; ++u) s += v[u];
+#pragma unroll
+  for (int u = 0; u < NIT; ++u) {
+    const int k = rl + 32 * u;
+    if (k < nrows) col[(size_t)k * pitch] = 0.0;
+  }
+  return s;
+}
+constexpr int FOLD_NIT = (STAT_ROWS > CHAN_REDUCE_ROWS ? STAT_ROWS : CHAN_REDUCE_ROWS) / 32;   // rows <= 32 * FOLD_NIT
+
+__global__ __launch_bounds__(1024) void slot_reduce_kernel(double* __restrict__ slots, int nrows, int n, int pitch, double* __restrict__ outd,
+                                                           float* __restrict__ outf0, int n0, float* __restrict__ outf1) {
+  __shared__ double part[32][33];
   const int e = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int j = blockIdx.x * 32 + e;
-  double s = 0.0;
-  if (j < n)
-    for (int k = rl; k < nrows; k += 8) {
-      s += slots[(size_t)k * pitch + j];
-      slots[(size_t)k * pitch + j] = 0.0;
-    }
+  double s = j < n ? fold_rows<FOLD_NIT>(slots + j, nrows, rl, (size_t)pitch) : 0.0;
   part[rl][e] = s;
   __syncthreads();
   if (rl != 0 || j >= n) return;
 #pragma unroll
-  for (int k = 1; k < 8; ++k) s += part[k][e];
+  for (int k = 1; k < 32; ++k) s += part[k][e];
   if (outd) outd[j] = s;
   if (j < n0) {
     if (outf0) outf0[j] = (float)s;
@@ -134,8 +150,7 @@ __global__ __launch_bounds__(256) void slot_reduce_kernel(double* __restrict__ s
 }
 
 size_t chan_reduce_work_bytes(int Cmax) {
-  const size_t a = (size_t)STAT_ROWS * 2 * Cmax, b = (size_t)1 << 19, c = (size_t)64 * 2 * Cmax;
-  return std::max(a, std::max(b, c)) * sizeof(double);
+  return (size_t)std::max(STAT_ROWS, CHAN_REDUCE_ROWS) * 2 * Cmax * sizeof(double);
 }
 
 // work: chan_reduce_work_bytes(C) of scratch.  Results: outd[0..n) doubles (n = 2C for modes 0/1, C for 2/3).
@@ -145,7 +160,7 @@ static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const fl
                                      float* outf1, hipStream_t s) {
   if ((C & 3) || C < 4 || C > 1024 || (ldz & 3) || M < 1) return hipErrorInvalidValue;
   int64_t blocks = (M + 63) / 64;   // `work` is zero on entry and on exit (slot_reduce_kernel cleans up)
-  if (blocks > chan_reduce_rows(C)) blocks = chan_reduce_rows(C);   // one row of the table per workgroup
+  if (blocks > CHAN_REDUCE_ROWS) blocks = CHAN_REDUCE_ROWS;   // one row of the table per workgroup
   const int rows = (int)((M + blocks - 1) / blocks);
   blocks = (M + rows - 1) / rows;
   const int npl = 256 / (C >> 2);
@@ -158,7 +173,7 @@ static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const fl
   else MGU_CR(3);
 #undef MGU_CR
   const int n = (mode == 0 || mode == 1) ? 2 * C : C;
-  hipLaunchKernelGGL(slot_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, work, (int)blocks, n, 2 * C, outd, outf0, n0, outf1);
+  hipLaunchKernelGGL(slot_reduce_kernel, dim3((n + 31) / 32), dim3(1024), 0, s, work, (int)blocks, n, 2 * C, outd, outf0, n0, outf1);
   return hipGetLastError();
 }
 
@@ -217,30 +232,26 @@ hipError_t launch_bn_finalize(const double* sum, const double* sumsq, int64_t M,
 }
 
 // ---- finalize straight from the slotted accumulator (statistics accumulated by the conv epilogue) -----------------
-// Folds the STAT_ROWS rows of channel c (sum at [k][c], sum of squares at [k][C + c]) in a fixed order, clears them, and
-// finishes BatchNorm2d exactly as bn_finalize_kernel does: one launch instead of reduction + row fold + finalize.
-// Block = 32 channels x 8 row lanes.
-__global__ __launch_bounds__(256) void bn_finalize_slots_kernel(double* __restrict__ slots, double* __restrict__ sums, double M, float eps,
-                                         float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
+// Folds the nrows (= workgroups of the producing launch) rows of channel c (sum at [k][c], sum of squares at [k][C + c]) in a
+// fixed order, clears them, and finishes BatchNorm2d exactly as bn_finalize_kernel does: one launch instead of reduction + row
+// fold + finalize.  Block = 32 channels x 32 row lanes.
+__global__ __launch_bounds__(1024) void bn_finalize_slots_kernel(double* __restrict__ slots, int nrows, double* __restrict__ sums, double M,
+                                         float eps, float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
                                          float* __restrict__ shift, float* __restrict__ run_mean, float* __restrict__ run_var, int C) {
-  __shared__ double part[2][8][32];
+  __shared__ double part[2][32][33];
   const int e = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + e;
   double s0 = 0.0, s1 = 0.0;
-  if (i < C)
-    for (int k = rl; k < STAT_ROWS; k += 8) {
-      double* sp = slots + (size_t)k * 2 * C;
-      s0 += sp[i];
-      s1 += sp[C + i];
-      sp[i] = 0.0;
-      sp[C + i] = 0.0;
-    }
+  if (i < C) {
+    s0 = fold_rows<FOLD_NIT>(slots + i, nrows, rl, (size_t)2 * C);
+    s1 = fold_rows<FOLD_NIT>(slots + C + i, nrows, rl, (size_t)2 * C);
+  }
   part[0][rl][e] = s0, part[1][rl][e] = s1;
   __syncthreads();
   if (rl != 0 || i >= C) return;
 #pragma unroll
-  for (int k = 1; k < 8; ++k) s0 += part[0][k][e], s1 += part[1][k][e];
+  for (int k = 1; k < 32; ++k) s0 += part[0][k][e], s1 += part[1][k][e];
   if (sums) sums[i] = s0, sums[C + i] = s1;
   const double mu = s0 / M;
   double var = s1 / M - mu * mu;
@@ -258,10 +269,11 @@ __global__ __launch_bounds__(256) void bn_finalize_slots_kernel(double* __restri
   }
 }
 
-hipError_t launch_bn_finalize_slots(double* slots, double* sums, int64_t M, float eps, float momentum, const float* gamma,
+hipError_t launch_bn_finalize_slots(double* slots, int nrows, double* sums, int64_t M, float eps, float momentum, const float* gamma,
                                     const float* beta, float* mean, float* invstd, float* scale, float* shift, float* run_mean,
                                     float* run_var, int C, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_slots_kernel, dim3((C + 31) / 32), dim3(256), 0, s, slots, sums, (double)M, eps, momentum, gamma, beta,
+  if (nrows < 1 || nrows > STAT_ROWS) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_finalize_slots_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, slots, nrows, sums, (double)M, eps, momentum, gamma, beta,
                      mean, invstd, scale, shift, run_mean, run_var, C);
   return hipGetLastError();
 }
