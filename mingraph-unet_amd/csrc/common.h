@@ -39,7 +39,6 @@ struct Tuning {
   bool gat_fused = true;    // MGU_NO_GAT_FUSED=1
   bool wino_ures = true;    // MGU_NO_WINO_URES=1: the 32-input-channel narrow layers reload their weight pieces every chunk (A/B)
   bool wino_prio = false;   // MGU_WINO_PRIO=1: s_setprio 1 for waves 4-7 of the component-pair Winograd kernels (A/B)
-  bool wino_head = true;    // MGU_NO_WINO_HEAD=1: the 1x1 head / patch means as kernels of their own instead of in the last conv's epilogue (A/B)
 };
 const Tuning& default_tuning();
 // The >64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: set it once per (kernel, device).
@@ -73,16 +72,6 @@ struct IgemmDesc {
   // optional (Winograd kernel, training forward): per-channel sum / sum of squares of the stored output accumulated into the
   // row-per-workgroup double accumulator [STAT_ROWS][2 * N] (train_kernels.hip), folded by launch_bn_finalize_slots
   double* stat_slots;
-  // optional fused consumers of a 32-output-channel Winograd layer (the last decoder conv, unet_decoder.py:141-143): the final 1x1
-  // conv on the output still in registers -> head_out (M, head_ncls) fp32, and -- pm_out != nullptr, H and W multiples of 16 --
-  // the 16 x 16 patch means pm_out (B * pm_nph * pm_npw, 32) (a workgroup walks the two 8-row patches of a band back to back
-  // and stores their sum: no atomics, nothing to clear).  The 32-channel feature is stored as always but never read back.
-  const float* head_w;   // (head_ncls, 32), the reference's final_conv.weight
-  const float* head_b;
-  float* head_out;
-  int head_ncls;         // 1..4
-  float* pm_out;
-  int pm_nph, pm_npw;
   // optional split epilogue (out_mode 0): columns n >= split_n go to out2[m*ld2 + (n - split_n)] (0 = off)
   int split_n;
   float* out2;
@@ -92,7 +81,6 @@ struct IgemmDesc {
 inline const Tuning& tun(const IgemmDesc& d) { return d.tn ? *d.tn : default_tuning(); }
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s);
 int wino_grid_blocks(const IgemmDesc& d);   // wino_f32.hip: workgroups of the Winograd launch for d (= accumulator rows of its statistics)
-bool wino_head_fusable(const IgemmDesc& d, int ncls);
 bool halo_pool_fusable(const IgemmDesc& d, int dtype);   // the halo conv kernel will run: MaxPool2d(2) can ride in its epilogue
 hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s);
 const char* igemm_kernel_name(const IgemmDesc& d, int dtype);

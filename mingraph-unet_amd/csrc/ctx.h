@@ -172,22 +172,11 @@ inline void level_dims(int H, int W, int depth, std::vector<int>& hs, std::vecto
   }
 }
 
-// consumers of the last decoder conv's output that may ride in its epilogue (wino_head_fusable): the final 1x1 conv and, when
-// pm_out != nullptr (patch 16, H and W multiples of 16), the patch means of the feature it stores
-struct HeadFuse {
-  const float *w, *b;   // final_conv.weight (ncls, 32), .bias
-  float* logits;
-  int ncls;
-  float* pm_out;
-  int nph, npw;
-};
-
 // one fused conv / convT / 1x1 launch described by a Layer (scale/shift chosen by the caller)
 int run_layer(mgu_ctx* c, const Layer& L, const void* in, int ldin, int B, int H, int W, void* out, int ldout, int coff,
               int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s,
               void* pool = nullptr, int ldpool = 0, bool* pool_fused = nullptr,   // optional fused MaxPool2d(2) output
-              double* stat_slots = nullptr, bool* stat_fused = nullptr,           // optional fused BatchNorm batch statistics
-              const HeadFuse* head = nullptr, bool* head_fused = nullptr);        // optional fused 1x1 head (+ 16x16 patch means)
+              double* stat_slots = nullptr, bool* stat_fused = nullptr);          // optional fused BatchNorm batch statistics
 
 void gat_destroy(mgu_ctx* c);   // gat_api.hip
 

@@ -83,7 +83,6 @@ int mgu_create(int device_id, mgu_ctx** out) {
   t.wgrad_thin = !flag("MGU_NO_THIN_WGRAD");
   t.wino_dgrad = !flag("MGU_NO_WINO_DGRAD");
   t.gat_fused = !flag("MGU_NO_GAT_FUSED");
-  t.wino_head = !flag("MGU_NO_WINO_HEAD");
   t.wino_ures = !flag("MGU_NO_WINO_URES");
   t.wino_prio = flag("MGU_WINO_PRIO");
   *out = c;
@@ -344,8 +343,7 @@ int mgu_unet_reserve(mgu_ctx* c, int B, int H, int W, int training) {
 
 int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int B, int H, int W, void* out_v, int ldout,
                     int coff, int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s,
-                    void* pool, int ldpool, bool* pool_fused, double* stat_slots, bool* stat_fused, const HeadFuse* head,
-                    bool* head_fused) {
+                    void* pool, int ldpool, bool* pool_fused, double* stat_slots, bool* stat_fused) {
   IgemmDesc d;
   memset(&d, 0, sizeof d);
   d.tn = &c->tn;
@@ -373,7 +371,6 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
   d.Wout = Wout;
   if (pool_fused) *pool_fused = false;
   if (stat_fused) *stat_fused = false;
-  if (head_fused) *head_fused = false;
   if (L.wf && ldin == L.Cp && first_conv_applicable(c->dtype, L.Cin, L.Cp, L.Cout, ldout, coff) &&
       (int64_t)B * H * W * std::max(ldout, 8) < (1ll << 31)) {
     ProfScope ps(c, s, "conv3x3_first_kernel", 2.0 * d.M * 9.0 * L.Cin * L.Cout, 0, -1);
@@ -389,14 +386,6 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
     // the Winograd / halo epilogue also writes the 2x2 max-pooled tensor
     d.pool = (float*)pool, d.ldpool = ldpool;
     if (pool_fused) *pool_fused = true;
-  }
-  if (head && c->dtype == MGU_DTYPE_F32 && !pool && !stat_slots && wino_head_fusable(d, head->ncls)) {
-    // the final 1x1 conv (and the requested patch means) ride in this layer's epilogue: the feature is stored, never re-read
-    d.head_w = head->w, d.head_b = head->b, d.head_out = head->logits, d.head_ncls = head->ncls;
-    if (head->pm_out) {
-      d.pm_out = head->pm_out, d.pm_nph = head->nph, d.pm_npw = head->npw;
-    }
-    if (head_fused) *head_fused = true;
   }
   if (L.wp_dirty && !(c->dtype == MGU_DTYPE_F32 && wino_applicable(d))) {   // falling back to the direct kernel: build its panel now
     HIPCHK(c, launch_pack_conv_w(L.w_src, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
@@ -420,9 +409,9 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
 
 static int run_conv(mgu_ctx* c, const Layer& L, const void* in, int ldin, int B, int H, int W, void* out, int ldout,
                     int coff, int relu, int Hout, int Wout, hipStream_t s, void* pool = nullptr, int ldpool = 0,
-                    bool* pool_fused = nullptr, const HeadFuse* head = nullptr, bool* head_fused = nullptr) {  // eval: folded BN scale/shift
+                    bool* pool_fused = nullptr) {  // eval: folded BN scale/shift
   return run_layer(c, L, in, ldin, B, H, W, out, ldout, coff, relu, L.bn.empty() ? nullptr : L.scale, L.shift, Hout, Wout, s,
-                   pool, ldpool, pool_fused, nullptr, nullptr, head, head_fused);
+                   pool, ldpool, pool_fused, nullptr, nullptr);
 }
 
 extern "C" {
@@ -500,7 +489,6 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
     cur = bott;
     cur_ld = C;
   }
-  bool head_done = false;
   for (int b = 0; b < depth; ++b) {  // decoder, unet_decoder.py:139-141
     const int i = depth - 1 - b;
     const int C = c->feat << i;
@@ -508,26 +496,12 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
     if ((rc = run_conv(c, c->layers[li++], cur, cur_ld, B, hs[i + 1], wsz[i + 1], cat_dev[i], 2 * C, C, 0, hs[i], wsz[i], s)))
       return rc;
     if ((rc = run_conv(c, c->layers[li++], cat_dev[i], 2 * C, B, hs[i], wsz[i], tmp, C, 0, 1, 0, 0, s))) return rc;
-    HeadFuse hf;
-    const HeadFuse* hfp = nullptr;
-    if (i == 0 && c->dtype == MGU_DTYPE_F32) {   // the shallowest block's conv2 feeds the final 1x1 conv (and the patch means)
-      const Layer& F = c->layers.back();
-      if (F.w_src && F.b_src && F.Cin == 32 && c->ncls <= 4) {
-        const bool pm = c->pm_out && c->pm_patch == 16 && H % 16 == 0 && W % 16 == 0;
-        hf = HeadFuse{F.w_src, F.b_src, (float*)logits_dev, c->ncls, pm ? (float*)c->pm_out : nullptr, H / 16, W / 16};
-        hfp = &hf;
-      }
-    }
-    if ((rc = run_conv(c, c->layers[li++], tmp, C, B, hs[i], wsz[i], feat_dev[i], C, 0, 1, 0, 0, s, nullptr, 0, nullptr, hfp, &head_done)))
-      return rc;
-    if (head_done && hf.pm_out) c->pm_out = nullptr;   // the request was served in that epilogue
+    if ((rc = run_conv(c, c->layers[li++], tmp, C, B, hs[i], wsz[i], feat_dev[i], C, 0, 1, 0, 0, s))) return rc;
     cur = feat_dev[i];
     cur_ld = C;
   }
   // final 1x1 conv (:143): a few output channels -> HBM-bound head kernel reading the reference's (ncls, C) weight
-  if (head_done) {
-    ++li;   // logits (and the patch means, if they were fusable) came out of the last conv's epilogue
-  } else {
+  {
     const Layer& F = c->layers[li++];
     const int pm_dtype = c->dtype;   // decoder features are stored in the compute dtype
     if (c->pm_out && F.w_src && F.b_src && patch_mean_head_fusable(pm_dtype, F.Cin, c->ncls) && F.Cin <= 256) {

@@ -52,14 +52,6 @@ __device__ __forceinline__ float scalar_fma(float a, float b, float c) {
   asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
-// x + (x of lane ^ 8 inside its row of 16): v_add_f32 with the row_ror:8 DPP modifier.  Inline asm on purpose: four
-// __builtin_amdgcn_update_dpp calls on the elements of one ext_vector were merged by hipcc (ROCm 7.2) into ONE DPP move of element 0
-// (seen in the ISA, caught by the parity test); the s_nop covers the VALU-write -> DPP-read hazard the compiler cannot see in asm.
-__device__ __forceinline__ float add_lane_xor8(float x) {
-  float y;
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(y) : "v"(x));
-  return y;
-}
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < N) {
@@ -679,13 +671,12 @@ constexpr int WINO_CP_RAWF = 8192;
 // URES (DEEP with exactly two chunks, i.e. 32 input channels): the two register sets of weight pieces hold the layer's WHOLE
 // transformed filter slice of this wave, so they are loaded once per workgroup and never again -- no weight-piece load sits in
 // the in-order memory pipe behind the halo loads and the epilogue's stores.
-template <int NTB, bool STATS, bool DEEP, bool HEAD = false, bool URES = false>
+template <int NTB, bool STATS, bool DEEP, bool URES = false>
 __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y, const int total_patches,
                         const int patches_per_block, const int ngroups, const int nitems, const int per_xcd, const int flags) {
   constexpr int NWAVES = 8;
   constexpr int MT = 2;                          // both m tiles of the 8 x 32 pixel patch
   const int yfast = flags & 1;
-  const int pairmajor = flags & 4;   // HEAD with patch sums: patches (2k, x), (2k + 1, x) of a 16-row band follow each other in a workgroup
   // flags & 2 (MGU_WINO_PRIO=1, A/B): static priority for the second-dispatched half of the workgroup (waves 4-7 = the jp = 1
   // waves, each the SIMD partner of wave - 4): the younger wave loses every VALU arbitration against its partner otherwise
   // (MI355X_MICROARCH.md, "Two waves per SIMD", item 4)
@@ -749,13 +740,8 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
   // share two of their ten halo rows, follow each other while those rows are still in the XCD's L2 -- measured with alternating
   // runs on one box: 1 % SLOWER on the headline step (the HBM read volume is not what bounds these kernels).
   auto setup_patch = [&](int p, int& img, int& y0, int& x0) {
-    int py = yfast ? p % tiles_y : (p / tiles_x) % tiles_y;
-    int px = yfast ? (p / tiles_y) % tiles_x : p % tiles_x;
-    if (HEAD && pairmajor) {   // tiles_y is even (H % 16 == 0): pair index x fastest, the two 8-row patches of a band adjacent
-      const int pair = p >> 1;
-      px = pair % tiles_x;
-      py = 2 * ((pair / tiles_x) % (tiles_y >> 1)) + (p & 1);
-    }
+    const int py = yfast ? p % tiles_y : (p / tiles_x) % tiles_y;
+    const int px = yfast ? (p / tiles_y) % tiles_x : p % tiles_x;
     img = p / (tiles_x * tiles_y);
     y0 = py * 8;
     x0 = px * 32;
@@ -908,7 +894,6 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
 #pragma unroll
   for (int nt = 0; nt < NTB; ++nt) st1[nt] = f32x4{0.f, 0.f, 0.f, 0.f}, st2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   int buf = 0;
-  float pm_keep = 0.f;   // (HEAD) patch sums of the upper 8-row patch of a band, held by the 64 reducer threads for its lower partner
   for (int pi = 0; pi < npatch; ++pi) {
     auto chunk_body = [&](const int c, auto par_c) {
       constexpr int P = decltype(par_c)::value;                  // DEEP: parity of the chunk = its register set
@@ -1045,17 +1030,6 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
       scw[nt] = d.scale ? d.scale[n] : 1.f;
       shw[nt] = (d.shift && wi == 1 && jp == 0) ? d.shift[n] : 0.f;
     }
-    // HEAD: the final 1x1 conv's weights of this thread's channel quad (loaded here for the reason given above)
-    float hwq[HEAD ? 4 : 1][4], hbq[HEAD ? 4 : 1];
-    if constexpr (HEAD) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int kc = min(k, d.head_ncls - 1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hwq[k][e] = d.head_w[kc * 32 + cq * 4 + e];
-        hbq[k] = d.head_b[kc];
-      }
-    }
 #pragma unroll
     for (int nt = 0; nt < NTB; ++nt) {
       const int n0 = nblock * NC + nt * 32 + cq * 4;
@@ -1145,76 +1119,7 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
           }
         }
       }
-      f32x4 pmq = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (HEAD) {
-        // ---- final 1x1 conv (unet_decoder.py:117,143) on the four pixels of this thread's tile, 4 of the 32 channels per lane:
-        // partial dot products, folded over the 8 lanes of the tile with three DPP adds (quad permutes + row_half_mirror).
-        // Lane cq == p stores pixel p of the tile: (oy, ox), (oy, ox + 1), (oy + 1, ox), (oy + 1, ox + 1).
-        const f32x4* px[4] = {&ya[0], &ya[1], &yb[0], &yb[1]};
-        float mine[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (k < d.head_ncls) {   // uniform
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-              float s = 0.f;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) s += (*px[p])[e] * hwq[k][e];
-              s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));    // lane ^ 1
-              s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));    // lane ^ 2
-              s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));   // 7 - lane
-              if (cq == p) mine[k] = s + hbq[k];
-            }
-          }
-        if (cq < 4) {
-          const int py = oy + (cq >> 1), pxx = ox + (cq & 1);
-          if (py < d.H && pxx < d.W) {
-            float* lp = d.head_out + ((size_t)(img * d.H + py) * d.W + pxx) * d.head_ncls;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (k < d.head_ncls) lp[k] = mine[k];
-          }
-        }
-        // ---- 16 x 16 patch sums of the stored feature: this thread's 4 pixels (masked at the image edge) ...
-        if (d.pm_out) {
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            const float ma = (interior || (ox + q < d.W && oy < d.H)) ? 1.f : 0.f;
-            const float mb = (interior || (ox + q < d.W && oy + 1 < d.H)) ? 1.f : 0.f;
-            pmq += ma * ya[q] + mb * yb[q];
-          }
-        }
-      }
       lds_barrier();   // the regions are rewritten by the next pass / region 0 receives the next raw chunk
-      if constexpr (HEAD) {
-        if (d.pm_out) {
-          // ... a wave holds 8 tiles of ONE tile row and ONE 16-pixel half of the patch (T = 8 wave + lane / 8): fold tile pairs
-          // with row_ror:8, park the four row sums per wave in the (now idle) exchange area, and let 64 threads add the 16
-          // partials of their (half, channel) in a fixed order.  The workgroup walks the two 8-row patches of a 16 x 16 graph
-          // patch one after the other (pair-major order): the first one's sums wait in a register, the second one's are added
-          // and the mean is stored -- no atomics (a float atomic would sit in front of the next halo loads in the in-order
-          // memory pipe for ~3000 cycles), no zero fill, a fixed summation order.
-          float* const pms = zext + RAWF;   // region (1, 0): read for the last time before the barrier above
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pmq[e] = add_lane_xor8(pmq[e]);
-          if ((et & 8) == 0) *reinterpret_cast<f32x4*>(pms + (((et >> 6) * 4 + ((et >> 4) & 3)) * 8 + cq) * 4) = pmq;
-          lds_barrier();
-          if (et < 64) {
-            const int hf = et >> 5, ch = et & 31;
-            float s = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < 4; ++wv)
-#pragma unroll
-              for (int rw = 0; rw < 4; ++rw) s += pms[((2 * wv + hf) * 4 + rw) * 32 + ch];
-            if ((pi & 1) == 0) {
-              pm_keep = s;
-            } else if (x0 + 16 * hf < d.W) {
-              const int gx = (x0 >> 4) + hf, gy = y0 >> 4;
-              d.pm_out[((size_t)(img * d.pm_nph + gy) * d.pm_npw + gx) * 32 + ch] = (pm_keep + s) * (1.f / 256.f);
-            }
-          }
-        }
-      }
     }
 #endif
 #pragma unroll
@@ -1247,7 +1152,7 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
   }
 }
 
-template <int NTB, bool STATS, bool DEEP = false, bool HEAD = false, bool URES = false>
+template <int NTB, bool STATS, bool DEEP = false, bool URES = false>
 static hipError_t launch_wino_cp(const IgemmDesc& d, hipStream_t s) {
   constexpr int NWAVES = 8;
   const int tiles_x = (d.W + 31) / 32, tiles_y = (d.H + 7) / 8;
@@ -1258,21 +1163,16 @@ static hipError_t launch_wino_cp(const IgemmDesc& d, hipStream_t s) {
   int ppb = (int)(((long)total * nblk) / (256 * rounds));
   if (ppb < 1) ppb = 1;
   if (ppb > cap) ppb = cap;
-  const bool pairs = HEAD && d.pm_out;   // patch sums: a workgroup owns whole 16-row bands (patch pairs); tiles_y is even
-  if (pairs) {
-    if ((d.H & 15) || (d.W & 15)) return hipErrorInvalidValue;
-    ppb = std::max(2, ppb & ~1);
-  }
   const int ngroups = (total + ppb - 1) / ppb;
   const int per_xcd = (ngroups * nblk + 7) / 8;
   dim3 grid(8 * per_xcd, 1);
   if (d.stat_slots && grid.x > (unsigned)STAT_ROWS) return hipErrorInvalidValue;   // one accumulator row per workgroup (common.h)
   const size_t lds = (size_t)(5 * WINO_CP_RAWF) * sizeof(float);   // two raw buffers + three exchange regions = the CU's 160 KB
   static bool attr_done[64] = {};
-  hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&wino3x3_cp_kernel<NTB, STATS, DEEP, HEAD, URES>), lds, attr_done);
+  hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&wino3x3_cp_kernel<NTB, STATS, DEEP, URES>), lds, attr_done);
   if (ae != hipSuccess) return ae;
-  hipLaunchKernelGGL((wino3x3_cp_kernel<NTB, STATS, DEEP, HEAD, URES>), grid, dim3(64 * NWAVES), lds, s, d, tiles_x, tiles_y, total, ppb, ngroups, ngroups * nblk,
-                     per_xcd, (tun(d).wino_yfast && !pairs ? 1 : 0) | (tun(d).wino_prio ? 2 : 0) | (pairs ? 4 : 0));
+  hipLaunchKernelGGL((wino3x3_cp_kernel<NTB, STATS, DEEP, URES>), grid, dim3(64 * NWAVES), lds, s, d, tiles_x, tiles_y, total, ppb, ngroups, ngroups * nblk,
+                     per_xcd, (tun(d).wino_yfast ? 1 : 0) | (tun(d).wino_prio ? 2 : 0));
   return hipGetLastError();
 }
 
@@ -1323,14 +1223,6 @@ bool wino_applicable(const IgemmDesc& d) {
          (d.ldin & 3) == 0 && (long)d.H * d.W * d.ldin < (1l << 31) && (long)d.H * d.W * d.ldout < (1l << 31);
 }
 
-// The 1x1 head (and the 16 x 16 patch sums) can ride in the epilogue of this layer: the launch below takes the narrow
-// component-pair kernel, the layer has exactly 32 output channels in one dense pixel (the decoder feature) and <= 4 classes.
-bool wino_head_fusable(const IgemmDesc& d, int ncls) {
-  return wino_applicable(d) && tun(d).wino_prec && tun(d).wino_cp && tun(d).wino_cp_narrow && tun(d).wino_head && d.N == 32 &&
-         d.coff == 0 && (d.ldout & 3) == 0 && !d.pool && !d.stat_slots && ncls >= 1 && ncls <= 4 &&
-         (long)d.H * d.W * d.ldin * 4 < (1l << 31);
-}
-
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
   const bool wide = d.N > 32 && tun(d).wino_mode != 1;
   if (tun(d).wino_prec && tun(d).wino_cp && (wide || tun(d).wino_cp_narrow) &&
@@ -1340,12 +1232,7 @@ hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
     const bool deep = !wide && ((d.Cp >> 4) & 1) == 0 && tun(d).wino_deep && !d.stat_slots;
     const bool ures = deep && (d.Cp >> 4) == 2 && tun(d).wino_ures;
     if (d.stat_slots) return wide ? launch_wino_cp<2, true>(d, s) : deep ? launch_wino_cp<1, true, true>(d, s) : launch_wino_cp<1, true>(d, s);
-    if (d.head_out) {   // fused 1x1 head (+ patch sums): only the narrow component-pair kernel carries it (wino_head_fusable)
-      if (wide || !(tun(d).wino_prec && tun(d).wino_cp)) return hipErrorInvalidValue;
-      if (deep && ures) return launch_wino_cp<1, false, true, true, true>(d, s);
-      return deep ? launch_wino_cp<1, false, true, true>(d, s) : launch_wino_cp<1, false, false, true>(d, s);
-    }
-    if (deep && ures) return launch_wino_cp<1, false, true, false, true>(d, s);
+    if (deep && ures) return launch_wino_cp<1, false, true, true>(d, s);
     return wide ? launch_wino_cp<2, false>(d, s) : deep ? launch_wino_cp<1, false, true>(d, s) : launch_wino_cp<1, false>(d, s);
   }
   if (tun(d).wino_prec) return wide ? launch_wino_mode<0, 1>(d, s) : launch_wino_mode<1, 1>(d, s);
