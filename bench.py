@@ -183,29 +183,39 @@ def load_traffic(kernel, dtype):
 
 
 def gat_record(dev, L, _lib):
-    """The graph kernel at the north-star point (64 graphs of the 512^2 / patch-16 grid = 65 536 nodes, 253 952 edges) on
-    synthetic node features, both schedules: aggregate-first (the patch GAT's, Fin 32 <= F' 64) and the Wh-row gather
-    (layers with Fin > F'; forced here with MGU_NO_GAT_FUSED=1 in a context of its own so that the same layer is measured)."""
+    """The graph layer on synthetic node features, both schedules -- aggregate-first (Fin <= F': the attention-weighted sum is taken
+    over the INPUT rows, gat_fused.hip) and the Wh-row gather (gat.hip; forced with MGU_NO_GAT_FUSED=1 in a context of its own so
+    that the same layer is measured) -- at three sizes: 8 and 64 graphs of the 512^2 / patch-16 grid (1024 nodes, 3968 edges each;
+    64 graphs = the north-star point) with the patch GAT (32 -> 4 x 64), and BASELINE configs[3]'s stress graphs (32 graphs of 2048
+    nodes, in-degree exactly 8, random sources; GAT 64 -> 4 x 64)."""
     import mgunet
     import mgunet_oracle as O
-    from mgunet.engine import gat_forward_csr
     out = {}
     graph = mgunet.PatchGraphConstructor(16)
-    Fin, heads, Fh = 32, 4, 64
-    for G in (8, 64):
+    heads, Fh = 4, 64
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+
+    def patch_case(G):
         rowptr, col, gp, N1, E1 = graph.batched_csr(512, 512, G, dev)
-        N, E = N1 * G, E1 * G
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(7)
+        return f"graphs_{G}", 32, rowptr, col, gp, N1 * G, E1 * G, G
+
+    def c4_case():
+        G, N1, deg = 32, 2048, 8
+        src = torch.randint(0, N1, (G, N1 * deg), device=dev, generator=gen) + (torch.arange(G, device=dev) * N1)[:, None]
+        return ("c4_32x2048_deg8", 64, (torch.arange(G * N1 + 1, device=dev, dtype=torch.int64) * deg).to(torch.int32),
+                src.reshape(-1).to(torch.int32), (torch.arange(G + 1, device=dev, dtype=torch.int64) * N1).to(torch.int32), G * N1, G * N1 * deg, G)
+
+    for key, Fin, rowptr, col, gp, N, E, G in (patch_case(8), patch_case(64), c4_case()):
         X = torch.randn((N, Fin), device=dev, generator=gen)
-        rec = {"graphs": G, "nodes": N, "edges": E}
+        rec = {"graphs": G, "nodes": N, "edges": E, "Fin": Fin, "heads": heads, "Fout_per_head": Fh}
         for sched, env in (("aggregate_first", {}), ("wh_row_gather", {"MGU_NO_GAT_FUSED": "1"})):
             old = {k: os.environ.get(k) for k in env}
             os.environ.update(env)
             ctx = _lib.Context(dev.index or 0)
             for k, v in old.items():
                 os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
-            gp_ = O.make_gat_params(32, 128, 64, 4, 1, seed=0)
+            gp_ = O.make_gat_params(Fin, 128, 64, 4, 1, seed=0)
             W = torch.cat([gp_[f"gat_layers.0.heads.{h}.W.weight"] for h in range(heads)], 0).contiguous().to(dev)
             a = torch.cat([gp_[f"gat_layers.0.heads.{h}.a.weight"] for h in range(heads)], 0).contiguous().to(dev)
             hnd = C.c_void_p()
@@ -244,19 +254,22 @@ def gat_record(dev, L, _lib):
                 dom_name = "gat_aggregate_kernel"
                 dom_bytes = N * heads * Fh * 4 + N * 2 * heads * 4 + csr + N * 4 + N * Fh * 4   # Wh table + s,t + CSR + out
             dom_us = kern.get(dom_name)
+            logical = E * (4 + (Fin if sched == "aggregate_first" else heads * Fh) * 4 + 4)
             rec[sched] = {"launches": len(ks), "layer_us": round(layer_us, 2), "kernel_us": kern,
                           "dominant_kernel": dom_name, "compulsory_bytes": dom_bytes,
                           "achieved_TBps": round(dom_bytes / (dom_us * 1e-6) / 1e12, 3) if dom_us else None,
                           "frac_of_hbm_peak": round(dom_bytes / (dom_us * 1e-6) / 1e12 / PEAK_HBM_TBS, 4) if dom_us else None,
-                          "logical_gather_bytes": E * (4 + (Fin if sched == "aggregate_first" else heads * Fh) * 4 + 4),
+                          "logical_gather_bytes": logical,
+                          "logical_gather_TBps": round(logical / (dom_us * 1e-6) / 1e12, 3) if dom_us else None,
                           "layer_compulsory_bytes": comp}
             L.mgu_gat_release(ctx.handle, hnd)
             del ctx
-        out[f"graphs_{G}"] = rec
+        out[key] = rec
     out["note"] = ("compulsory_bytes: every array the dominant kernel must touch once (node table or input rows, attention scalars, CSR, "
                    "node->graph ids, output); at these sizes the tables (8-67 MB) stay in the 256 MB Infinity Cache between the producer "
                    "and the gather, so the ceiling is the cache, not HBM -- the HBM fraction the north star asks for is quoted as-is, "
-                   "against the 8 TB/s spec peak")
+                   "against the 8 TB/s spec peak; logical_gather_*: one source row per edge (what the reference's index / scatter_add "
+                   "formulation moves)")
     return out
 
 
@@ -362,6 +375,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: 8 = BASELINE configs[1]/[2]; train mode: 4 = configs[4])")
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--workload", choices=["c2", "c4"], default="c2",
+                    help="c2 (default): BASELINE configs[1]/[2], batch 8 x 3x512x512 + the 16-pixel patch graph; c4: BASELINE configs[3], "
+                         "batch 32 x 3x1024x1024 U-Net forward + the GAT(64->64, 4 heads) on 32 synthetic superpixel graphs of 2048 nodes "
+                         "with in-degree 8 (SURVEY 8d C4) -- its own line, never the headline value")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer: BASELINE configs[1]/[2] full forward (the headline); train: configs[4] train step "
                          "(fwd + CE + bwd + RCCL grad all-reduce + Adam), 4 images per GPU unless --batch is given")
@@ -412,15 +429,37 @@ def main():
 
     if a.mode == "train":
         return bench_train(a, world, rank, local_rank, dev, dist)
-    B, H, W = a.batch if a.batch is not None else 8, a.size, a.size
+    c4 = a.workload == "c4"
+    if c4:
+        a.size = 1024
+    B, H, W = a.batch if a.batch is not None else (32 if c4 else 8), a.size, a.size
     unet = mgunet.UNet(3, 2, 32, 4, compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     unet.load_state_dict(O.make_unet_params(3, 2, 32, 4, seed=0))     # random-init-scale formula weights
-    gat = mgunet.GATNetwork(32, 128, 64, 4, 1)
-    gat.load_state_dict(O.make_gat_params(32, 128, 64, 4, 1, seed=0))
-    model = mgunet.MinGraphUNet(unet.to(dev).eval(), gat.to(dev).eval(), 16).eval()
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     x = torch.randn((B, 3, H, W), device=dev, generator=gen)           # synthetic batch, resident in HBM
+    if not c4:
+        gat = mgunet.GATNetwork(32, 128, 64, 4, 1)
+        gat.load_state_dict(O.make_gat_params(32, 128, 64, 4, 1, seed=0))
+        model = mgunet.MinGraphUNet(unet.to(dev).eval(), gat.to(dev).eval(), 16).eval()
+    else:
+        # per image a synthetic superpixel-like graph, 2048 nodes, 16384 directed edges, in-degree exactly 8,
+        # target-sorted; X (2048, 64); GATNetwork(64, 128, 64, 4, 1) -- Fin 64 = F' 64 with 4 heads: the Wh-row gather schedule
+        from mgunet.engine import gat_forward_csr
+        gat = mgunet.GATNetwork(64, 128, 64, 4, 1)
+        gat.load_state_dict(O.make_gat_params(64, 128, 64, 4, 1, seed=0))
+        gat = gat.to(dev).eval()
+        unet = unet.to(dev).eval()
+        N1, deg = 2048, 8
+        src = torch.randint(0, N1, (B, N1 * deg), device=dev, generator=gen) + (torch.arange(B, device=dev) * N1)[:, None]
+        g_col = src.reshape(-1).to(torch.int32)
+        g_rowptr = (torch.arange(B * N1 + 1, device=dev, dtype=torch.int64) * deg).to(torch.int32)
+        g_ptr = (torch.arange(B + 1, device=dev, dtype=torch.int64) * N1).to(torch.int32)
+        gX = torch.randn((B * N1, 64), device=dev, generator=gen)
+
+        def model(xx):
+            lg, sk, ft = unet(xx)
+            return lg, sk, ft, gat_forward_csr(gat, gX, g_rowptr, g_col, g_ptr)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -489,7 +528,7 @@ def main():
         # the label describes the DOMINANT record itself: an fp32 result computed on the bf16 pipe is the three-piece split
         arithmetic = ("bf16 storage, fp32 accumulate" if a.dtype == "bf16" else
                       (ARITH_3PIECE if dom is not None and dom["pipe"] == 1 else "exact fp32 MFMA operands"))
-        traffic = load_traffic(dom["name"], a.dtype) if dom and (B, H, W) == (8, 512, 512) else None
+        traffic = load_traffic(dom["name"], a.dtype) if dom and (B, H, W) == (8, 512, 512) and not c4 else None
         roof = roofline_from(stats, nprof, arithmetic, traffic)
         ksum = sum(k["ms"] for k in stats) / nprof
         timing = {"ms_per_step": round(ms_step, 4), "instrumented_ms_per_step": round(inst_ms, 4),
@@ -506,17 +545,20 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(2, H, W, 14)   # ~12 s of host work on the GPU box's 16-core share
+        cpu = cpu_baseline(2, H, W, 14) if not c4 else cpu_baseline(1, H, W, 4)   # ~12 s of host work on the GPU box's 16-core share
 
     if rank == 0:
-        line = {"metric": "segmented Mpix/sec, full MinGraph-UNet forward (U-Net + patch-graph GAT), 512x512 batch",
+        line = {"metric": ("segmented Mpix/sec, full MinGraph-UNet forward (U-Net + patch-graph GAT), 512x512 batch" if not c4 else
+                           "segmented Mpix/sec, MinGraph-UNet forward (U-Net + stress-graph GAT), 1024x1024 batch"),
                 "value": round(mpix, 3), "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                 "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": a.dtype, "data": "synthetic (N(0,1) images resident in HBM, formula random-init-scale weights)",
-                "config": {"workload": (f"BASELINE configs[1]: batch {B}/GPU x 3x{H}x{W} fp32 full forward "
-                                        if a.dtype == "f32" else
-                                        f"BASELINE configs[2] precision: batch {B}/GPU x 3x{H}x{W}, bf16 storage + fp32 accumulate, full forward ")
-                                       + "(UNet(3,2,32,4) + patch16 graph GAT(32->64,4 heads)), eval",
+                "config": {"workload": (f"BASELINE configs[3]: batch {B}/GPU x 3x{H}x{W} {a.dtype} U-Net forward + GAT(64->64, 4 heads) on {B} "
+                                        f"synthetic graphs of 2048 nodes, in-degree 8 (UNet(3,2,32,4)), eval" if c4 else
+                                        (f"BASELINE configs[1]: batch {B}/GPU x 3x{H}x{W} fp32 full forward "
+                                         if a.dtype == "f32" else
+                                         f"BASELINE configs[2] precision: batch {B}/GPU x 3x{H}x{W}, bf16 storage + fp32 accumulate, full forward ")
+                                        + "(UNet(3,2,32,4) + patch16 graph GAT(32->64,4 heads)), eval"),
                            "images_per_gpu": B, "global_batch": B * world, "parallelism": f"batch-shard x{world}, no collective"},
                 "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / a.steps, 4),
                 "spread": {"windows": len(windows), "steps_per_window": a.steps, "min_ms": round(min(windows), 4),

@@ -13,6 +13,7 @@
 //   gat_aggregate : CSR-by-target neighbour gather -> weighted sum -> /(D+1e-10) -> ELU -> concat | head-mean
 //                   one wavefront per 4-row CSR segment, 8 row gathers in flight per lane, segmented
 //                   register accumulation, head-mean staged through LDS, XCD-aware workgroup order.
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
     }
   }
 }
+
 
 hipError_t launch_gat_aggregate(const float* wh, int P, const float* st, const int32_t* rowptr, const int32_t* col,
                                 const int32_t* node_graph, const unsigned long long* gmax_enc, int N, int heads, int Fh, int concat,
