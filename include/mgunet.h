@@ -202,6 +202,22 @@ int mgu_unet_backward_allreduce(mgu_ctx* ctx, const void* dlogits_dev, void* fla
 int mgu_unet_request_patch_mean(mgu_ctx* ctx, int patch, void* out_dev);
 
 /* ---- patch graph: replaces preprocessing/graph_construction/patch_graph_construction.py:49-102 -- */
+/* ---- GAT training (the reference puts the graph branch's parameters in the optimizer, scripts/train_end_to_end.py:219-226, and
+ * differentiates through GraphAttentionLayer.forward with loss.backward(), :478; dropout must be off: p = 0 or eval mode) ----------
+ * DEVICE: transpose of a CSR-by-target: rowptr_src (N+1) / eid_src (E) list, per SOURCE node and in target-CSR order, the positions
+ * of its out-edges in col[]; tgt_of_edge (E) is the target row of every edge.  Stable radix sort: every sum of the backward has a
+ * fixed order.  Static per graph: build once, reuse for every step. */
+int mgu_csr_transpose_device(mgu_ctx* ctx, const int32_t* rowptr_dev, const int32_t* col_dev, int64_t E, int num_nodes,
+                             int32_t* rowptr_src_dev, int32_t* eid_src_dev, int32_t* tgt_of_edge_dev, void* hip_stream);
+/* Backward of mgu_gat_layer_forward (same arguments; the forward's intermediates are recomputed from X, W, a): given dout
+ * (N, heads*Fout_head if concat else Fout_head) writes dW (heads*Fout_head, Fin), da (heads, 2*Fout_head) and, if dX_dev is not
+ * NULL, dX (N, Fin).  Includes the gradient through the graph-wide max of graph_attention.py:86 (torch.max()'s backward: to the
+ * arg-max edge, evenly over ties).  heads*Fout_head <= 256. */
+int mgu_gat_layer_backward(mgu_ctx* ctx, const void* X_dev, int N, int Fin, const int32_t* rowptr_dev, const int32_t* col_dev, int64_t E,
+                           const int32_t* rowptr_src_dev, const int32_t* eid_src_dev, const int32_t* tgt_of_edge_dev,
+                           const int32_t* graph_ptr_dev, int num_graphs, const void* W_dev, const void* a_dev, int heads, int Fout_head,
+                           int concat, float alpha, const void* dout_dev, void* dX_dev, void* dW_dev, void* da_dev, void* hip_stream);
+
 /* HOST routine (index maps are tiny and static per image size).  Emits the COO edge_index in the
  * reference's exact order (:77-92) into coo[0..E) (sources) and coo[E..2E) (targets), and the
  * CSR-by-target (rowptr[N+1], col[E]) that keeps each target's sources in COO order.  Any output

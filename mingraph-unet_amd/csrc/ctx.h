@@ -74,6 +74,10 @@ struct mgu_ctx {
   size_t arena_floats = 0;
   void* ws = nullptr;   // eval scratch
   size_t ws_bytes = 0;
+  void* gbws = nullptr;     // GAT backward scratch (gat_bwd.hip)
+  size_t gbws_bytes = 0;
+  void* gbpanel = nullptr;  // GAT backward: the linear layer's packed panel
+  size_t gbpanel_bytes = 0;
   void* gws = nullptr;  // GAT / building-block scratch
   size_t gws_bytes = 0;
   void* tws = nullptr;  // training scratch (saved activations + backward temporaries)
@@ -84,6 +88,9 @@ struct mgu_ctx {
   std::vector<float*> t_cat, t_feat, t_pooled;
   float* t_logits = nullptr;
   void gat_destroy(mgu_ctx* c);   // gat_api.hip
+int gmax_buffer(mgu_ctx* c, int need, unsigned long long** buf, unsigned* gen);
+int gat_linear_st(mgu_ctx* c, const float* X, int N, int Fin, const float* W, const float* a, int heads, int Fh, float* wh, float* st,
+                  hipStream_t s);
 
 // gradient exchange (comm.hip): RCCL communicator owned by this context, its stream and a small pool of ordering events
   void* comm = nullptr;     // ncclComm_t
@@ -179,6 +186,9 @@ int run_layer(mgu_ctx* c, const Layer& L, const void* in, int ldin, int B, int H
               double* stat_slots = nullptr, bool* stat_fused = nullptr);          // optional fused BatchNorm batch statistics
 
 void gat_destroy(mgu_ctx* c);   // gat_api.hip
+int gmax_buffer(mgu_ctx* c, int need, unsigned long long** buf, unsigned* gen);
+int gat_linear_st(mgu_ctx* c, const float* X, int N, int Fin, const float* W, const float* a, int heads, int Fh, float* wh, float* st,
+                  hipStream_t s);
 
 // gradient exchange (comm.hip)
 int comm_bucket(mgu_ctx* c, float* flat, int64_t lo, int64_t hi, hipStream_t s);

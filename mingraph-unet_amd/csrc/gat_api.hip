@@ -58,8 +58,10 @@ int check_layer_shape(mgu_ctx* c, int Fin, int heads, int Fh) {
   return MGU_OK;
 }
 
+}  // namespace
+
 // the slotted per-(graph, head) max accumulators [64 slots][cap] of 64-bit (generation, value) words and this call's generation
-int gmax_buffer(mgu_ctx* c, int need, unsigned long long** buf, unsigned* gen) {
+int mgud::gmax_buffer(mgu_ctx* c, int need, unsigned long long** buf, unsigned* gen) {
   if (need > c->gmax_cap) {
     const int cap = (std::max(need, 256) + 15) / 16 * 16;   // entries per slot: whole 128-byte lines
     if (c->gmaxbuf) {
@@ -80,6 +82,32 @@ int gmax_buffer(mgu_ctx* c, int need, unsigned long long** buf, unsigned* gen) {
   *gen = ++c->gmax_gen;
   return MGU_OK;
 }
+
+// Wh (N, HF) and the attention scalars st (N, 2H) = [s | t] from ONE GEMM on the panel [W | W^T a_src | W^T a_tgt] (the gather
+// schedule's first launch), with the panel packed on the spot into a buffer of the backward's own: mgu_gat_layer_backward
+// recomputes the forward's intermediates from the CURRENT weights.
+int mgud::gat_linear_st(mgu_ctx* c, const float* X, int N, int Fin, const float* W, const float* a, int heads, int Fh, float* wh, float* st,
+                        hipStream_t s) {
+  const int HF = heads * Fh, Kp = rup(Fin, 32), NPp = rup(HF + 2 * heads, 128);
+  int rc = ensure(c, &c->gbpanel, &c->gbpanel_bytes, (size_t)NPp * Kp * sizeof(float));
+  if (rc) return rc;
+  float* panel = (float*)c->gbpanel;
+  HIPCHK(c, hipMemsetAsync(panel, 0, (size_t)NPp * Kp * sizeof(float), s));
+  HIPCHK(c, launch_pack_conv_w(W, panel, 0, HF, Fin, Fin, 1, Kp, s));
+  HIPCHK(c, launch_gat_wa_rows(W, a, panel, HF, heads, Fh, Fin, Kp, s));
+  IgemmDesc d;
+  memset(&d, 0, sizeof d);
+  d.tn = &c->tn;
+  d.in = X, d.w = panel, d.out = wh;
+  d.M = N, d.H = 1, d.W = N;
+  d.Cp = Fin, d.ldin = Fin, d.KS = 1, d.K = Fin, d.Kp = Kp;
+  d.N = HF + 2 * heads, d.ldout = HF;
+  d.split_n = HF, d.out2 = st, d.ld2 = 2 * heads;
+  HIPCHK(c, launch_igemm_f32(d, s));
+  return MGU_OK;
+}
+
+namespace {
 
 int forward_prepared(mgu_ctx* c, const mgu_gat_weights* p, const float* X, int N, const int32_t* rowptr, const int32_t* col, int64_t E,
                      const int32_t* graph_ptr, int num_graphs, int concat, float alpha, float* out, hipStream_t s) {

@@ -1,0 +1,335 @@
+// Backward of one multi-head graph attention layer (GraphAttentionLayer / MultiHeadGATLayer, model/gat/graph_attention.py:40-160)
+// in eval-dropout form (p = 0): what torch autograd computes for the reference when the graph branch is trained
+// (scripts/train_end_to_end.py:219-226 puts the GAT parameters in the optimizer, :478 calls loss.backward()).
+//
+// Forward, per head (all heads in one pass; Wh = X W^T, s = Wh a_src, t = Wh a_tgt):
+//     z_k = s_src(k) + t_tgt(k),  e_k = LeakyReLU(z_k),  x_k = exp(e_k - m),  m = max over ALL edges of the graph (:86)
+//     D_j = sum_{k: tgt = j} x_k,  alpha_k = x_k / (D_j + 1e-10) (:96),  h'_j = sum_k alpha_k Wh_src(k),  out_j = ELU(h'_j) (:118)
+// Backward (g* = gradient of the loss):
+//     gh'_j  = gout_j * ELU'(h'_j)                       (gout / H for the head mean, :158)
+//     ga_k   = gh'_tgt . Wh_src                          c_j = sum_k alpha_k ga_k
+//     ge_k   = alpha_k (ga_k - c_j)                      gz_k = ge_k * (z_k > 0 ? 1 : slope)
+//     gm     = -sum_j c_j * 1e-10 / (D_j + 1e-10)        (the global max is an input of every alpha; its gradient goes to the
+//                                                         arg-max edge(s), evenly over ties -- torch.max()'s backward; it matters
+//                                                         exactly where the 1e-10 bites: rows whose D_j is tiny)
+//     gt_j   = sum_{k: tgt = j} gz_k                     gs_i = sum_{k: src = i} gz_k
+//     gWh_i  = sum_{k: src = i} alpha_k gh'_tgt(k) + gs_i a_src + gt_i a_tgt
+//     ga_src = sum_i gs_i Wh_i,  ga_tgt = sum_j gt_j Wh_j,  gW = gWh^T X,  gX = gWh W
+// Kernels: one wavefront per target row (three passes over its in-edges; per-edge alpha and gz are parked in edge arrays),
+// one block per (graph, head) for the max term, one wavefront per SOURCE row over the transposed CSR (no float atomics: every
+// sum has a fixed order, so the gradients are bitwise reproducible), a two-level column reduction for ga, and the two GEMMs
+// through the 1x1-convolution gradient launchers of the U-Net (bwd_blocks.hip).  HF = heads * Fh <= 256.
+#include <algorithm>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "ctx.h"
+#include "gat_common.h"
+
+namespace mgu {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void gatb_edge_keys_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int N,
+                                                             int* __restrict__ keys, int* __restrict__ vals, int* __restrict__ tgt) {
+  // one wave per target row: key = source, value = edge position (target-CSR order), tgt[edge] = row
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= N) return;
+  const int s0 = rowptr[j], s1 = rowptr[j + 1];
+  for (int k = s0 + lane; k < s1; k += 64) keys[k] = col[k], vals[k] = k, tgt[k] = j;
+}
+__global__ __launch_bounds__(256) void gatb_rowptr_kernel(const int* __restrict__ sorted_keys, int64_t E, int N, int* __restrict__ rowptr) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j > N) return;
+  int64_t lo = 0, hi = E;   // first position with key >= j
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (sorted_keys[mid] < j) lo = mid + 1; else hi = mid;
+  }
+  rowptr[j] = (int)lo;
+}
+
+// per (graph, head) max as a plain float table (decoded from the slotted accumulators of the forward's edge-max pass)
+__global__ void gatb_gmax_decode_kernel(const gmax_t* __restrict__ gmax, int n, unsigned gen, float* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  gmax_t u = 0;
+  for (int sl = 0; sl < GMAX_SLOTS; ++sl) {
+    const gmax_t o = gmax[(size_t)e * GMAX_SLOTS + sl];
+    u = o > u ? o : u;
+  }
+  out[e] = gmax_decode(u, gen);
+}
+
+// sum over the qh consecutive lanes of a head, valid in the head's FIRST lane (cin == 0): segmented doubling with shfl_down,
+// any qh <= 64
+__device__ __forceinline__ float head_sum(float v, int cin, int qh) {
+  for (int o = 1; o < qh; o <<= 1) {
+    const float u = __shfl_down(v, o);
+    if (cin + o < qh) v += u;
+  }
+  return v;
+}
+
+// ---- per target row: alpha, gh', ga, c, gz, gt, the row's share of the max term -----------------------------------------------
+__global__ __launch_bounds__(256) void gatb_target_kernel(const float* __restrict__ wh, const float* __restrict__ st,
+                                                          const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                          const int32_t* __restrict__ node_graph, const float* __restrict__ gm_f,
+                                                          const float* __restrict__ dout, int N, int heads, int Fh, int concat, float slope,
+                                                          float* __restrict__ ghp, float* __restrict__ alpha_e, float* __restrict__ gz_e,
+                                                          float* __restrict__ gt, float* __restrict__ gmrow) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= N) return;   // wave-uniform
+  const int HF = heads * Fh, nq = HF >> 2, qh = Fh >> 2, H2 = 2 * heads;
+  const bool on = lane < nq;
+  const int head = on ? lane / qh : 0, cin = on ? lane - head * qh : 0;
+  const bool lead = on && cin == 0;                      // the lane that owns the (row, head) scalars
+  const int s0 = rowptr[j], s1 = rowptr[j + 1];
+  const int g = node_graph ? node_graph[j] : 0;
+  const float tj = st[(size_t)j * H2 + heads + head], m = gm_f[g * heads + head];
+  // pass 1: D, h'
+  float D = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = s0; k < s1; ++k) {
+    const int src = col[k];
+    const float z = st[(size_t)src * H2 + head] + tj;
+    const float x = on ? __expf((z > 0.f ? z : slope * z) - m) : 0.f;
+    D += x;
+    acc += x * *reinterpret_cast<const f32x4*>(wh + (size_t)src * HF + (on ? lane * 4 : 0));
+  }
+  const float inv = 1.f / (D + 1e-10f);
+  f32x4 go = {0.f, 0.f, 0.f, 0.f};
+  if (on) go = concat ? *reinterpret_cast<const f32x4*>(dout + (size_t)j * HF + lane * 4)
+                      : *reinterpret_cast<const f32x4*>(dout + (size_t)j * Fh + cin * 4) * (1.f / (float)heads);
+  f32x4 gh;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float hp = acc[q] * inv;
+    gh[q] = go[q] * (hp > 0.f ? 1.f : __expf(hp));       // ELU'(x) = 1 (x > 0), exp(x) otherwise
+  }
+  if (on) *reinterpret_cast<f32x4*>(ghp + (size_t)j * HF + lane * 4) = gh;
+  // pass 2: ga_k, alpha_k, c
+  float c = 0.f;
+  for (int k = s0; k < s1; ++k) {
+    const int src = col[k];
+    const f32x4 w = *reinterpret_cast<const f32x4*>(wh + (size_t)src * HF + (on ? lane * 4 : 0));
+    const float ga = head_sum(on ? gh[0] * w[0] + gh[1] * w[1] + gh[2] * w[2] + gh[3] * w[3] : 0.f, cin, qh);   // lead lane
+    const float z = st[(size_t)src * H2 + head] + tj;
+    const float al = __expf((z > 0.f ? z : slope * z) - m) * inv;
+    c += al * ga;
+    if (lead) alpha_e[(size_t)k * heads + head] = al, gz_e[(size_t)k * heads + head] = ga;
+  }
+  // pass 3: gz_k (own values back from the edge arrays: same lane wrote them), gt
+  float gtv = 0.f;
+  if (lead)
+    for (int k = s0; k < s1; ++k) {
+      const int src = col[k];
+      const float z = st[(size_t)src * H2 + head] + tj;
+      const float gz = alpha_e[(size_t)k * heads + head] * (gz_e[(size_t)k * heads + head] - c) * (z > 0.f ? 1.f : slope);
+      gz_e[(size_t)k * heads + head] = gz;
+      gtv += gz;
+    }
+  if (lead) gt[(size_t)j * heads + head] = gtv, gmrow[(size_t)j * heads + head] = -c * 1e-10f * inv;
+}
+
+// ---- the max term: gm[g][h] = sum of the rows' shares (fixed order), added to the arg-max edge(s) of the graph -----------------
+__global__ __launch_bounds__(256) void gatb_max_term_kernel(const float* __restrict__ st, const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ col, const int32_t* __restrict__ tgt_e,
+                                                            const int32_t* __restrict__ graph_ptr, int N, int heads, float slope,
+                                                            const float* __restrict__ gm_f, const float* __restrict__ gmrow,
+                                                            float* __restrict__ gz_e, float* __restrict__ gt) {
+  __shared__ double red[256];
+  __shared__ int cnt;
+  const int g = blockIdx.x / heads, h = blockIdx.x - g * heads, t = threadIdx.x, H2 = 2 * heads;
+  const int n0 = graph_ptr ? graph_ptr[g] : 0, n1 = graph_ptr ? graph_ptr[g + 1] : N;
+  double s = 0.0;
+  for (int j = n0 + t; j < n1; j += 256) s += (double)gmrow[(size_t)j * heads + h];
+  red[t] = s;
+  if (t == 0) cnt = 0;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  const float gm = (float)red[0], m = gm_f[g * heads + h];
+  if (gm == 0.f) return;   // block-uniform
+  const int e0 = rowptr[n0], e1 = rowptr[n1];
+  int mine = 0;
+  for (int k = e0 + t; k < e1; k += 256) {
+    const float z = st[(size_t)col[k] * H2 + h] + st[(size_t)tgt_e[k] * H2 + heads + h];
+    mine += ((z > 0.f ? z : slope * z) == m) ? 1 : 0;
+  }
+  if (mine) atomicAdd(&cnt, mine);
+  __syncthreads();
+  if (cnt == 0) return;
+  const float share = gm / (float)cnt;   // evenly over ties (torch.max() backward)
+  for (int k = e0 + t; k < e1; k += 256) {
+    const float z = st[(size_t)col[k] * H2 + h] + st[(size_t)tgt_e[k] * H2 + heads + h];
+    if ((z > 0.f ? z : slope * z) == m) {
+      const float v = share * (z > 0.f ? 1.f : slope);
+      gz_e[(size_t)k * heads + h] += v;                       // one writer per edge
+      atomicAdd(gt + (size_t)tgt_e[k] * heads + h, v);        // ties that share a target are the only unordered sum of the layer
+    }
+  }
+}
+
+// ---- per source row over the transposed CSR: gs, gWh ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gatb_source_kernel(const float* __restrict__ ghp, const float* __restrict__ alpha_e,
+                                                          const float* __restrict__ gz_e, const float* __restrict__ gt,
+                                                          const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ eid_s,
+                                                          const int32_t* __restrict__ tgt_e, const float* __restrict__ a, int N, int heads,
+                                                          int Fh, float* __restrict__ gwh, float* __restrict__ gs) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= N) return;
+  const int HF = heads * Fh, nq = HF >> 2, qh = Fh >> 2;
+  const bool on = lane < nq;
+  const int head = on ? lane / qh : 0, cin = on ? lane - head * qh : 0;
+  float gsv = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int p = rowptr_s[i]; p < rowptr_s[i + 1]; ++p) {
+    const int k = eid_s[p], j = tgt_e[k];
+    gsv += gz_e[(size_t)k * heads + head];
+    acc += alpha_e[(size_t)k * heads + head] * *reinterpret_cast<const f32x4*>(ghp + (size_t)j * HF + (on ? lane * 4 : 0));
+  }
+  if (!on) return;
+  const float gtv = gt[(size_t)i * heads + head];
+  const f32x4 as = *reinterpret_cast<const f32x4*>(a + (size_t)head * 2 * Fh + cin * 4);
+  const f32x4 at = *reinterpret_cast<const f32x4*>(a + (size_t)head * 2 * Fh + Fh + cin * 4);
+  *reinterpret_cast<f32x4*>(gwh + (size_t)i * HF + lane * 4) = acc + gsv * as + gtv * at;
+  if (cin == 0) gs[(size_t)i * heads + head] = gsv;
+}
+
+// ---- ga: column sums of gs_i Wh_i and gt_i Wh_i (two levels, fixed order) ------------------------------------------------------
+__global__ __launch_bounds__(256) void gatb_da_partial_kernel(const float* __restrict__ wh, const float* __restrict__ gs,
+                                                              const float* __restrict__ gt, int N, int heads, int Fh, int rows_per_block,
+                                                              float* __restrict__ part) {
+  const int HF = heads * Fh, t = threadIdx.x;
+  if (t >= HF) return;
+  const int head = t / Fh;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+  float ss = 0.f, tt = 0.f;
+  for (int i = r0; i < r1; ++i) {
+    const float w = wh[(size_t)i * HF + t];
+    ss += gs[(size_t)i * heads + head] * w;
+    tt += gt[(size_t)i * heads + head] * w;
+  }
+  part[((size_t)blockIdx.x * 2 + 0) * HF + t] = ss;
+  part[((size_t)blockIdx.x * 2 + 1) * HF + t] = tt;
+}
+__global__ __launch_bounds__(256) void gatb_da_final_kernel(const float* __restrict__ part, int nb, int heads, int Fh, float* __restrict__ da) {
+  const int HF = heads * Fh, t = threadIdx.x;
+  if (t >= HF) return;
+  double ss = 0.0, tt = 0.0;
+  for (int b = 0; b < nb; ++b) ss += (double)part[((size_t)b * 2 + 0) * HF + t], tt += (double)part[((size_t)b * 2 + 1) * HF + t];
+  const int head = t / Fh, f = t - head * Fh;
+  da[(size_t)head * 2 * Fh + f] = (float)ss;        // a = [a_src | a_tgt] per head (graph_attention.py:31,61-64)
+  da[(size_t)head * 2 * Fh + Fh + f] = (float)tt;
+}
+
+}  // namespace mgu
+
+using namespace mgu;
+using namespace mgud;
+
+extern "C" {
+
+int mgu_conv2d_dgrad_nhwc(mgu_ctx* c, const void* dz_dev, const void* w_oihw_dev, int B, int H, int W, int Cin, int Cout, int ksize,
+                          void* din_dev, int ld_out, void* hip_stream);
+int mgu_conv2d_wgrad_nhwc(mgu_ctx* c, const void* in_dev, int ld_in, const void* dz_dev, int B, int H, int W, int Cin, int Cout,
+                          int ksize, void* dw_oihw_dev, void* hip_stream);
+
+int mgu_csr_transpose_device(mgu_ctx* c, const int32_t* rowptr_dev, const int32_t* col_dev, int64_t E, int num_nodes,
+                             int32_t* rowptr_src_dev, int32_t* eid_src_dev, int32_t* tgt_of_edge_dev, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (E < 0 || num_nodes < 1 || E >= (1ll << 31) || !rowptr_dev || !rowptr_src_dev || (E > 0 && (!col_dev || !eid_src_dev || !tgt_of_edge_dev)))
+    return fail(c, MGU_ERR_INVALID, "bad csr_transpose_device args (E < 2^31)");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (E == 0) {
+    HIPCHK(c, hipMemsetAsync(rowptr_src_dev, 0, ((size_t)num_nodes + 1) * sizeof(int32_t), s));
+    return MGU_OK;
+  }
+  int bits = 1;
+  while ((1ll << bits) < num_nodes) ++bits;
+  size_t temp_bytes = 0;
+  HIPCHK(c, rocprim::radix_sort_pairs(nullptr, temp_bytes, (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr, (size_t)E, 0, bits, s));
+  const size_t stride = ((size_t)E * 4 + 255) / 256 * 256;
+  int rc = ensure(c, &c->gws, &c->gws_bytes, 3 * stride + temp_bytes + 256);
+  if (rc) return rc;
+  char* g = (char*)c->gws;
+  int *keys = (int*)g, *vals = (int*)(g + stride), *skeys = (int*)(g + 2 * stride);
+  hipLaunchKernelGGL(gatb_edge_keys_kernel, dim3((num_nodes + 3) / 4), dim3(256), 0, s, rowptr_dev, col_dev, num_nodes, keys, vals,
+                     (int*)tgt_of_edge_dev);
+  // stable LSD radix sort by source: a source's out-edges keep their target-CSR order -> every later sum has a fixed order
+  HIPCHK(c, rocprim::radix_sort_pairs(g + 3 * stride, temp_bytes, keys, skeys, vals, (int*)eid_src_dev, (size_t)E, 0, bits, s));
+  hipLaunchKernelGGL(gatb_rowptr_kernel, dim3((num_nodes + 1 + 255) / 256), dim3(256), 0, s, skeys, E, num_nodes, (int*)rowptr_src_dev);
+  HIPCHK(c, hipGetLastError());
+  return MGU_OK;
+}
+
+int mgu_gat_layer_backward(mgu_ctx* c, const void* X_dev, int N, int Fin, const int32_t* rowptr_dev, const int32_t* col_dev, int64_t E,
+                           const int32_t* rowptr_src_dev, const int32_t* eid_src_dev, const int32_t* tgt_of_edge_dev,
+                           const int32_t* graph_ptr_dev, int num_graphs, const void* W_dev, const void* a_dev, int heads, int Fout_head,
+                           int concat, float alpha, const void* dout_dev, void* dX_dev, void* dW_dev, void* da_dev, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  const int Fh = Fout_head, HF = heads * Fh;
+  if (!X_dev || !rowptr_dev || !W_dev || !a_dev || !dout_dev || !dW_dev || !da_dev || N < 1 || Fin < 4 || (Fin & 3) || heads < 1 || Fh < 4 ||
+      (Fh & 3) || E < 0 || (E > 0 && (!col_dev || !rowptr_src_dev || !eid_src_dev || !tgt_of_edge_dev)))
+    return fail(c, MGU_ERR_INVALID, "bad gat_layer_backward args (Fin, Fout_head multiples of 4)");
+  if (HF > 256) return fail(c, MGU_ERR_INVALID, "gat_layer_backward supports heads * Fout_head <= 256 (got %d x %d)", heads, Fh);
+  if ((int64_t)N * HF >= (1ll << 31)) return fail(c, MGU_ERR_INVALID, "N * heads * Fout_head must be < 2^31");
+  if (num_graphs < 1 || !graph_ptr_dev) num_graphs = 1, graph_ptr_dev = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  // ---- scratch of its own (the GEMM launchers below use the shared building-block scratch) ----
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const int nb = std::max(1, std::min(256, (N + 255) / 256));
+  const int rpb = (N + nb - 1) / nb;
+  const size_t o_wh = take((size_t)N * HF * 4), o_st = take((size_t)N * 2 * heads * 4), o_ng = take((size_t)N * 4),
+               o_gm = take((size_t)num_graphs * heads * 4), o_ghp = take((size_t)N * HF * 4), o_al = take((size_t)std::max<int64_t>(E, 1) * heads * 4),
+               o_gz = take((size_t)std::max<int64_t>(E, 1) * heads * 4), o_gt = take((size_t)N * heads * 4), o_gs = take((size_t)N * heads * 4),
+               o_gmr = take((size_t)N * heads * 4), o_gwh = take((size_t)N * HF * 4), o_part = take((size_t)nb * 2 * HF * 4);
+  int rc = ensure(c, &c->gbws, &c->gbws_bytes, off);
+  if (rc) return rc;
+  char* g = (char*)c->gbws;
+  float *wh = (float*)(g + o_wh), *st = (float*)(g + o_st), *gm_f = (float*)(g + o_gm), *ghp = (float*)(g + o_ghp), *al = (float*)(g + o_al),
+        *gz = (float*)(g + o_gz), *gt = (float*)(g + o_gt), *gs = (float*)(g + o_gs), *gmr = (float*)(g + o_gmr), *gwh = (float*)(g + o_gwh),
+        *part = (float*)(g + o_part);
+  int32_t* node_graph = num_graphs > 1 ? (int32_t*)(g + o_ng) : nullptr;
+  // ---- recompute Wh, s, t and the per-graph max exactly as the forward's gather schedule does ----
+  if ((rc = gat_linear_st(c, (const float*)X_dev, N, Fin, (const float*)W_dev, (const float*)a_dev, heads, Fh, wh, st, s))) return rc;
+  unsigned long long* gmax;
+  unsigned gen;
+  if ((rc = gmax_buffer(c, num_graphs * heads, &gmax, &gen))) return rc;
+  if (node_graph) HIPCHK(c, launch_gat_node_graph(graph_ptr_dev, num_graphs, 0, N, node_graph, s));
+  HIPCHK(c, launch_gat_edge_max(st, rowptr_dev, col_dev, node_graph, N, heads, alpha, gmax, c->gmax_cap, gen, s));
+  hipLaunchKernelGGL(gatb_gmax_decode_kernel, dim3((num_graphs * heads + 63) / 64), dim3(64), 0, s, gmax, num_graphs * heads, gen, gm_f);
+  // ---- attention backward ----
+  hipLaunchKernelGGL(gatb_target_kernel, dim3((N + 3) / 4), dim3(256), 0, s, wh, st, rowptr_dev, col_dev, node_graph, gm_f,
+                     (const float*)dout_dev, N, heads, Fh, concat, alpha, ghp, al, gz, gt, gmr);
+  if (E > 0)
+    hipLaunchKernelGGL(gatb_max_term_kernel, dim3(num_graphs * heads), dim3(256), 0, s, st, rowptr_dev, col_dev, tgt_of_edge_dev, graph_ptr_dev, N,
+                       heads, alpha, gm_f, gmr, gz, gt);
+  if (E > 0) {
+    hipLaunchKernelGGL(gatb_source_kernel, dim3((N + 3) / 4), dim3(256), 0, s, ghp, al, gz, gt, rowptr_src_dev, eid_src_dev, tgt_of_edge_dev,
+                       (const float*)a_dev, N, heads, Fh, gwh, gs);
+  } else {   // no edges: nothing reaches Wh (every output row is ELU(0) = 0)
+    HIPCHK(c, hipMemsetAsync(gwh, 0, (size_t)N * HF * 4, s));
+    HIPCHK(c, hipMemsetAsync(gs, 0, (size_t)N * heads * 4, s));
+  }
+  hipLaunchKernelGGL(gatb_da_partial_kernel, dim3(nb), dim3(256), 0, s, wh, gs, gt, N, heads, Fh, rpb, part);
+  hipLaunchKernelGGL(gatb_da_final_kernel, dim3(1), dim3(256), 0, s, part, nb, heads, Fh, (float*)da_dev);
+  HIPCHK(c, hipGetLastError());
+  // ---- the linear layer: gW = gWh^T X, gX = gWh W (a 1x1 convolution over an N x 1 image) ----
+  if ((rc = mgu_conv2d_wgrad_nhwc(c, X_dev, Fin, gwh, 1, 1, N, Fin, HF, 1, dW_dev, hip_stream))) return rc;
+  if (dX_dev && (rc = mgu_conv2d_dgrad_nhwc(c, gwh, W_dev, 1, 1, N, Fin, HF, 1, dX_dev, Fin, hip_stream))) return rc;
+  return MGU_OK;
+}
+
+}  // extern "C"

@@ -97,6 +97,8 @@ void mgu_destroy(mgu_ctx* c) {
   if (c->arena) (void)hipFree(c->arena);
   if (c->ws) (void)hipFree(c->ws);
   if (c->gws) (void)hipFree(c->gws);
+  if (c->gbws) (void)hipFree(c->gbws);
+  if (c->gbpanel) (void)hipFree(c->gbpanel);
   if (c->tws) (void)hipFree(c->tws);
   if (c->redws) (void)hipFree(c->redws);
   if (c->wuws) (void)hipFree(c->wuws);

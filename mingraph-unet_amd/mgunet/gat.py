@@ -6,6 +6,9 @@ the CSR-by-target the HIP kernels consume is derived once per edge_index tensor 
 All heads of a layer run in ONE kernel sequence (the reference loops over heads in Python,
 graph_attention.py:151).  Eval-mode semantics (dropout = identity); train mode is accepted only with
 dropout_rate == 0, because the reference's train-mode output depends on torch's dropout RNG stream.
+The layers are differentiable: when a parameter or the node features require grad, the call becomes a
+torch.autograd.Function whose backward is mgu_gat_layer_backward (dX, dW, da per head), so the graph
+branch trains under loss.backward() as in scripts/train_end_to_end.py:219-226, :478.
 """
 from __future__ import annotations
 
@@ -141,41 +144,116 @@ def _gat_layer_forward(heads, X, edge_index, concat, alpha, training, dropout_ra
         raise TypeError(f"expected float32 node features, got {X.dtype}")
     if X.dim() != 2:
         raise ValueError("node_features must be (N, F)")
+    if heads[0].W.weight.shape[1] != X.shape[1]:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({X.shape[0]}x{X.shape[1]} and "
+                           f"{heads[0].W.weight.shape[1]}x{heads[0].out_features})")
+    meta = _LayerCall(heads, edge_index, concat, alpha, graph_ptr, cache)
+    params = [t for h in heads for t in (h.W.weight, h.a.weight)]
+    if torch.is_grad_enabled() and (X.requires_grad or any(t.requires_grad for t in params)):
+        # a node of the autograd graph whose backward is mgu_gat_layer_backward (gat_bwd.hip): loss.backward() reaches the GAT
+        # parameters as it does in the reference's loop (scripts/train_end_to_end.py:219-226, :478)
+        return _GatLayerFn.apply(X, meta, *params)
+    return _gat_layer_run(X, meta)[0]
+
+
+class _LayerCall:
+    """The non-tensor arguments of one layer call."""
+
+    def __init__(self, heads, edge_index, concat, alpha, graph_ptr, cache):
+        self.heads, self.edge_index, self.concat, self.alpha, self.graph_ptr, self.cache = heads, edge_index, concat, alpha, graph_ptr, cache
+
+
+def _gat_layer_run(X, m):
+    """The forward through libmgunet; returns (out, saved) with `saved` what a backward needs."""
+    heads, cache = m.heads, m.cache
     dev = X.device
     N, Fin = X.shape
     H = len(heads)
     Fh_true = heads[0].out_features
     Fh = (Fh_true + 3) // 4 * 4   # narrow heads (e.g. the 2-segment predictor) run zero-padded, see stacked_head_weights
     W, a = stacked_head_weights(heads, cache)
-    if heads[0].W.weight.shape[1] != Fin:
-        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({N}x{Fin} and {heads[0].W.weight.shape[1]}x{Fh_true})")
     Xc = X.detach().contiguous()
     if Fin % 4:  # zero-pad K to a multiple of 4: exact (W is padded the same way in stacked_head_weights)
         Xc = F.pad(Xc, (0, 4 - Fin % 4))
+    edge_index = m.edge_index
     key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, N, str(edge_index.device))
     ent = cache.get("csr")
     if ent is None or ent[0] != key:
         rowptr, col = coo_to_csr_device(edge_index.to(dev), N)
         ent = cache["csr"] = (key, rowptr, col, edge_index)  # keep the key tensor alive so data_ptr stays unique
+        cache.pop("csr_t", None)
     rowptr, col = ent[1], ent[2]
-    G, gp_ptr = 1, None
-    if graph_ptr is not None:
-        gp = graph_ptr.to(device=dev, dtype=torch.int32).contiguous()
-        G, gp_ptr = gp.numel() - 1, gp.data_ptr()
-    out = torch.empty((N, H * Fh if concat else Fh), device=dev, dtype=torch.float32)
+    G, gp = 1, None
+    if m.graph_ptr is not None:
+        gp = m.graph_ptr.to(device=dev, dtype=torch.int32).contiguous()
+        G = gp.numel() - 1
+    out = torch.empty((N, H * Fh if m.concat else Fh), device=dev, dtype=torch.float32)
     ctx = _context(dev)
     if W.device != dev:
         raise RuntimeError(f"GAT parameters are on {W.device}, node features on {dev}")
     handle = prepared_head_weights(heads, cache, ctx, dev, col.numel() > 0)
     with torch.cuda.device(dev):
         rc = _lib.lib().mgu_gat_layer_forward_prepared(ctx.handle, handle, Xc.data_ptr(), N, rowptr.data_ptr(),
-                                                       col.data_ptr() if col.numel() else None, col.numel(), gp_ptr, G,
-                                                       1 if concat else 0, float(alpha), out.data_ptr(),
+                                                       col.data_ptr() if col.numel() else None, col.numel(), gp.data_ptr() if gp is not None else None,
+                                                       G, 1 if m.concat else 0, float(m.alpha), out.data_ptr(),
                                                        _lib.current_stream_ptr(dev))
     _lib.check(rc, ctx.handle)
+    saved = (Xc, W, a, rowptr, col, gp, G, Fh, Fh_true, Fin)
     if Fh != Fh_true:
         out = out.view(N, -1, Fh)[:, :, :Fh_true].reshape(N, -1).contiguous()
-    return out
+    return out, saved
+
+
+def _transposed_csr(cache, rowptr, col, N, dev, ctx):
+    """CSR by source of the cached CSR by target (mgu_csr_transpose_device), built once per graph."""
+    ent = cache.get("csr_t")
+    if ent is None or ent[0] is not rowptr:
+        E = col.numel()
+        rp = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        eid = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        tgt = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgu_csr_transpose_device(ctx.handle, rowptr.data_ptr(), col.data_ptr() if E else None, E, N, rp.data_ptr(),
+                                                           eid.data_ptr(), tgt.data_ptr(), _lib.current_stream_ptr(dev)), ctx.handle)
+        ent = cache["csr_t"] = (rowptr, rp, eid, tgt)
+    return ent[1], ent[2], ent[3]
+
+
+class _GatLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx_, X, meta, *params):
+        out, saved = _gat_layer_run(X, meta)
+        ctx_.meta, ctx_.saved = meta, saved
+        return out
+
+    @staticmethod
+    def backward(ctx_, gout):
+        m = ctx_.meta
+        Xc, W, a, rowptr, col, gp, G, Fh, Fh_true, Fin = ctx_.saved
+        heads = m.heads
+        H, N, dev = len(heads), Xc.shape[0], Xc.device
+        g = gout.detach().float()
+        if Fh != Fh_true:   # the padded output features never reach the caller: their gradient is 0
+            g = F.pad(g.view(N, -1, Fh_true), (0, Fh - Fh_true)).reshape(N, -1)
+        g = g.contiguous()
+        ctx = _context(dev)
+        rps, eid, tgt = _transposed_csr(m.cache, rowptr, col, N, dev, ctx)
+        need_x = ctx_.needs_input_grad[0]
+        dX = torch.empty_like(Xc) if need_x else None
+        dW, da = torch.empty_like(W), torch.empty_like(a)
+        E = col.numel()
+        with torch.cuda.device(dev):
+            rc = _lib.lib().mgu_gat_layer_backward(ctx.handle, Xc.data_ptr(), N, Xc.shape[1], rowptr.data_ptr(), col.data_ptr() if E else None, E,
+                                                   rps.data_ptr(), eid.data_ptr(), tgt.data_ptr(), gp.data_ptr() if gp is not None else None, G,
+                                                   W.data_ptr(), a.data_ptr(), H, Fh, 1 if m.concat else 0, float(m.alpha), g.data_ptr(),
+                                                   dX.data_ptr() if need_x else None, dW.data_ptr(), da.data_ptr(),
+                                                   _lib.current_stream_ptr(dev))
+        _lib.check(rc, ctx.handle)
+        grads = []
+        for h in range(H):
+            grads.append(dW[h * Fh:h * Fh + Fh_true, :Fin].contiguous())
+            grads.append(torch.cat([da[h:h + 1, :Fh_true], da[h:h + 1, Fh:Fh + Fh_true]], 1).contiguous())
+        return (dX[:, :Fin].contiguous() if need_x else None, None, *grads)
 
 
 class MultiHeadGATLayer(nn.Module):

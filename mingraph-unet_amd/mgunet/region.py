@@ -91,7 +91,8 @@ def region_stage(patch_feats, hard_labels, B, K, region_gat: GATNetwork, nph, np
             ei = torch.cat([one + K * b for b in range(B)], dim=1)
             gp = torch.arange(B + 1, device=reg.device, dtype=torch.int32) * K
             ent = _REGION_GRAPHS[key] = (ei, gp)
-        emb = region_gat(reg, ent[0], graph_ptr=ent[1])   # :383-384; exp(e - max e) is per graph (graph_attention.py:86)
+        with torch.no_grad():   # this stage produces forward values (the pooling / fuse kernels around it carry no autograd graph)
+            emb = region_gat(reg, ent[0], graph_ptr=ent[1])   # :383-384; exp(e - max e) is per graph (graph_attention.py:86)
     else:
         emb = reg                                                            # :385-387: no edges, unrefined features
     return emb, region_fuse(f_u, emb, hard_labels, B, H, W, nph, npw, K)

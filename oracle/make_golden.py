@@ -7,7 +7,7 @@ weights / inputs of oracle/mgunet_oracle.py, checks that the oracle restatement 
 stores the reference's outputs as small fixtures.  Fixtures hold data only (inputs that are
 not formula-derivable, expected outputs, sample indices) -- never reference source text.
 
-Usage:  python oracle/make_golden.py [--only tiny,gat,graph,mincut,region,dethead,losses,scriptlosses,c1,c2,c4,c5]
+Usage:  python oracle/make_golden.py [--only tiny,gat,gatgrad,graph,mincut,region,dethead,losses,scriptlosses,c1,c2,c4,c5]
 """
 import argparse
 import os
@@ -152,6 +152,64 @@ def gen_gat():
     check("mh_concat", oc, yc)
     out["mhc_out"] = yc.numpy()
     save("gat_small.npz", **out)
+
+
+GATGRAD_CASES = {   # tag: (cfg (in, hidden, out, heads), layers, nodes, graph, x scale, weight scale)
+    "g10": ((32, 64, 16, 4), 1, 10, "edge10", 1.0, 1.0),
+    "iso": ((32, 64, 16, 4), 1, 12, "edge_iso", 1.0, 1.0),
+    "wide": ((32, 64, 16, 2), 1, 10, "edge10", 4.0, 3.0),          # |e| range > 23: the 1e-10 and the graph-wide max bite
+    "mid": ((32, 64, 16, 4), 1, 10, "edge10", 2.0, 1.5),
+    "l2h1": ((32, 24, 8, 1), 2, 10, "edge10", 1.0, 1.0),           # two layers chained (one head: SURVEY G3)
+    "grid": ((32, 128, 64, 4), 1, 256, "grid16", 1.0, 1.0),        # the patch GAT's shape on a 16 x 16 patch grid
+    "pred": ((64, 64, 2, 2), 1, 64, "grid8", 1.0, 1.0),            # the segment predictor's shape (train_end_to_end.py:155-163)
+}
+
+
+def gatgrad_inputs(tag):
+    cfg, layers, N, graph, xs, ws = GATGRAD_CASES[tag]
+    if graph == "edge10":
+        ei = EDGE10
+    elif graph == "edge_iso":
+        ei = np.concatenate([EDGE10, np.array([[10, 10], [0, 3]], dtype=np.int64)], axis=1)
+    else:
+        side = int(graph[4:])
+        ei = O.patch_graph_edges(side * 16, side * 16, 16)
+    X = torch.from_numpy(O.formula_normal(f"gatgrad/{tag}/x", (N, cfg[0]), seed=3)) * xs
+    R = torch.from_numpy(O.formula_normal(f"gatgrad/{tag}/r", (N, cfg[2]), seed=4))     # loss = sum(out * R)
+    p = O.make_gat_params(cfg[0], cfg[1], cfg[2], cfg[3], layers, seed=3, scale=ws)
+    return cfg, layers, torch.from_numpy(np.ascontiguousarray(ei)), X, R, p
+
+
+def gen_gatgrad():
+    print("[gatgrad] gradients of the reference GATNetwork (eval-mode dropout) under torch autograd: d/dX, d/dW, d/da")
+    out = {}
+    for tag in GATGRAD_CASES:
+        cfg, layers, ei, X, R, p = gatgrad_inputs(tag)
+        g = RefGAT(cfg[0], cfg[1], cfg[2], cfg[3], num_gat_layers=layers).eval()
+        g.load_state_dict(p)
+        Xr = X.clone().requires_grad_(True)
+        (g(Xr, ei) * R).sum().backward()
+        # the oracle restatement under autograd
+        q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        Xo = X.clone().requires_grad_(True)
+        (O.gat_network_forward(q, Xo, ei, cfg[3], layers) * R).sum().backward()
+        check(tag + ".dX", Xo.grad, Xr.grad, tol=2e-6 * max(1.0, float(Xr.grad.abs().max())))
+        out[tag + "_dX"] = Xr.grad.numpy()
+        for k, v in g.named_parameters():
+            check(f"{tag}.d{k}", q[k].grad, v.grad, tol=2e-6 * max(1.0, float(v.grad.abs().max())))
+            out[f"{tag}_d_{k}"] = v.grad.numpy()
+        # float64 yardstick from the restatement (the reference class itself is fp32-only: its torch.zeros() calls carry no dtype,
+        # SURVEY appendix A); it says how far the reference's OWN fp32 gradients sit from exact arithmetic (wide-logit case!)
+        q64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
+        X64 = X.double().requires_grad_(True)
+        (O.gat_network_forward(q64, X64, ei, cfg[3], layers) * R.double()).sum().backward()
+        out[tag + "_dX64"] = X64.grad.numpy()
+        for k in q64:
+            out[f"{tag}_d64_{k}"] = q64[k].grad.numpy()
+        dev = float((Xr.grad.double() - X64.grad).abs().max() / (X64.grad.abs().max() + 1e-300))
+        out[tag + "_cond"] = np.float64(dev)
+        print(f"   {tag}: max|dX| {float(Xr.grad.abs().max()):.3e}, reference fp32 vs float64 {dev:.1e}")
+    save("gat_grad.npz", **out)
 
 
 def gen_mincut():
@@ -648,11 +706,11 @@ def gen_c5():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,gat,graph,mincut,region,dethead,losses,scriptlosses,c1,c2,c4,c5")
+    ap.add_argument("--only", default="tiny,gat,gatgrad,graph,mincut,region,dethead,losses,scriptlosses,c1,c2,c4,c5")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    fns = {"tiny": gen_tiny, "gat": gen_gat, "graph": gen_graph, "mincut": gen_mincut, "region": gen_region, "dethead": gen_dethead, "losses": gen_losses, "scriptlosses": gen_scriptlosses, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
+    fns = {"tiny": gen_tiny, "gat": gen_gat, "gatgrad": gen_gatgrad, "graph": gen_graph, "mincut": gen_mincut, "region": gen_region, "dethead": gen_dethead, "losses": gen_losses, "scriptlosses": gen_scriptlosses, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
     for k in a.only.split(","):
         t0 = time.time()
         fns[k]()

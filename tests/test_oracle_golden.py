@@ -233,6 +233,41 @@ def test_aux_losses_and_feature_fusion_branches_vs_reference_fixtures(golden):
     assert torch.equal(O.feature_fusion_full([fu0, fu1], fg2, 12, region_to_pixel_map=rmap), torch.from_numpy(g["ff_regions"]))
 
 
+GATGRAD_CASES = {   # tag: (cfg (in, hidden, out, heads), layers, nodes, graph, x scale, weight scale) -- as oracle/make_golden.py
+    "g10": ((32, 64, 16, 4), 1, 10, "edge10", 1.0, 1.0), "iso": ((32, 64, 16, 4), 1, 12, "edge_iso", 1.0, 1.0),
+    "wide": ((32, 64, 16, 2), 1, 10, "edge10", 4.0, 3.0), "mid": ((32, 64, 16, 4), 1, 10, "edge10", 2.0, 1.5),
+    "l2h1": ((32, 24, 8, 1), 2, 10, "edge10", 1.0, 1.0), "grid": ((32, 128, 64, 4), 1, 256, "grid16", 1.0, 1.0),
+    "pred": ((64, 64, 2, 2), 1, 64, "grid8", 1.0, 1.0)}
+
+
+def gatgrad_inputs(golden, tag):
+    cfg, layers, N, graph, xs, ws = GATGRAD_CASES[tag]
+    if graph in ("edge10", "edge_iso"):
+        ei = golden["gat_small"][graph]
+    else:
+        side = int(graph[4:])
+        ei = O.patch_graph_edges(side * 16, side * 16, 16)
+    X = torch.from_numpy(O.formula_normal(f"gatgrad/{tag}/x", (N, cfg[0]), seed=3)) * xs
+    R = torch.from_numpy(O.formula_normal(f"gatgrad/{tag}/r", (N, cfg[2]), seed=4))
+    p = O.make_gat_params(cfg[0], cfg[1], cfg[2], cfg[3], layers, seed=3, scale=ws)
+    return cfg, layers, torch.from_numpy(np.ascontiguousarray(ei)), X, R, p
+
+
+@pytest.mark.parametrize("tag", list(GATGRAD_CASES))
+def test_gat_gradients_vs_reference_fixture(golden, tag):
+    """d/dX, d/dW, d/da of sum(GATNetwork(X) * R) as the REFERENCE class produced them under torch autograd (eval-mode dropout;
+    tests/golden/gat_grad.npz): the oracle restatement reproduces them, including the gradient through the graph-wide max."""
+    g = golden["gat_grad"]
+    cfg, layers, ei, X, R, p = gatgrad_inputs(golden, tag)
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    Xo = X.clone().requires_grad_(True)
+    (O.gat_network_forward(q, Xo, ei, cfg[3], layers) * R).sum().backward()
+    assert np.abs(Xo.grad.numpy() - g[tag + "_dX"]).max() <= 2e-6 * max(1.0, np.abs(g[tag + "_dX"]).max())
+    for k in q:
+        ref = g[f"{tag}_d_{k}"]
+        assert np.abs(q[k].grad.numpy() - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), k
+
+
 SCRIPT_TV = {"tv_a": ((2, 1, 17, 23), 1.0, 1), "tv_b": ((3, 2, 64, 48), 0.37, 2), "tv_c": ((1, 1, 2, 2), 1.0, 3), "tv_d": ((8, 1, 128, 128), 0.1, 4)}
 SCRIPT_DICE = {"dice_a": (2, 2, 16, 16, 1.0, 2.0, 5), "dice_b": (3, 4, 33, 20, 0.5, 1.0, 6), "dice_c": (1, 2, 128, 128, 1.0, 3.0, 7),
                "dice_d": (2, 3, 8, 8, 1e-3, 8.0, 8)}
