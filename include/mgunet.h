@@ -62,6 +62,12 @@ int64_t mgu_unet_param_count(mgu_ctx* ctx);
  * eval folds bias + BatchNorm running stats (unet_encoder.py:12-13, eps 1e-5) into a per-channel
  * scale/shift applied in the conv epilogue.  Must be re-called after the parameters change. */
 int mgu_unet_load_weights(mgu_ctx* ctx, const mgu_tensor_desc* named, int n, void* hip_stream);
+/* The parameter tensors recorded by the last mgu_unet_load_weights were modified IN PLACE (same addresses: an optimizer step
+ * through the flat parameter buffer, scripts/train_segmentation.py:134): rebuild every packed weight form from them -- one launch
+ * for all Winograd sets (forward and, once the context has trained, data-gradient), the eval BatchNorm fold stays lazy.  The
+ * train step calls this instead of going through the named state_dict again. */
+int mgu_unet_refresh_weights(mgu_ctx* ctx, void* hip_stream);
+
 /* Bytes of library-owned scratch a forward of this shape uses (allocated on first use).  training = 1: the train-mode
  * forward + backward scratch (every layer's pre-activation and activation, gradient temporaries, weight-gradient partial
  * panels: about 1.9 GB at 4 x 3x512x512), a separate allocation from the eval scratch. */

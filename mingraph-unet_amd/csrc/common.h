@@ -99,6 +99,21 @@ hipError_t launch_first_conv(int dtype, const void* in, const float* wf, const f
 // wino_f32.hip: Winograd F(2x2,3x3) for fp32 3x3 layers with Cp % 16 == 0
 size_t wino_u_floats(int Cout, int Cp);
 hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int Cp, int dgrad, int prec, hipStream_t s);
+// several Winograd weight sets in one launch (wino_f32.hip): w (Cout, Cin, 3, 3) [dgrad: roles swapped, see pack_wino_w_kernel]
+struct WinoPackItem {
+  const float* w;
+  float* U;
+  int Cout, Cin, Cp, Np, dgrad;
+  unsigned blk0;   // Np, blk0: filled by the launcher
+};
+constexpr int WINO_PACK_MAX = 40;
+struct WinoPackBatch {
+  int n, prec;
+  unsigned total_blocks;
+  WinoPackItem it[WINO_PACK_MAX];
+};
+bool wino_pack_batch_prepare(WinoPackBatch& b);   // fills Np / blk0 / total_blocks; false if an item cannot be packed
+hipError_t launch_pack_wino_w_multi(const WinoPackBatch* batch_dev, unsigned total_blocks, hipStream_t s);
 bool wino_applicable(const IgemmDesc& d);
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s);
 
@@ -146,6 +161,8 @@ hipError_t launch_bn_finalize_slots(double* slots, int nrows, double* sums, int6
                                     float* run_var, int C, hipStream_t s);
 hipError_t launch_bn_apply_relu(const float* z, const float* scale, const float* shift, float* y, int ldy, int64_t M, int C,
                                 hipStream_t s);
+hipError_t launch_bn_apply_relu_pool(const float* z, const float* scale, const float* shift, float* y, int ldy, float* pooled, int B, int H,
+                                     int W, int C, hipStream_t s);
 hipError_t launch_bn_bwd_reduce(const float* dy, int lddy, const float* fwd_scale, const float* fwd_shift, const float* z, int ldz,
                                 const float* mean, const float* invstd, int64_t M, int C, double* work, double* sums,
                                 float* dbeta, float* dgamma, hipStream_t s);

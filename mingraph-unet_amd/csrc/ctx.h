@@ -25,6 +25,8 @@ struct Layer {
   bool wino = false;     // fp32 3x3 layer with Cp % 16 == 0: Winograd-transformed weights kept in wu
   mutable bool wp_dirty = false;   // direct panel wp not yet rebuilt from w_src (packed on first use)
   float* wu = nullptr;
+  float* wug = nullptr;          // Winograd weights of the layer's DATA-GRADIENT convolution (training; same launch as wu)
+  mutable bool wug_valid = false;   // wug holds the current weights
   float* wf = nullptr;   // first conv (Cp == 4): [9][4][Cout] weights for conv3x3_first_kernel
   // caller-owned parameter tensors recorded by load_weights (used by the training path)
   const float *w_src = nullptr, *b_src = nullptr, *gamma = nullptr, *beta = nullptr;
@@ -47,6 +49,10 @@ struct mgu_ctx {
   mgu::Tuning tn;           // kernel-selection switches of THIS context (MGU_* environment at mgu_create)
   std::string err;
   bool configured = false, loaded = false;
+  std::vector<mgu::WinoPackBatch> pack_host;   // the Winograd pack tables as last uploaded (repack_weights)
+  mgu::WinoPackBatch* pack_dev = nullptr;
+  int pack_dev_cap = 0;
+  bool want_train = false;  // a training forward has run on this context: weight refreshes also build the data-gradient forms
   bool fold_dirty = false;  // BN running stats / affine changed since the eval scale/shift were folded
   int* err_word = nullptr;  // host-mapped word a kernel sets when it meets invalid DATA (e.g. a label out of range): read by
                             // mgu_sync_check and, without a sync, at the entry of the next training call
@@ -194,6 +200,7 @@ int gat_linear_st(mgu_ctx* c, const float* X, int N, int Fin, const float* W, co
 int comm_bucket(mgu_ctx* c, float* flat, int64_t lo, int64_t hi, hipStream_t s);
 int comm_join(mgu_ctx* c, hipStream_t s);
 
+int repack_weights(mgu_ctx* c, hipStream_t s);   // mgunet_api.hip: every packed weight form from the recorded parameter tensors
 // training path (mgunet_train.hip)
 size_t train_ws_bytes(const mgu_ctx* c, int B, int H, int W);
 int unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t xs_c, int64_t xs_h, int64_t xs_w, int B, int H,

@@ -98,6 +98,7 @@ void mgu_destroy(mgu_ctx* c) {
   if (c->ws) (void)hipFree(c->ws);
   if (c->gws) (void)hipFree(c->gws);
   if (c->gbws) (void)hipFree(c->gbws);
+  if (c->pack_dev) (void)hipFree(c->pack_dev);
   if (c->gbpanel) (void)hipFree(c->gbpanel);
   if (c->tws) (void)hipFree(c->tws);
   if (c->redws) (void)hipFree(c->redws);
@@ -178,6 +179,7 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     total += (size_t)L.Np * L.Kp + 2 * (size_t)L.Np + (L.bn.empty() ? 0 : 4 * (size_t)L.Np);
     L.wino = dtype == MGU_DTYPE_F32 && !L.convt && L.KS == 3 && L.Cp % 16 == 0;   // Winograd F(2x2,3x3) layers (wino_f32.hip)
     if (L.wino) total += wino_u_floats(L.Cout, L.Cp);
+    if (L.wino && rup(L.Cout, 4) % 16 == 0) total += wino_u_floats(L.Cin, rup(L.Cout, 4));   // data-gradient conv: roles swapped
     // fp32 ConvTranspose on fragment-ordered three-piece weights (convt_x3.hip).  (A bf16-storage sibling of that kernel -- one
     // fragment per operand straight from global memory -- was measured SLOWER than the LDS-tiled generic kernel, 0.178 vs 0.163 ms per
     // step: 32-byte row segments per K slice; not kept.)
@@ -228,6 +230,8 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     p += L.Np;
     L.wu = nullptr;
     if (L.wino) L.wu = p, p += wino_u_floats(L.Cout, L.Cp);
+    L.wug = nullptr, L.wug_valid = false;
+    if (L.wino && rup(L.Cout, 4) % 16 == 0) L.wug = p, p += wino_u_floats(L.Cin, rup(L.Cout, 4));
     if (L.ctx3) L.wu = p, p += convt_x3_floats(L.Cin, L.Cout);
     L.wf = nullptr;
     if (L.first) L.wf = p, p += 9 * 4 * (size_t)L.Cout;
@@ -290,22 +294,10 @@ int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void*
       if ((rc = get(cw + ".weight", (int64_t)L.Cin * L.Cout * 4, &w))) return rc;
       if ((rc = get(cw + ".bias", L.Cout, &b))) return rc;
       L.w_src = w, L.b_src = b;
-      HIPCHK(c, launch_pack_convt_w(w, L.wp, c->dtype, L.Cin, L.Cout, L.Kp, s));
-      if (L.ctx3) HIPCHK(c, launch_pack_convt_x3(w, L.wu, L.Cin, L.Cout, s));
-      HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 4, s));  // scale unused (nullptr at launch)
     } else {
       if ((rc = get(cw + ".weight", (int64_t)L.Cout * L.Cin * L.KS * L.KS, &w))) return rc;
       if ((rc = get(cw + ".bias", L.Cout, &b))) return rc;
       L.w_src = w, L.b_src = b;
-      // a layer that runs as Winograd / first-conv reads wu / wf; its direct panel is packed lazily, only if a launch
-      // ever falls back to the implicit-GEMM kernel (run_layer)
-      L.wp_dirty = true;
-      if (L.wu) HIPCHK(c, launch_pack_wino_w(w, L.wu, L.Cout, L.Cin, L.Cp, 0, c->tn.wino_prec, s));
-      if (!L.wu && !L.first) {
-        HIPCHK(c, launch_pack_conv_w(w, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
-        L.wp_dirty = false;
-      }
-      if (L.wf) HIPCHK(c, launch_pack_first_w(w, L.wf, L.Cout, L.Cin, s));
       if (!L.bn.empty()) {
         const float *g, *be, *rm, *rv;
         const std::string bn = L.prefix + L.bn;
@@ -314,14 +306,20 @@ int mgu_unet_load_weights(mgu_ctx* c, const mgu_tensor_desc* named, int n, void*
         if ((rc = get(bn + ".running_mean", L.Cout, &rm))) return rc;
         if ((rc = get(bn + ".running_var", L.Cout, &rv))) return rc;
         L.gamma = g, L.beta = be, L.run_mean = const_cast<float*>(rm), L.run_var = const_cast<float*>(rv);
-        c->fold_dirty = true;   // eval scale/shift are folded lazily by the next eval forward (training never reads them)
-      } else {
-        HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 1, s));
       }
     }
   }
+  int rc = repack_weights(c, s);
+  if (rc) return rc;
   c->loaded = true;
   return MGU_OK;
+}
+
+int mgu_unet_refresh_weights(mgu_ctx* c, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!c->configured || !c->loaded) return fail(c, MGU_ERR_STATE, "mgu_unet_refresh_weights needs a preceding mgu_unet_load_weights");
+  HIPCHK(c, hipSetDevice(c->device));
+  return repack_weights(c, (hipStream_t)hip_stream);
 }
 
 int mgu_unet_workspace_bytes(mgu_ctx* c, int B, int H, int W, int training, size_t* out) {
@@ -342,6 +340,64 @@ int mgu_unet_reserve(mgu_ctx* c, int B, int H, int W, int training) {
 }
 
 }  // extern "C"
+
+// Every packed weight form from the parameter tensors recorded by mgu_unet_load_weights (their CONTENTS may have changed: an
+// optimizer step through the flat buffer).  All Winograd sets -- and, once the context has trained, the data-gradient sets --
+// go out in one launch; the eval BatchNorm fold stays lazy.
+int mgud::repack_weights(mgu_ctx* c, hipStream_t s) {
+  std::vector<WinoPackItem> items;
+  for (auto& L : c->layers) {
+    const float *w = L.w_src, *b = L.b_src;
+    if (L.convt) {
+      HIPCHK(c, launch_pack_convt_w(w, L.wp, c->dtype, L.Cin, L.Cout, L.Kp, s));
+      if (L.ctx3) HIPCHK(c, launch_pack_convt_x3(w, L.wu, L.Cin, L.Cout, s));
+      HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 4, s));  // scale unused (nullptr at launch)
+    } else {
+      // a layer that runs as Winograd / first-conv reads wu / wf; its direct panel is packed lazily, only if a launch
+      // ever falls back to the implicit-GEMM kernel (run_layer)
+      L.wp_dirty = true;
+      if (L.wu) items.push_back(WinoPackItem{w, L.wu, L.Cout, L.Cin, L.Cp, 0, 0, 0});
+      L.wug_valid = false;
+      if (L.wug && c->want_train && c->tn.wino_dgrad && c->tn.use_wino) {
+        items.push_back(WinoPackItem{w, L.wug, L.Cin, L.Cout, rup(L.Cout, 4), 0, 1, 0});
+        L.wug_valid = true;
+      }
+      if (!L.wu && !L.first) {
+        HIPCHK(c, launch_pack_conv_w(w, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
+        L.wp_dirty = false;
+      }
+      if (L.wf) HIPCHK(c, launch_pack_first_w(w, L.wf, L.Cout, L.Cin, s));
+      if (!L.bn.empty()) c->fold_dirty = true;   // eval scale/shift are folded lazily by the next eval forward (training never reads them)
+      else HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 1, s));
+    }
+  }
+  // batches of <= WINO_PACK_MAX items; the tables are uploaded only when they differ from what the device already holds (a
+  // refresh after an optimizer step finds them unchanged: same tensors, same buffers)
+  std::vector<WinoPackBatch> batches;
+  for (size_t i0 = 0; i0 < items.size(); i0 += WINO_PACK_MAX) {
+    WinoPackBatch b;
+    memset(&b, 0, sizeof b);
+    b.n = (int)std::min<size_t>(WINO_PACK_MAX, items.size() - i0), b.prec = c->tn.wino_prec;
+    for (int i = 0; i < b.n; ++i) b.it[i] = items[i0 + i];
+    if (!wino_pack_batch_prepare(b)) return fail(c, MGU_ERR_STATE, "internal: a Winograd layer is not packable");
+    batches.push_back(b);
+  }
+  const bool same = batches.size() == c->pack_host.size() &&
+                    (batches.empty() || memcmp(batches.data(), c->pack_host.data(), batches.size() * sizeof(WinoPackBatch)) == 0);
+  if (!same) {
+    if ((int)batches.size() > c->pack_dev_cap) {
+      if (c->pack_dev) HIPCHK(c, hipFree(c->pack_dev));
+      c->pack_dev = nullptr;
+      HIPCHK(c, hipMalloc((void**)&c->pack_dev, batches.size() * sizeof(WinoPackBatch)));
+      c->pack_dev_cap = (int)batches.size();
+    }
+    HIPCHK(c, hipStreamSynchronize(s));   // an earlier launch may still read the old table
+    HIPCHK(c, hipMemcpy(c->pack_dev, batches.data(), batches.size() * sizeof(WinoPackBatch), hipMemcpyHostToDevice));
+    c->pack_host = batches;
+  }
+  for (size_t k = 0; k < batches.size(); ++k) HIPCHK(c, launch_pack_wino_w_multi(c->pack_dev + k, batches[k].total_blocks, s));
+  return MGU_OK;
+}
 
 int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int B, int H, int W, void* out_v, int ldout,
                     int coff, int relu, const float* scale, const float* shift, int Hout, int Wout, hipStream_t s,

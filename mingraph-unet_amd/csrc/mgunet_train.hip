@@ -86,7 +86,7 @@ inline float* at(mgu_ctx* c, size_t off) { return (float*)((char*)c->tws + off);
 
 // conv (+bias) -> z ; batch statistics ; y = relu(bn(z)) written with pitch ldy
 int conv_bn_relu_train(mgu_ctx* c, Layer& L, const float* in, int ldin, int B, int H, int W, float* z, float* y, int ldy,
-                       double* sums, double* red, hipStream_t s) {
+                       double* sums, double* red, hipStream_t s, float* pooled = nullptr, bool* pool_done = nullptr) {
   const int64_t M = (int64_t)B * H * W;
   const int C = L.Cout;
   bool stats_done = false;   // Winograd layers accumulate sum z / sum z^2 in the conv epilogue
@@ -100,7 +100,13 @@ int conv_bn_relu_train(mgu_ctx* c, Layer& L, const float* in, int ldin, int B, i
     HIPCHK(c, launch_bn_finalize(sums, sums + C, M, 1e-5f, 0.1f, L.gamma, L.beta, L.mean, L.invstd, L.tscale, L.tshift,
                                  L.run_mean, L.run_var, C, s));
   }
-  HIPCHK(c, launch_bn_apply_relu(z, L.tscale, L.tshift, y, ldy, M, C, s));
+  if (pool_done) *pool_done = false;
+  if (pooled && !(H & 1) && !(W & 1)) {   // MaxPool2d(2) of y in the same pass (even sizes: windows tile the image)
+    HIPCHK(c, launch_bn_apply_relu_pool(z, L.tscale, L.tshift, y, ldy, pooled, B, H, W, C, s));
+    if (pool_done) *pool_done = true;
+  } else {
+    HIPCHK(c, launch_bn_apply_relu(z, L.tscale, L.tshift, y, ldy, M, C, s));
+  }
   L.t_in = in, L.t_ldin = ldin, L.t_z = z, L.t_y = y, L.t_ldy = ldy, L.t_B = B, L.t_H = H, L.t_W = W;
   return MGU_OK;
 }
@@ -150,11 +156,18 @@ int conv_dgrad(Bwd& w, const Layer& L, const float* dz, float* out, int ldout) {
   d.Cp = Cop, d.ldin = L.Cout == Cop ? L.Cout : Cop, d.KS = L.KS, d.K = Kd, d.Kp = Kpd;
   d.N = L.Cin, d.ldout = ldout;
   if (c->tn.wino_dgrad && L.wino && L.KS == 3 && Cop % 16 == 0 && c->tn.use_wino) {   // same Winograd kernel, weights flipped + transposed
-    d.wu = w.wug;
+    d.wu = L.wug ? L.wug : w.wug;
   }
-  // only the weight form the chosen kernel reads is built: Winograd U or the direct flipped/transposed panel
-  if (wino_applicable(d)) HIPCHK(c, launch_pack_wino_w(L.w_src, w.wug, L.Cin, L.Cout, Cop, 1, c->tn.wino_prec, w.s));
-  else HIPCHK(c, launch_pack_dgrad_w(L.w_src, w.dgp, L.Cout, L.Cin, Cop, L.KS, Kpd, w.s));
+  // only the weight form the chosen kernel reads is built: Winograd U (normally already packed with all the others by the last
+  // weight refresh, repack_weights) or the direct flipped/transposed panel
+  if (wino_applicable(d)) {
+    if (!(L.wug && L.wug_valid)) {
+      HIPCHK(c, launch_pack_wino_w(L.w_src, const_cast<float*>(d.wu), L.Cin, L.Cout, Cop, 1, c->tn.wino_prec, w.s));
+      if (L.wug) L.wug_valid = true;
+    }
+  } else {
+    HIPCHK(c, launch_pack_dgrad_w(L.w_src, w.dgp, L.Cout, L.Cin, Cop, L.KS, Kpd, w.s));
+  }
   {
     const double alg = 2.0 * d.M * (double)L.KS * L.KS * L.Cin * L.Cout;
     const bool wn = wino_applicable(d);
@@ -209,6 +222,8 @@ int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t x
       return fail(c, MGU_ERR_STATE, "training needs the parameter tensors recorded by mgu_unet_load_weights");
   const TPlan p = plan_train(c, B, H, W);
   c->have_train_fwd = false;
+  c->want_train = true;    // from now on a weight refresh also packs the data-gradient Winograd sets (repack_weights)
+  c->fold_dirty = true;    // this forward updates the BatchNorm running statistics in place: the eval fold is stale
   int rc = ensure(c, &c->tws, &c->tws_bytes, p.total);
   if (rc) return rc;
   if ((rc = ensure_red(c))) return rc;
@@ -232,9 +247,12 @@ int mgud::unet_forward_train(mgu_ctx* c, const float* x, int64_t xs_n, int64_t x
     const int C = c->feat << i, li = 2 * i;
     float* cat = (float*)cat_dev[i];
     if ((rc = conv_bn_relu_train(c, c->layers[li], cur, ld, B, hs[i], ws[i], at(c, p.z[li]), at(c, p.y1[li]), C, sums, red, s))) return rc;
-    if ((rc = conv_bn_relu_train(c, c->layers[li + 1], at(c, p.y1[li]), C, B, hs[i], ws[i], at(c, p.z[li + 1]), cat, 2 * C, sums, red, s))) return rc;
     float* pooled = at(c, p.pooled[i]);
-    HIPCHK(c, launch_maxpool2(cat, 2 * C, pooled, 0, B, hs[i], ws[i], C, s));
+    bool pooled_done = false;
+    if ((rc = conv_bn_relu_train(c, c->layers[li + 1], at(c, p.y1[li]), C, B, hs[i], ws[i], at(c, p.z[li + 1]), cat, 2 * C, sums, red, s, pooled,
+                                 &pooled_done)))
+      return rc;
+    if (!pooled_done) HIPCHK(c, launch_maxpool2(cat, 2 * C, pooled, 0, B, hs[i], ws[i], C, s));
     c->t_cat[i] = cat, c->t_pooled[i] = pooled;
     cur = pooled, ld = C;
   }

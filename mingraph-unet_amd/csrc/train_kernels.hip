@@ -296,6 +296,44 @@ __global__ void bn_apply_relu_kernel(const float* __restrict__ z, const float* _
   }
 }
 
+// the same with MaxPool2d(2) (unet_encoder.py:48) of y in the same pass: a thread owns a 2 x 2 window of one channel quad
+// (even H and W: every pixel belongs to exactly one window); saves the pool kernel's re-read of y
+__global__ void bn_apply_relu_pool_kernel(const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
+                                          float* __restrict__ y, int ldy, float* __restrict__ pooled, int B, int H, int W, int C) {
+  const int q = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const int64_t total = (int64_t)B * Ho * Wo * q;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % q) * 4;
+    int64_t r = i / q;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho), n = (int)(r / Ho);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c0);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c0);
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};   // ReLU outputs are >= 0
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int64_t pix = ((int64_t)n * H + 2 * yo + dy) * W + 2 * xo + dx;
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + pix * C + c0);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaxf(zv[j] * sc[j] + sh[j], 0.f), m[j] = fmaxf(m[j], o[j]);
+        *reinterpret_cast<f32x4*>(y + pix * ldy + c0) = o;
+      }
+    *reinterpret_cast<f32x4*>(pooled + (((int64_t)n * Ho + yo) * Wo + xo) * C + c0) = m;
+  }
+}
+
+hipError_t launch_bn_apply_relu_pool(const float* z, const float* scale, const float* shift, float* y, int ldy, float* pooled, int B, int H,
+                                     int W, int C, hipStream_t s) {
+  if ((H & 1) || (W & 1) || (C & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bn_apply_relu_pool_kernel, dim3(nblk((int64_t)B * (H >> 1) * (W >> 1) * (C >> 2), 256)), dim3(256), 0, s, z, scale,
+                     shift, y, ldy, pooled, B, H, W, C);
+  return hipGetLastError();
+}
+
 hipError_t launch_bn_apply_relu(const float* z, const float* scale, const float* shift, float* y, int ldy, int64_t M, int C,
                                 hipStream_t s) {
   hipLaunchKernelGGL(bn_apply_relu_kernel, dim3(nblk(M * (C >> 2), 256)), dim3(256), 0, s, z, scale, shift, y, ldy, M, C);
@@ -517,28 +555,46 @@ hipError_t launch_unpack_conv_grad(const float* dwp, int groups, size_t panel_st
   return hipGetLastError();
 }
 // convT: partial panels [groups][Cin][Kp], k = q*Cout + co  ->  (Cin, Cout, 2, 2), the panels added in a fixed order.
-// Thread -> panel element (ci, k) with k fastest, so the reads of every partial panel are coalesced.
-__global__ void unpack_convt_grad_kernel(const float* __restrict__ dwp, int groups, size_t panel_stride, float* __restrict__ g, int Cin,
-                                         int Cout, int Kp) {
+// Same shape as unpack_conv_grad_kernel: a workgroup owns 32 consecutive panel elements (128-byte coalesced reads of every
+// partial panel) and splits the group loop over 8 slices with four loads in flight each -- the thin ConvTranspose layers write
+// ~1000 partial panels (pixel splits are their only parallelism), and a thread per element summing them one after the other
+// took 123 us on the shallowest layer.
+__global__ __launch_bounds__(256) void unpack_convt_grad_kernel(const float* __restrict__ dwp, int groups, size_t panel_stride,
+                                                                float* __restrict__ g, int Cin, int Cout, int Kp) {
+  __shared__ float part[8][32];
   const int K = 4 * Cout;
   const int64_t total = (int64_t)Cin * K;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i % K), ci = (int)(i / K);
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (int64_t i0 = (int64_t)blockIdx.x * 32; i0 < total; i0 += (int64_t)gridDim.x * 32) {
+    const int64_t i = i0 + e;
+    const bool ok = i < total;
+    const int k = ok ? (int)(i % K) : 0, ci = ok ? (int)(i / K) : 0;
     const float* p = dwp + (int64_t)ci * Kp + k;
-    float s0 = 0.f, s1 = 0.f;
-    int q = 0;
-    for (; q + 1 < groups; q += 2) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int q = sl;
+    for (; q + 24 < groups; q += 32) {   // 4 independent loads in flight
       s0 += p[(size_t)q * panel_stride];
-      s1 += p[(size_t)(q + 1) * panel_stride];
+      s1 += p[(size_t)(q + 8) * panel_stride];
+      s2 += p[(size_t)(q + 16) * panel_stride];
+      s3 += p[(size_t)(q + 24) * panel_stride];
     }
-    if (q < groups) s0 += p[(size_t)q * panel_stride];
-    const int tap = k / Cout, co = k - tap * Cout;
-    g[((int64_t)ci * Cout + co) * 4 + tap] = s0 + s1;
+    for (; q < groups; q += 8) s0 += p[(size_t)q * panel_stride];
+    part[sl][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && ok) {
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += part[j][e];
+      const int tap = k / Cout, co = k - tap * Cout;
+      g[((int64_t)ci * Cout + co) * 4 + tap] = sum;
+    }
+    __syncthreads();
   }
 }
 hipError_t launch_unpack_convt_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cin, int Cout, int Kp, hipStream_t s) {
-  hipLaunchKernelGGL(unpack_convt_grad_kernel, dim3(nblk((int64_t)Cin * Cout * 4, 256)), dim3(256), 0, s, dwp, groups, panel_stride, g, Cin,
-                     Cout, Kp);
+  int64_t blocks = ((int64_t)Cin * Cout * 4 + 31) / 32;
+  if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(unpack_convt_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dwp, groups, panel_stride, g, Cin, Cout, Kp);
   return hipGetLastError();
 }
 

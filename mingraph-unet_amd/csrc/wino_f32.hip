@@ -87,10 +87,68 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 //
 // prec = 1 (three bf16 pieces):  Ux[ntile][cin/16][i*4+j][piece][lane (h = lane>>5, r = lane&31)][e]  (uint16),
 // cout = 32*ntile + r, cin = 16*(cin/16) + 8*h + e: the B fragment of v_mfma_f32_32x32x16_bf16, one 16-byte lane load.
-__global__ void pack_wino_w_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Cp, int Np,
-                                   int dgrad, int prec) {
+__device__ __forceinline__ void pack_wino_w_body(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Cp, int Np,
+                                                 int dgrad, int prec, unsigned vblock, unsigned vgrid) {
+  if (prec == 1) {
+    // Three-piece layout, store-coalesced: a thread owns output channel n and EIGHT consecutive input channels, i.e. one whole
+    // 16-byte lane entry of every (component, piece) fragment; lane & 31 = n & 31 and lane >> 5 = the 8-channel half, so a wave's
+    // store instruction writes one contiguous 1-KB fragment (a thread per (n, c) wrote 2-byte pieces 1 KB apart: 1.1 TB/s on the
+    // 164 MB a train step re-packs).
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const int nC = Cp >> 4;
+    const int64_t total8 = (int64_t)Np * (Cp >> 3);
+    for (int64_t idx = vblock * (int64_t)blockDim.x + threadIdx.x; idx < total8; idx += (int64_t)vgrid * blockDim.x) {
+      const int lane = (int)(idx & 63);
+      const int64_t grp = idx >> 6;
+      const int c16 = (int)(grp % nC), ntile = (int)(grp / nC);
+      const int n = ntile * 32 + (lane & 31), c0 = c16 * 16 + (lane >> 5) * 8;
+      float g[8][3][3];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+          for (int v = 0; v < 3; ++v) {
+            const int c = c0 + e;
+            float x = 0.f;
+            if (n < Cout && c < Cin)
+              x = dgrad ? w[(((int64_t)c * Cout + n) * 3 + (2 - u)) * 3 + (2 - v)] : w[(((int64_t)n * Cin + c) * 3 + u) * 3 + v];
+            g[e][u][v] = x;
+          }
+      u32x4_t* dst = reinterpret_cast<u32x4_t*>(U) + ((int64_t)ntile * nC + c16) * 16 * 192 + lane;   // [comp][piece][64 lanes] x 16 B
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          unsigned short p0[8], p1[8], p2[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t3[3];   // row i of G g: t[i][v]
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+              t3[v] = i == 0 ? g[e][0][v] : i == 3 ? g[e][2][v] : 0.5f * (g[e][0][v] + (i == 1 ? g[e][1][v] : -g[e][1][v]) + g[e][2][v]);
+            const float uv = j == 0 ? t3[0] : j == 3 ? t3[2] : 0.5f * (t3[0] + (j == 1 ? t3[1] : -t3[1]) + t3[2]);
+            const unsigned b0 = __float_as_uint(uv) & 0xffff0000u;
+            const float r1 = uv - __uint_as_float(b0);               // exact
+            const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(b1);               // exact; 8 significant bits are left
+            p0[e] = (unsigned short)(b0 >> 16), p1[e] = (unsigned short)(b1 >> 16), p2[e] = (unsigned short)(__float_as_uint(r2) >> 16);
+          }
+          u32x4_t q0, q1, q2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            q0[e] = (unsigned)p0[2 * e] | ((unsigned)p0[2 * e + 1] << 16);
+            q1[e] = (unsigned)p1[2 * e] | ((unsigned)p1[2 * e + 1] << 16);
+            q2[e] = (unsigned)p2[2 * e] | ((unsigned)p2[2 * e + 1] << 16);
+          }
+          u32x4_t* q = dst + (i * 4 + j) * 192;
+          q[0] = q0, q[64] = q1, q[128] = q2;
+        }
+    }
+    return;
+  }
   const int64_t total = (int64_t)Np * Cp;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t idx = vblock * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)vgrid * blockDim.x) {
     const int c = (int)(idx % Cp), n = (int)(idx / Cp);
     float g[3][3];
 #pragma unroll
@@ -147,8 +205,44 @@ __global__ void pack_wino_w_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
+__global__ void pack_wino_w_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin, int Cp, int Np,
+                                   int dgrad, int prec) {
+  pack_wino_w_body(w, U, Cout, Cin, Cp, Np, dgrad, prec, blockIdx.x, gridDim.x);
+}
+
+// Every Winograd weight set of a model in ONE launch (a train step re-packs 17 forward + 17 data-gradient sets after each
+// optimizer step: 34 launches of ~5 us, most of them smaller than a launch gap).  The item table lives in device memory (the launcher uploads it when it changes: a
+// 1.6 KB by-value kernel argument cost ~100 us of host time per launch).
+__global__ void pack_wino_w_multi_kernel(const WinoPackBatch* __restrict__ bp) {
+  const WinoPackBatch& b = *bp;
+  int i = 0;
+  while (i + 1 < b.n && blockIdx.x >= b.it[i + 1].blk0) ++i;   // <= 40 items: a linear scan of the block prefix
+  const WinoPackItem& t = b.it[i];
+  const unsigned vgrid = (i + 1 < b.n ? b.it[i + 1].blk0 : b.total_blocks) - t.blk0;
+  pack_wino_w_body(t.w, t.U, t.Cout, t.Cin, t.Cp, t.Np, t.dgrad, b.prec, blockIdx.x - t.blk0, vgrid);
+}
+
 // n tiles padded to pairs; 6 bytes per value in the three-piece layout (sized for either)
 size_t wino_u_floats(int Cout, int Cp) { return (size_t)((Cout + 63) / 64 * 64) * Cp * 24; }
+
+// fills the launcher-owned fields of a batch (Np, block prefix); false if an item is not packable
+bool wino_pack_batch_prepare(WinoPackBatch& b) {
+  unsigned blk = 0;
+  for (int i = 0; i < b.n; ++i) {
+    WinoPackItem& t = b.it[i];
+    if (t.Cp & (b.prec ? 15 : 7)) return false;
+    t.Np = (t.Cout + 63) / 64 * 64;
+    t.blk0 = blk;
+    blk += (unsigned)std::min<int64_t>(2048, ((int64_t)t.Np * t.Cp / (b.prec ? 8 : 1) + 255) / 256);
+  }
+  b.total_blocks = blk;
+  return true;
+}
+hipError_t launch_pack_wino_w_multi(const WinoPackBatch* batch_dev, unsigned total_blocks, hipStream_t s) {
+  if (total_blocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_wino_w_multi_kernel, dim3(total_blocks), dim3(256), 0, s, batch_dev);
+  return hipGetLastError();
+}
 
 hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int Cp, int dgrad, int prec, hipStream_t s) {
   if (Cp & (prec ? 15 : 7)) return hipErrorInvalidValue;

@@ -46,6 +46,7 @@ _PROTOS = {
     "mgu_unet_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mgu_unet_param_count": (C.c_int64, [C.c_void_p]),
     "mgu_unet_load_weights": (C.c_int, [C.c_void_p, C.POINTER(TensorDesc), C.c_int, C.c_void_p]),
+    "mgu_unet_refresh_weights": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mgu_unet_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "mgu_unet_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mgu_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,

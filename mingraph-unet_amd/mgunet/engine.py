@@ -63,6 +63,7 @@ class MinGraphUNetE2E(nn.Module):
         self.segment_predictor, self.mincut, self.region_gat, self.detection_head = segment_predictor, mincut, region_gat, detection_head
         self.num_segments = num_segments
 
+    @torch.no_grad()   # a pipeline of forward values (the pooling / cut / fuse kernels between the modules carry no autograd graph)
     def forward(self, x):
         from .region import region_stage
         B, _, H, W = x.shape
@@ -389,7 +390,7 @@ class Trainer:
                                                 self.exp_avg_sq.data_ptr(), self.flat.numel(), self.lr, self.betas[0],
                                                 self.betas[1], self.eps, self.wd, self.step_count, grad_scale,
                                                 _lib.current_stream_ptr(dev)), ctx.handle)
-        model.mark_parameters_changed()
+        model.refresh_packed_weights(dev)   # same tensors, new contents: repack in place (no state_dict round trip per step)
 
     def train_step(self, images: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
         if self._rccl:   # the only data-path collective of the build, issued from inside backward

@@ -137,7 +137,7 @@ class UNet(nn.Module):
 
     def _sync_weights(self, ctx, device) -> None:
         tensors = self._named_tensors()
-        sig = tuple((v.data_ptr(), v._version) for _, v in tensors)
+        sig = tuple((v.data_ptr(), v._version) for _, v in tensors if v.dtype.is_floating_point)   # not num_batches_tracked
         if self._loaded_sig.get(ctx.key) == sig:
             return
         descs, keep = [], []
@@ -156,9 +156,20 @@ class UNet(nn.Module):
         self._loaded_sig[ctx.key] = sig
 
     def mark_parameters_changed(self) -> None:
-        """Parameters/buffers were modified behind torch's back (Adam step or BN running stats written by
-        the library through raw pointers): repack on the next forward."""
+        """Parameters/buffers were modified behind torch's back (through raw pointers, without a version bump): hand the whole
+        state_dict to the library again on the next forward."""
         self._loaded_sig.clear()
+
+    def refresh_packed_weights(self, device) -> None:
+        """The parameter tensors the library already knows were updated IN PLACE (the Trainer's Adam kernel writes the flat
+        buffer they are views of): rebuild the packed weight forms from the recorded pointers (mgu_unet_refresh_weights: one
+        launch for all Winograd sets) instead of a full mgu_unet_load_weights.  Falls back to the full path if this context
+        has not been loaded yet."""
+        ctx = self._context(device)
+        if self._loaded_sig.get(ctx.key) is None:
+            return
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().mgu_unet_refresh_weights(ctx.handle, _lib.current_stream_ptr(device)), ctx.handle)
 
     def _bn_counters(self):
         return [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
@@ -208,8 +219,8 @@ class UNet(nn.Module):
         if self.training:
             # the library updated running_mean/var in place through raw pointers: bump the counters the
             # reference's BatchNorm bumps (num_batches_tracked) and drop the folded eval scale/shift
+            # (the library marks its own folded eval scale / shift stale: nothing has to be re-sent through the state_dict)
             torch._foreach_add_(self._bn_counters(), 1)
-            self.mark_parameters_changed()
             self._train_outputs = (logits, cats, feats)  # kept alive for mgu_unet_backward
         skips = [cats[i].permute(0, 3, 1, 2)[:, : (f << i)] for i in range(d)]
         return logits.permute(0, 3, 1, 2), skips, [t.permute(0, 3, 1, 2) for t in feats]
