@@ -218,7 +218,7 @@ hipError_t launch_gat_node_graph(const int32_t* gp, int G, int nodes_per_graph, 
 hipError_t launch_gat_edge_max(const float* st, const int32_t* rowptr, const int32_t* col, const int32_t* node_graph, int N,
                                int heads, float alpha, unsigned long long* gmax_enc, int gstride, unsigned gen, hipStream_t s);
 hipError_t launch_gat_aggregate(const float* wh, int P, const float* st, const int32_t* rowptr, const int32_t* col,
-                                const int32_t* node_graph, const unsigned long long* gmax_enc, int N, int heads, int Fh, int concat,
-                                float alpha, float* out, int gstride, unsigned gen, hipStream_t s);
+                                const int32_t* node_graph, const unsigned long long* gmax_enc, int N, int64_t E, int heads, int Fh,
+                                int concat, float alpha, float* out, int gstride, unsigned gen, hipStream_t s);
 
 }  // namespace mgu

@@ -146,16 +146,18 @@ hipError_t launch_gat_edge_max(const float* st, const int32_t* rowptr, const int
 // reduction by a wave-uniform row index).  The head mean is staged through a per-wave LDS row.  Workgroup
 // ids are remapped so each XCD (private 4 MiB L2) works on a contiguous range of rows: neighbouring patch
 // rows (j +- 1, j +- npw) then hit the same L2 instead of being re-fetched by other XCDs.
-template <int NCH>
+// DENSE: also compile the 2 x 8 batch of the lane-parallel fast path (graphs with more than 4 in-edges per node on average); the
+// sparse instantiation stays at 92 registers = 5 waves per SIMD, which the patch grids need (26.4 -> 23.6 us at 64 graphs)
+template <int NCH, bool DENSE = false>
 __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restrict__ wh, int P, const float* __restrict__ st,
                                                             const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col,
                                                             const int32_t* __restrict__ node_graph,
                                                             const gmax_t* __restrict__ gmax, int N, int heads, int Fh,
                                                             int concat, float alpha, float* __restrict__ out, int gstride, unsigned gen) {
-  constexpr int R = 4;    // rows (one CSR segment) per wavefront
+  constexpr int R = 4;    // rows (one CSR segment) per wavefront (8 rows = two 4 x 4 batches per wave measured no faster: 24.7 vs 23.6 us)
   constexpr int EB = 8;   // row gathers in flight per lane
-  __shared__ __attribute__((aligned(16))) float stage[4][NCH == 1 ? 4 * 256 : NCH * 256];   // NCH 1: room for a wave's four rows
+  __shared__ __attribute__((aligned(16))) float stage[4][NCH == 1 ? 4 * 256 + 64 : NCH * 256];   // NCH 1: a wave's four rows + its 64 softmax weights
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // XCD-aware bijective remap of the workgroup id (blocks b, b+8, ... share an XCD)
@@ -188,6 +190,119 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
   // once by the whole wave; a lane then keeps the value of the head its channels belong to
   const int gs0 = node_graph ? node_graph[j0] : 0, gs1 = node_graph ? node_graph[min(j0 + R - 1, N - 1)] : 0;
   const bool seg_one_graph = gs0 == gs1;
+
+  // ---- fast path, lane-parallel attention (every patch-graph segment): all R rows have <= 4 in-edges, lie in one graph, and
+  // the layer has <= 4 heads -----------------------------------------------------------------------------------------------------
+  // The kernel is instruction-issue bound (rocprofv3, 64 graphs: 653 VALU + 364 SALU per 4-row segment, 34 % of the wave cycles
+  // issuing, and the same 0.49 ns per node whether the node table sits in L2, in the Infinity Cache or in HBM).  Most of those
+  // instructions were REDUNDANT: the softmax weight x = exp(LeakyReLU(s + t) - max) of an (edge, head) pair was evaluated by all
+  // 16 lanes that hold the head's channels, for each of the 16 (row, edge slot) pairs -- 16 x 16 evaluations per lane where the
+  // segment has 64 distinct values.  Here lane (head h = lane / 16, pair p = lane % 16 = row * 4 + slot) evaluates ITS value
+  // once (one scalar gather of s, one exp), the 64 weights go through a 256-byte LDS line, and each channel lane reads the 16
+  // weights of its head back with four 16-byte reads.  The per-graph max is reduced inside the 16-lane row of a head (four DPP
+  // steps over 4 x 16 slots) instead of four full-wave reductions.
+  if constexpr (NCH == 1)
+  if (heads <= 4 && seg_one_graph && j0 + R <= N && ne <= 64) {
+    int s0r[R], dg[R], dmax = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      s0r[r] = __builtin_amdgcn_readlane(rpv, r) - start;
+      dg[r] = __builtin_amdgcn_readlane(rpv, r + 1) - start - s0r[r];
+      dmax = max(dmax, dg[r]);
+    }
+    // a batch = RB rows x K edge slots = 16 (row, slot) pairs per head: 4 x 4 (the patch grids) or 2 x 8 (denser graphs, e.g. the
+    // in-degree-8 stress graphs of BASELINE configs[3]), two batches per segment in the latter case
+    auto fast = [&](auto rb_c, auto k_c) {
+      constexpr int RB = decltype(rb_c)::value, K = decltype(k_c)::value;
+      static_assert(RB * K == 16, "16 pairs per head");
+      float* const xs = &stage[wave][4 * 256];        // 64 weights behind this wave's (<= 4) head-mean rows
+      // max of head hh over its 64 slots: 4 slots per lane of the head's 16-lane row, then a row reduction (once per segment)
+      const int ph = lane >> 4, pp = lane & 15, pr = pp / K, pk = pp % K;
+      const int hh = min(ph, heads - 1);
+      unsigned um = 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const gmax_t w = gmax[(size_t)(gs0 * heads + hh) * GMAX_SLOTS + q * 16 + pp];
+        um = max(um, (unsigned)(w >> 32) == gen ? (unsigned)w : 0u);
+      }
+      um = max(um, (unsigned)__builtin_amdgcn_update_dpp(0, (int)um, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+      um = max(um, (unsigned)__builtin_amdgcn_update_dpp(0, (int)um, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+      um = max(um, (unsigned)__builtin_amdgcn_update_dpp(0, (int)um, 0x141, 0xF, 0xF, true));   // row_half_mirror
+      um = max(um, (unsigned)__builtin_amdgcn_update_dpp(0, (int)um, 0x140, 0xF, 0xF, true));   // row_mirror
+      const float pgm = um ? gat_dec_ordered(um) : -INFINITY;
+#pragma unroll
+      for (int rb = 0; rb < R; rb += RB) {
+        // -- producer: lane (h, p) evaluates the weight of pair p = (row rb + pr, slot pk) for head h --
+        const int ra = rb + pr;
+        int pdg = dg[rb], ps0 = s0r[rb];
+#pragma unroll
+        for (int r = 1; r < RB; ++r) pdg = pr == r ? dg[rb + r] : pdg, ps0 = pr == r ? s0r[rb + r] : ps0;
+        // (the shuffle runs UNCONDITIONALLY: inside `pdg > 0 ? ... : j0` hipcc branches around it, and a ds_bpermute under a
+        //  partial EXEC mask cannot read the lanes that are switched off -- exactly the lanes of an empty row, which hold ids)
+        const int pany = __shfl(seg_ids, ps0 + min(pk, max(pdg, 1) - 1));
+        const int psrc = pdg > 0 ? pany : j0;                                      // slots past the degree re-read the last neighbour
+        const float psv = st[(unsigned)(psrc * H2) + hh];
+        const float ptj = st[(size_t)(j0 + ra) * H2 + heads + hh];
+        float pev = psv + ptj;
+        pev = pev > 0.f ? pev : alpha * pev;                                        // LeakyReLU (:65)
+        if (rb) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");             // the previous batch's reads of xs come first
+        xs[lane] = (pk < pdg && ph < heads) ? __expf(pev - pgm) : 0.f;              // exp(e - max(e)) (:86); dead slots weigh 0
+        // -- the 16 source-row gathers of the batch, all in flight before any is consumed --
+        f32x4 v[RB][K];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const int src = dg[rb + r] > 0 ? __builtin_amdgcn_readlane(seg_ids, s0r[rb + r] + min(k, dg[rb + r] - 1)) : j0;
+            v[r][k] = *reinterpret_cast<const f32x4*>(wh + (unsigned)(src * P) + coff4[0]);
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // a wavefront's LDS operations complete in order
+        // -- consumer: a channel lane reads the 16 weights of its head --
+        f32x4 xw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xw[q] = *reinterpret_cast<const f32x4*>(xs + head[0] * 16 + q * 4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          float D = 0.f;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < K; ++k) {
+            const float x = xw[(r * K + k) >> 2][(r * K + k) & 3];
+            D += x;
+            acc += x * v[r][k];
+          }
+          if (on[0]) {
+            const float inv = __frcp_rn(D + 1e-10f);                          // (:96)
+            f32x4 o = acc * inv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : (__expf(o[q]) - 1.f);   // ELU (:118)
+            if (concat) *reinterpret_cast<f32x4*>(out + (size_t)(j0 + rb + r) * HF + lane * 4) = o;
+            else *reinterpret_cast<f32x4*>(&stage[wave][r * 256 + lane * 4]) = o;
+          }
+        }
+        if (!concat) {   // head mean (:158): the batch's rows through the wave's own LDS stage
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          for (int u = lane; u < RB * qh; u += 64) {
+            const int r = u / qh, c = u - r * qh;
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+            for (int h = 0; h < heads; ++h) sum += *reinterpret_cast<const f32x4*>(&stage[wave][r * 256 + h * Fh + c * 4]);
+            *reinterpret_cast<f32x4*>(out + (size_t)(j0 + rb + r) * Fh + c * 4) = sum * inv_heads;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+      }
+    };
+    if (dmax <= 4) {   // wave-uniform
+      fast(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+      return;
+    }
+    if constexpr (DENSE)
+      if (dmax <= 8) {
+        fast(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{});
+        return;
+      }
+  }
   float gm_seg[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) gm_seg[i] = 0.f;
@@ -197,69 +312,6 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
 #pragma unroll
       for (int i = 0; i < NCH; ++i) gm_seg[i] = head[i] == h ? mh : gm_seg[i];
     }
-
-  // ---- fast path (every patch-graph segment): all R rows have <= 4 in-edges and lie inside the graph ------------------------
-  // The R rows are processed TOGETHER: their 16 source-row gathers (16 KiB per wave) and 16 attention scalars are all in
-  // flight before the first is consumed, instead of four rows one after the other with 4 gathers each.  The row-by-row loop
-  // below costs ~350 issued instructions per row (loop control, per-row setup, per-batch masks) and leaves one row's worth
-  // of loads in flight per wave; this form issues each of them once per segment.
-  if (NCH == 1 && j0 + R <= N && ne <= 4 * R) {
-    bool small = true;
-    int s0r[R], dg[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      s0r[r] = __builtin_amdgcn_readlane(rpv, r) - start;
-      dg[r] = __builtin_amdgcn_readlane(rpv, r + 1) - start - s0r[r];
-      small = small && dg[r] <= 4;
-    }
-    if (small) {   // wave-uniform
-      f32x4 v[R][4];
-      float sv[R][4], tj[R], gm[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          // slots past the row's degree re-read its last neighbour (row j0 itself for an isolated row) and get weight 0
-          const int src = dg[r] > 0 ? __builtin_amdgcn_readlane(seg_ids, s0r[r] + min(k, dg[r] - 1)) : j0;
-          v[r][k] = *reinterpret_cast<const f32x4*>(wh + (unsigned)(src * P) + coff4[0]);
-          sv[r][k] = st[(unsigned)(src * H2) + head[0]];
-        }
-        tj[r] = st[(size_t)(j0 + r) * H2 + heads + head[0]];
-        gm[r] = seg_one_graph ? gm_seg[0] : gmax_read_lane(gmax, gstride, (node_graph ? node_graph[j0 + r] : 0) * heads + head[0], gen);
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        float D = 0.f;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float ev = sv[r][k] + tj[r];
-          ev = ev > 0.f ? ev : alpha * ev;                                  // LeakyReLU (:65)
-          const float x = (k < dg[r] && on[0]) ? __expf(ev - gm[r]) : 0.f;  // exp(e - max(e)) (:86)
-          D += x;
-          acc += x * v[r][k];
-        }
-        if (on[0]) {
-          const float inv = __frcp_rn(D + 1e-10f);                          // (:96)
-          f32x4 o = acc * inv;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = o[q] > 0.f ? o[q] : (__expf(o[q]) - 1.f);   // ELU (:118)
-          if (concat) *reinterpret_cast<f32x4*>(out + (size_t)(j0 + r) * HF + lane * 4) = o;
-          else *reinterpret_cast<f32x4*>(&stage[wave][r * 256 + lane * 4]) = o;
-        }
-      }
-      if (!concat) {   // head mean (:158): the wave's four rows through its own LDS stage
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        for (int u = lane; u < R * qh; u += 64) {
-          const int r = u / qh, c = u - r * qh;
-          f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-          for (int h = 0; h < heads; ++h) sum += *reinterpret_cast<const f32x4*>(&stage[wave][r * 256 + h * Fh + c * 4]);
-          *reinterpret_cast<f32x4*>(out + (size_t)(j0 + r) * Fh + c * 4) = sum * inv_heads;
-        }
-      }
-      return;
-    }
-  }
 
 #pragma unroll 1
   for (int r = 0; r < R; ++r) {
@@ -351,8 +403,8 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(const float* __restr
 
 
 hipError_t launch_gat_aggregate(const float* wh, int P, const float* st, const int32_t* rowptr, const int32_t* col,
-                                const int32_t* node_graph, const unsigned long long* gmax_enc, int N, int heads, int Fh, int concat,
-                                float alpha, float* out, int gstride, unsigned gen, hipStream_t s) {
+                                const int32_t* node_graph, const unsigned long long* gmax_enc, int N, int64_t E, int heads, int Fh,
+                                int concat, float alpha, float* out, int gstride, unsigned gen, hipStream_t s) {
   const int HF = heads * Fh;
   if (HF > GAT_MAX_HF || (Fh & 3) || (P & 3) || (long)N * P >= (1l << 31)) return hipErrorInvalidValue;
   if (N == 0) return hipSuccess;
@@ -360,7 +412,10 @@ hipError_t launch_gat_aggregate(const float* wh, int P, const float* st, const i
 #define MGU_AGG(NCH)                                                                                              \
   hipLaunchKernelGGL(gat_aggregate_kernel<NCH>, dim3((N + 15) / 16), block, 0, s, wh, P, st, rowptr, col, node_graph, gmax_enc, \
                      N, heads, Fh, concat, alpha, out, gstride, gen)
-  if (HF <= 256) MGU_AGG(1);
+  if (HF <= 256 && E > 4 * (int64_t)N)
+    hipLaunchKernelGGL((gat_aggregate_kernel<1, true>), dim3((N + 15) / 16), block, 0, s, wh, P, st, rowptr, col, node_graph, gmax_enc, N, heads,
+                       Fh, concat, alpha, out, gstride, gen);
+  else if (HF <= 256) MGU_AGG(1);
   else if (HF <= 512) MGU_AGG(2);
   else MGU_AGG(4);
 #undef MGU_AGG

@@ -173,7 +173,7 @@ int forward_prepared(mgu_ctx* c, const mgu_gat_weights* p, const float* X, int N
     HIPCHK(c, launch_gat_edge_max(st, rowptr, col, node_graph, N, heads, alpha, gmax, c->gmax_cap, gen, s));
   }
   ProfScope ps(c, s, "gat_aggregate_kernel");
-  HIPCHK(c, launch_gat_aggregate(Whp, HF, st, rowptr, col, node_graph, gmax, N, heads, Fh, concat, alpha, out, c->gmax_cap, gen, s));
+  HIPCHK(c, launch_gat_aggregate(Whp, HF, st, rowptr, col, node_graph, gmax, N, E, heads, Fh, concat, alpha, out, c->gmax_cap, gen, s));
   return MGU_OK;
 }
 

@@ -97,6 +97,34 @@ def test_ragged_random_graph_with_isolated_nodes(cuda, sched):
     assert float(got[::9].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("sched", ["aggregate_first", "wh_row_gather"])
+@pytest.mark.parametrize("scale", [0.1, 2.0])
+def test_segment_degree_patterns(cuda, sched, scale):
+    """Four-row CSR segments with every mix of empty, short and full rows (in-degree 0..8, the range of the gather kernel's
+    lane-parallel fast path: 4 x 4 and 2 x 8 batches) and a 9-edge row beside them (per-row path).  An empty row in FRONT of a
+    short one once broke the fast path: its lanes were switched off around a cross-lane shuffle that read the ids they hold."""
+    ctx = make_ctx({"MGU_NO_GAT_FUSED": "1"} if sched == "wh_row_gather" else {})
+    Fin, heads, Fh = 32, 4, 64
+    W = torch.from_numpy(O.formula_uniform("gs/rw", (heads * Fh, Fin), -0.5, 0.5, seed=4))
+    a = torch.from_numpy(O.formula_uniform("gs/ra", (heads, 2 * Fh), -0.5, 0.5, seed=5))
+    pats = [[4, 0, 2, 0], [4, 2, 0, 0], [2, 2, 2, 2], [4, 4, 4, 4], [0, 0, 0, 1], [3, 0, 3, 0], [1, 1, 1, 1], [0, 2, 0, 2], [0, 0, 0, 0],
+            [8, 8, 8, 8], [5, 0, 8, 1], [0, 7, 0, 6], [8, 0, 0, 0], [9, 1, 1, 1], [4, 4, 4, 5]]
+    deg = np.array([d for p in pats for d in p] + [3, 1])          # a ragged last segment
+    N = deg.size
+    rng = np.random.default_rng(1)
+    tgt = np.repeat(np.arange(N), deg)
+    src = rng.integers(0, N, size=tgt.size)
+    ei = torch.from_numpy(np.stack([src, tgt]).astype(np.int64))
+    rowptr, col = coo_to_csr_device(ei.to(cuda), N)
+    X = torch.from_numpy(O.formula_normal("gs/px", (N, Fin), seed=3)) * scale
+    for concat in (0, 1):
+        ref = oracle_layer(X, [(ei, 0, N)], W, a, heads, Fh, concat)
+        got = run(ctx, cuda, X.to(cuda), rowptr, col, None, W, a, heads, Fh, concat)
+        err = (got - ref).abs().max(1).values
+        assert float(err.max()) <= 1e-4 * max(1.0, float(ref.abs().max())), (concat, err.numpy().round(5).tolist())
+        assert float(got[torch.from_numpy(deg == 0)].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("N,E", [(203, 1500), (1, 0), (50, 0), (5000, 200000), (7, 3)])
 def test_device_coo_to_csr_matches_host_routine_bit_exact(cuda, N, E):
     """mgu_coo_to_csr_device (stable radix sort by target) against the host routine mgu_coo_to_csr / the oracle: index maps are
