@@ -283,6 +283,19 @@ int mgu_ncut_edge_weights(mgu_ctx* ctx, const float* feats_dev, int N, int D, co
 int mgu_ncut_forward(mgu_ctx* ctx, const float* feats_dev, int N, int D, const int32_t* rowptr_src_dev,
                      const int32_t* col_tgt_dev, int64_t E, const float* assign_dev, int K, int assign_is_logits,
                      float* soft_dev, int32_t* hard_dev, float* loss_dev, void* hip_stream);
+/* loss.backward() through that loss (scripts/train_end_to_end.py:348-356 with :472-479; the reference differentiates through
+ * the edge weights as well, mincut_refinement.py:79).  soft_dev (N,K): the assignments the forward used (its soft_dev, or its
+ * assign_dev when that already held probabilities); CSR BY SOURCE as in the forward plus CSR BY TARGET (rowptr_tgt, col = sources:
+ * mgu_coo_to_csr_device of the unflipped list, or mgu_csr_transpose_device).  gloss_dev: upstream gradient of the loss (one
+ * float, NULL = 1); gsoft_dev (N,K) or NULL: upstream gradient of the returned soft assignments (logits only).  Writes
+ * dassign_dev (N,K) -- w.r.t. the logits when assign_is_logits, else w.r.t. the probabilities -- and dfeats_dev (N,D) (may be
+ * NULL).  Every element is written; both are gathers (no atomics: bitwise reproducible).  D <= 1024, 1 <= K <= 16. */
+int mgu_ncut_backward(mgu_ctx* ctx, const float* feats_dev, int N, int D, const int32_t* rowptr_src_dev, const int32_t* col_tgt_dev,
+                      const int32_t* rowptr_tgt_dev, const int32_t* col_src_dev, int64_t E, const float* soft_dev, int K,
+                      int assign_is_logits, const float* gloss_dev, const float* gsoft_dev, float* dassign_dev, float* dfeats_dev,
+                      void* hip_stream);
+/* dz[i] = y[i] > 0 ? dy[i] : 0 -- the ReLU of the MLP segment predictor (scripts/train_end_to_end.py:59-63) in its backward. */
+int mgu_relu_backward(mgu_ctx* ctx, const float* dy_dev, const float* y_dev, int64_t n, float* dz_dev, void* hip_stream);
 
 /* ---- Region stage + fusion of the e2e forward: replaces scripts/train_end_to_end.py:366-373
  *      (label-mean pooling), :403-421 (region embedding -> patches -> nearest upsample) and the concat of

@@ -277,6 +277,87 @@ def gen_mincut():
     save("mincut.npz", **out)
 
 
+def _ref_predictor_module(in_dim, K, hidden, use_gnn, heads, params):
+    """PatchSegmentPredictor (scripts/train_end_to_end.py:40-70) is this wrapper around the reference GATNetwork / an MLP; the script
+    itself cannot be imported (its import runs the whole training set-up).  Returns (module, call(x, ei))."""
+    if use_gnn:
+        g = RefGAT(in_dim, hidden if hidden else in_dim, K, heads, num_gat_layers=1, dropout_rate=0.1, alpha=0.2).eval()
+        g.load_state_dict({k[len("gnn_predictor."):]: v for k, v in params.items()})
+        return g, "gnn_predictor.", (lambda x, ei: g(x, ei))
+    hd = hidden if hidden is not None else in_dim * 2
+    m = torch.nn.Sequential(torch.nn.Linear(in_dim, hd), torch.nn.ReLU(), torch.nn.Linear(hd, K)).eval()
+    m.load_state_dict({k[len("mlp_predictor."):]: v for k, v in params.items()})
+    return m, "mlp_predictor.", (lambda x, ei: m(x))
+
+
+def gen_mincutgrad():
+    print("[mincutgrad] L_partition.backward() of the reference MinCutRefinement + segment predictor (+ patch GAT) under torch autograd")
+    out = {}
+    ref = RefMinCut()
+    for tag in O.MINCUTGRAD_CASES:
+        ei, X, R, p, K, use_gnn, heads, shift = O.mincutgrad_inputs(tag)
+        hidden = O.MINCUTGRAD_CASES[tag][4]
+        mod, prefix, call = _ref_predictor_module(X.shape[1], K, hidden, use_gnn, heads, p)
+        net = call if shift is None else (lambda x, e: call(x, e) + shift)
+        Xr = X.clone().requires_grad_(True)
+        loss, soft = ref(Xr, ei, K, net)                         # MinCutRefinement.forward, :163-205
+        total = loss + 0.05 * (soft * R).sum()                   # the second term sends a gradient through the returned assignments
+        total.backward()
+        out[tag + "_loss"] = np.float32(float(loss))
+        out[tag + "_dX"] = Xr.grad.numpy()
+        for k, v in mod.named_parameters():
+            out[f"{tag}_d_{prefix}{k}"] = v.grad.numpy().copy()
+        # the loss function called directly with soft assignments as the leaf (normalized_cut_loss, :55-160)
+        P = soft.detach().clone().requires_grad_(True)
+        Xq = X.clone().requires_grad_(True)
+        l2 = ref.normalized_cut_loss(Xq, ei, P, K)
+        (2.5 * l2).backward()
+        out[tag + "_direct_dP"] = P.grad.numpy()
+        out[tag + "_direct_dX"] = Xq.grad.numpy()
+        # the analytic restatement against the reference's autograd, fp32 and (as a yardstick for the tests) float64
+        aP, aF = O.normalized_cut_loss_grad(X, ei, soft.detach(), K, gloss=2.5)
+        check(tag + ".direct_dP", aP, P.grad, tol=5e-6 * max(1.0, float(P.grad.abs().max())))
+        check(tag + ".direct_dX", aF, Xq.grad, tol=5e-6 * max(1.0, float(Xq.grad.abs().max())))
+        aP64, aF64 = O.normalized_cut_loss_grad(X.double(), ei, soft.detach().double(), K, gloss=2.5)
+        out[tag + "_direct_dP64"] = aP64.numpy()
+        out[tag + "_direct_dX64"] = aF64.numpy()
+        print(f"   {tag}: loss {float(loss):.6f} max|dX| {float(Xr.grad.abs().max()):.3e} max|dP| {float(P.grad.abs().max()):.3e}")
+
+    # patch GAT -> MinCut (GNN predictor): the chain the e2e loop trains (train_end_to_end.py:332-356, 219-226), three SGD steps
+    ei = torch.from_numpy(O.patch_graph_edges(128, 128, 16))
+    X0 = torch.from_numpy(O.formula_normal("mincutgrad/chain/x", (64, 16), seed=21)) * 0.5
+    gp = O.make_gat_params(16, 8, 16, 2, 1, seed=22)
+    pp = O.make_segment_predictor_params(16, 2, 8, True, 2, seed=23)
+    gat = RefGAT(16, 8, 16, 2, num_gat_layers=1).eval()
+    gat.load_state_dict(gp)
+    pred, prefix, call = _ref_predictor_module(16, 2, 8, True, 2, pp)
+    params = list(gat.parameters()) + list(pred.parameters())
+    opt = torch.optim.SGD(params, lr=0.2)
+    losses = []
+    for step in range(4):
+        opt.zero_grad()
+        feats = gat(X0, ei)
+        loss, soft = ref(feats, ei, 2, call)
+        losses.append(float(loss))
+        if step == 0:
+            loss.backward()
+            for k, v in gat.named_parameters():
+                out[f"chain_d_gat.{k}"] = v.grad.numpy().copy()
+            for k, v in pred.named_parameters():
+                out[f"chain_d_{prefix}{k}"] = v.grad.numpy().copy()
+        elif step < 3:
+            loss.backward()
+        if step < 3:
+            opt.step()
+    out["chain_losses"] = np.array(losses, np.float32)
+    for k, v in gat.state_dict().items():
+        out[f"chain_final_gat.{k}"] = v.numpy().copy()
+    for k, v in pred.state_dict().items():
+        out[f"chain_final_{prefix}{k}"] = v.numpy().copy()
+    print(f"   chain: losses {losses}")
+    save("mincut_grad.npz", **out)
+
+
 def gen_region():
     print("[region] label-mean pooling -> region GAT -> map back -> nearest upsample -> FeatureFusion (SURVEY 8f row 2)")
     import torch.nn.functional as TF
@@ -706,11 +787,11 @@ def gen_c5():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,gat,gatgrad,graph,mincut,region,dethead,losses,scriptlosses,c1,c2,c4,c5")
+    ap.add_argument("--only", default="tiny,gat,gatgrad,graph,mincut,mincutgrad,region,dethead,losses,scriptlosses,c1,c2,c4,c5")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    fns = {"tiny": gen_tiny, "gat": gen_gat, "gatgrad": gen_gatgrad, "graph": gen_graph, "mincut": gen_mincut, "region": gen_region, "dethead": gen_dethead, "losses": gen_losses, "scriptlosses": gen_scriptlosses, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
+    fns = {"tiny": gen_tiny, "gat": gen_gat, "gatgrad": gen_gatgrad, "graph": gen_graph, "mincut": gen_mincut, "mincutgrad": gen_mincutgrad, "region": gen_region, "dethead": gen_dethead, "losses": gen_losses, "scriptlosses": gen_scriptlosses, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
     for k in a.only.split(","):
         t0 = time.time()
         fns[k]()

@@ -415,6 +415,67 @@ def normalized_cut_loss(node_features, edge_index, soft, num_segments):
     return total
 
 
+def normalized_cut_loss_grad(node_features, edge_index, soft, num_segments, gloss=1.0):
+    """Analytic gradient of normalized_cut_loss (the function above = mincut_refinement.py:55-160) w.r.t. the soft assignments
+    and the node features, in the inputs' dtype -- what torch autograd computes for the reference when total_loss.backward()
+    (train_end_to_end.py:478) reaches L_partition.  With c_k = cut_k, a_k = assoc_k, kept_k = (a_k > 1e-8) (:152):
+        alpha_k = g / a_k,   beta_k = -g c_k / a_k^2                               (0 for a skipped segment)
+        dL/dP_ik = sum_{e: src=i} w_e (alpha_k (1 - P_tgt,k) + beta_k) - sum_{e: tgt=i} w_e alpha_k P_src,k
+        dL/dw_e  = sum_k P_src,k (alpha_k (1 - P_tgt,k) + beta_k)
+        dL/df    : w_e = exp(-|f_s - f_t|^2 / 2)  =>  dw_e/df_s = -w_e (f_s - f_t) = -dw_e/df_t      (:43-51)
+    Returns (dP (N, K), dF (N, D)).  tests/ check it against the reference's autograd fixture; the HIP kernel
+    (csrc/ncut.hip: ncut_bwd_node_kernel) evaluates exactly these sums as two gathers per node."""
+    src, tgt = edge_index[0], edge_index[1]
+    N, D = node_features.shape
+    dt = node_features.dtype
+    diff = node_features[src] - node_features[tgt]
+    w = torch.exp(-torch.sum(diff ** 2, dim=1) / 2.0)
+    Ps, Pt = soft[src], soft[tgt]                                   # (E, K)
+    cut = torch.sum(w[:, None] * Ps * (1 - Pt), dim=0)              # (K,)
+    assoc = torch.sum(w[:, None] * Ps, dim=0)
+    kept = assoc > 1e-8
+    safe = torch.where(kept, assoc, torch.ones_like(assoc))
+    alpha = torch.where(kept, gloss / safe, torch.zeros_like(assoc))
+    beta = torch.where(kept, -gloss * cut / (safe * safe), torch.zeros_like(assoc))
+    t = alpha[None, :] * (1 - Pt) + beta[None, :]                   # (E, K)
+    dP = torch.zeros(N, num_segments, dtype=dt)
+    dP.index_add_(0, src, w[:, None] * t)
+    dP.index_add_(0, tgt, -w[:, None] * alpha[None, :] * Ps)
+    q = torch.sum(Ps * t, dim=1)                                    # dL/dw_e
+    gsrc = -(q * w)[:, None] * diff
+    dF = torch.zeros(N, D, dtype=dt)
+    dF.index_add_(0, src, gsrc)
+    dF.index_add_(0, tgt, -gsrc)
+    return dP, dF
+
+
+# cases of tests/golden/mincut_grad.npz (oracle/make_golden.py gen_mincutgrad runs the REFERENCE classes under autograd on them)
+MINCUTGRAD_CASES = {   # tag: (graph, nodes, D, K, hidden, use_gnn, heads, seed, logit shift, feature scale)
+    "a": ("patch128", 64, 64, 2, 32, True, 2, 5, None, 0.15),          # the configuration of train_end_to_end.py:155-163
+    "b": ("directed", 50, 24, 3, None, False, 1, 6, None, 0.2),        # MLP predictor, directed graph, a node without edges
+    "c": ("directed", 50, 24, 3, None, False, 1, 6, (0.0, -60.0, 0.0), 0.2),   # a skipped segment (:152-153): no gradient through it
+    "d": ("patch512", 1024, 64, 2, 32, True, 2, 7, None, 0.15),       # the headline patch graph
+    "e": ("directed", 50, 24, 16, 40, False, 1, 8, None, 0.3),         # K = 16, the widest the kernels take
+}
+
+
+def mincutgrad_inputs(tag):
+    """(edge_index (2,E) int64 tensor, X (N,D), R (N,K) weights of the soft-assignment side loss, predictor params, K, use_gnn, heads, shift)."""
+    graph, N, D, K, hidden, use_gnn, heads, seed, shift, xs = MINCUTGRAD_CASES[tag]
+    if graph == "patch128":
+        ei = patch_graph_edges(128, 128, 16)
+    elif graph == "patch512":
+        ei = patch_graph_edges(512, 512, 16)
+    else:   # the directed random graph of the forward fixture (make_golden.gen_mincut case b): node 49 has no outgoing edge, 48 none
+        u = formula_uniform("mincut/b/e", (2, 200), 0.0, 1.0, 3)
+        ei = np.stack([np.minimum((u[0] * 48).astype(np.int64), 47), np.minimum((u[1] * 50).astype(np.int64), 49)])
+    X = torch.from_numpy(formula_normal(f"mincutgrad/{tag}/x", (N, D), seed=seed)) * xs
+    R = torch.from_numpy(formula_normal(f"mincutgrad/{tag}/r", (N, K), seed=seed + 100))
+    p = make_segment_predictor_params(D, K, hidden, use_gnn, heads, seed=seed)
+    sh = None if shift is None else torch.tensor(shift, dtype=torch.float32)
+    return torch.from_numpy(np.ascontiguousarray(ei)), X, R, p, K, use_gnn, heads, sh
+
+
 def segment_predictor_param_shapes(in_dim, num_segments, hidden_dim=None, use_gnn=False, num_heads=1):
     """state_dict keys of PatchSegmentPredictor (train_end_to_end.py:40-60; one GAT layer as configured at :156-163)."""
     out: "OrderedDict[str, tuple]" = OrderedDict()

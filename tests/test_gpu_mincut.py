@@ -27,7 +27,8 @@ def test_mincut_forward_vs_reference_fixture(cuda, golden, tag):
     Xd, eid = X.to(cuda), ei.to(cuda)
     net = pred if shift is None else (lambda x, e: pred(x, e) + shift.to(cuda))
     mc = mgunet.MinCutRefinement()
-    loss, soft = mc(Xd, eid, K, net)
+    with torch.no_grad():   # the parameters require gradients: without this the outputs are autograd nodes, as in the reference
+        loss, soft = mc(Xd, eid, K, net)
     ref_loss = float(g[f"{tag}_loss"])
     assert tuple(soft.shape) == (X.shape[0], K) and loss.dim() == 0
     assert np.abs(soft.cpu().numpy() - g[f"{tag}_soft"]).max() <= 1e-5

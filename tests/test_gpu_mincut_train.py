@@ -1,0 +1,131 @@
+"""Training through the MinCut stage on the HIP path: `loss.backward()` of `mgunet.MinCutRefinement` runs mgu_ncut_backward, the MLP
+predictor's Linear layers run their backward on the library's 1x1-convolution dgrad / wgrad kernels, the GNN predictor and the patch
+GAT run mgu_gat_layer_backward.  Reference: the gradients the reference's own MinCutRefinement + predictor produced under torch
+autograd (tests/golden/mincut_grad.npz, oracle/make_golden.py gen_mincutgrad).  Tolerance: 2e-5 of max|gradient| (fp32 sums in a
+different order; the float64 analytic gradient is the second yardstick for the loss kernel alone)."""
+import numpy as np
+import pytest
+import torch
+
+import mgunet
+import mgunet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def build_predictor(cuda, D, K, hidden, use_gnn, heads, params):
+    m = mgunet.PatchSegmentPredictor(D, K, hidden_dim=hidden, use_gnn=use_gnn, num_gnn_layers=1, num_heads=heads)
+    m.load_state_dict(params, strict=True)
+    return m.to(cuda).eval()   # eval: the GNN predictor's dropout(0.1) is torch-RNG noise in train mode
+
+
+def close(got, ref, what, tol=TOL):
+    got = got.detach().cpu().numpy().astype(np.float64)
+    d = np.abs(got - ref).max()
+    assert d <= tol * max(1.0, np.abs(ref).max()), (what, d, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("tag", list(O.MINCUTGRAD_CASES))
+def test_mincut_backward_vs_reference_fixture(cuda, golden, tag):
+    g = golden["mincut_grad"]
+    ei, X, R, p, K, use_gnn, heads, shift = O.mincutgrad_inputs(tag)
+    hidden = O.MINCUTGRAD_CASES[tag][4]
+    pred = build_predictor(cuda, X.shape[1], K, hidden, use_gnn, heads, p)
+    net = pred if shift is None else (lambda x, e: pred(x, e) + shift.to(cuda))
+    mc = mgunet.MinCutRefinement()
+    Xd = X.to(cuda).requires_grad_(True)
+    eid = ei.to(cuda)
+    loss, soft = mc(Xd, eid, K, net)
+    assert loss.requires_grad and soft.requires_grad
+    assert abs(float(loss.detach()) - float(g[tag + "_loss"])) <= 2e-5 * max(1.0, float(g[tag + "_loss"]))
+    (loss + 0.05 * (soft * R.to(cuda)).sum()).backward()
+    close(Xd.grad, g[tag + "_dX"], "dX")
+    for k, v in pred.named_parameters():
+        assert v.grad is not None, k
+        close(v.grad, g[f"{tag}_d_{k}"], k)
+    # normalized_cut_loss called directly, the soft assignments as the leaf (:55-160); float64 analytic gradient as yardstick
+    lg = O.segment_predictor_forward(p, X, ei, use_gnn, heads)
+    P = torch.softmax(lg if shift is None else lg + shift, dim=1).to(cuda).requires_grad_(True)
+    Xq = X.to(cuda).requires_grad_(True)
+    (2.5 * mc.normalized_cut_loss(Xq, eid, P, K)).backward()
+    close(P.grad, g[tag + "_direct_dP"], "direct dP")
+    close(Xq.grad, g[tag + "_direct_dX"], "direct dX")
+    close(P.grad, g[tag + "_direct_dP64"], "direct dP vs float64", tol=1e-5)
+    close(Xq.grad, g[tag + "_direct_dX64"], "direct dX vs float64", tol=1e-5)
+    # a second backward gives the same bytes: both gradients are gathers, no atomics
+    P2 = P.detach().clone().requires_grad_(True)
+    X2 = X.to(cuda).requires_grad_(True)
+    (2.5 * mc.normalized_cut_loss(X2, eid, P2, K)).backward()
+    assert torch.equal(P2.grad, P.grad) and torch.equal(X2.grad, Xq.grad)
+
+
+def test_patch_gat_to_mincut_chain_trains_like_the_reference(cuda, golden):
+    """patch GAT -> MinCut with the GNN predictor (train_end_to_end.py:332-356), parameters of both in one SGD optimizer
+    (:219-226): first-step gradients, three steps of losses and the final parameters against the reference's own run."""
+    g = golden["mincut_grad"]
+    ei = torch.from_numpy(O.patch_graph_edges(128, 128, 16)).to(cuda)
+    X0 = (torch.from_numpy(O.formula_normal("mincutgrad/chain/x", (64, 16), seed=21)) * 0.5).to(cuda)
+    gat = mgunet.GATNetwork(16, 8, 16, 2, num_gat_layers=1, dropout_rate=0.0)
+    gat.load_state_dict(O.make_gat_params(16, 8, 16, 2, 1, seed=22))
+    gat = gat.to(cuda).train()
+    pred = build_predictor(cuda, 16, 2, 8, True, 2, O.make_segment_predictor_params(16, 2, 8, True, 2, seed=23))
+    mc = mgunet.MinCutRefinement()
+    opt = torch.optim.SGD(list(gat.parameters()) + list(pred.parameters()), lr=0.2)
+    losses = []
+    for step in range(4):
+        opt.zero_grad()
+        loss, soft = mc(gat(X0, ei), ei, 2, pred)
+        losses.append(float(loss.detach()))
+        if step < 3:
+            loss.backward()
+            if step == 0:
+                for k, v in gat.named_parameters():
+                    close(v.grad, g[f"chain_d_gat.{k}"], "gat." + k)
+                for k, v in pred.named_parameters():
+                    close(v.grad, g[f"chain_d_{k}"], k)
+            opt.step()
+    assert np.abs(np.array(losses) - g["chain_losses"]).max() <= 2e-5
+    assert losses[3] < losses[0]
+    for k, v in gat.state_dict().items():
+        close(v, g[f"chain_final_gat.{k}"], "final gat." + k)
+    for k, v in pred.state_dict().items():
+        close(v, g[f"chain_final_{k}"], "final " + k)
+
+
+def test_mlp_predictor_linear_backward_vs_torch(cuda):
+    """The Linear -> ReLU -> Linear predictor alone against torch's own autograd on the same weights (float64), widths that are
+    not multiples of the MFMA tile and K = 3 outputs (a padded 4-column buffer)."""
+    torch.manual_seed(3)
+    pred = mgunet.PatchSegmentPredictor(24, 3, hidden_dim=40, use_gnn=False).to(cuda)
+    x = torch.randn(301, 24, device=cuda)
+    r = torch.randn(301, 3, device=cuda)
+    xr = x.clone().requires_grad_(True)
+    (pred(xr) * r).sum().backward()
+    ref = torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.ReLU(), torch.nn.Linear(40, 3)).double()
+    ref.load_state_dict({k[len("mlp_predictor."):]: v.double().cpu() for k, v in pred.state_dict().items()})
+    x64 = x.double().cpu().requires_grad_(True)
+    (ref(x64) * r.double().cpu()).sum().backward()
+    close(xr.grad, x64.grad.numpy(), "dx")
+    for (k, v), (_, w) in zip(pred.named_parameters(), ref.named_parameters()):
+        close(v.grad, w.grad.numpy(), k)
+
+
+def test_ncut_backward_interface(cuda):
+    mc = mgunet.MinCutRefinement()
+    ei = torch.tensor([[0, 1, 2], [1, 0, 0]], device=cuda)
+    # no gradient is recorded under no_grad, and a graph without edges gives zero gradients (every segment is skipped)
+    X = torch.randn(4, 8, device=cuda, requires_grad=True)
+    P = torch.full((4, 2), 0.5, device=cuda, requires_grad=True)
+    with torch.no_grad():
+        assert not mc.normalized_cut_loss(X, ei, P, 2).requires_grad
+    l = mc.normalized_cut_loss(X, torch.zeros((2, 0), dtype=torch.int64, device=cuda), P, 2)
+    l.backward()
+    assert float(X.grad.abs().max()) == 0.0 and float(P.grad.abs().max()) == 0.0
+    # feature rows wider than the kernel's register budget are refused, not truncated
+    Xw = torch.randn(4, 1028, device=cuda, requires_grad=True)
+    with pytest.raises(ValueError, match="D <= 1024"):
+        mc.normalized_cut_loss(Xw, ei, P, 2)
+    with torch.no_grad():
+        assert torch.isfinite(mc.normalized_cut_loss(Xw, ei, P, 2))   # the forward alone takes any width

@@ -381,3 +381,29 @@ def test_input_pipeline_restatements_self_consistency():
     assert h[:2].max() <= 1 and h[2:].min() >= 254                               # luminance stretched to the ends
     pm = O.patch_mean_u8(np.full((5, 5), 100, np.uint8), 4)
     assert pm.shape == (4, 1) and abs(float(pm[0]) - 100) < 1e-4 and abs(float(pm[3]) - 100 / 16) < 1e-4
+
+
+@pytest.mark.parametrize("tag", list(O.MINCUTGRAD_CASES))
+def test_mincut_gradients_vs_reference_fixture(golden, tag):
+    """L_partition.backward() (train_end_to_end.py:348-356, 472-479) as the REFERENCE MinCutRefinement + predictor produced it
+    under torch autograd (tests/golden/mincut_grad.npz): (i) the analytic gradient the HIP kernel implements
+    (O.normalized_cut_loss_grad) equals the reference's autograd of normalized_cut_loss called directly, (ii) the oracle
+    restatement under autograd reproduces d/dX and the predictor's parameter gradients of the whole stage."""
+    g = golden["mincut_grad"]
+    ei, X, R, p, K, use_gnn, heads, shift = O.mincutgrad_inputs(tag)
+    lg = O.segment_predictor_forward(p, X, ei, use_gnn, heads)
+    soft = torch.softmax(lg if shift is None else lg + shift, dim=1)
+    aP, aF = O.normalized_cut_loss_grad(X, ei, soft, K, gloss=2.5)
+    for got, key in ((aP, "_direct_dP"), (aF, "_direct_dX")):
+        ref = g[tag + key]
+        assert np.abs(got.numpy() - ref).max() <= 5e-6 * max(1.0, np.abs(ref).max()), key
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    Xo = X.clone().requires_grad_(True)
+    lg = O.segment_predictor_forward(q, Xo, ei, use_gnn, heads)
+    loss, so, _ = O.mincut_forward(Xo, ei, K, lg if shift is None else lg + shift)
+    (loss + 0.05 * (so * R).sum()).backward()
+    assert abs(float(loss.detach()) - float(g[tag + "_loss"])) <= 1e-5 * max(1.0, float(g[tag + "_loss"]))
+    assert np.abs(Xo.grad.numpy() - g[tag + "_dX"]).max() <= 5e-6 * max(1.0, np.abs(g[tag + "_dX"]).max())
+    for k in q:
+        ref = g[f"{tag}_d_{k}"]
+        assert np.abs(q[k].grad.numpy() - ref).max() <= 5e-6 * max(1.0, np.abs(ref).max()), k
