@@ -129,3 +129,53 @@ def test_ncut_backward_interface(cuda):
         mc.normalized_cut_loss(Xw, ei, P, 2)
     with torch.no_grad():
         assert torch.isfinite(mc.normalized_cut_loss(Xw, ei, P, 2))   # the forward alone takes any width
+
+
+def test_graph_branch_losses_of_the_e2e_step_vs_oracle_composition(cuda):
+    """The graph-branch half of one iteration of scripts/train_end_to_end.py:300-356, 438-479 for a batch of two images: per image
+    patch GAT -> L_feature (FeatureConsistencyLoss, called with the batch dimension the script forgets: SURVEY appendix A) and
+    MinCut -> L_partition; total = 0.1 mean(L_feature) + 0.5 mean(L_partition) (the script's default weights, :462-465);
+    total.backward().  The patch GAT output feeds three consumers (feature loss, predictor, edge weights of the cut): its
+    gradient is their sum.  Compared with the oracle's restatement of the same composition under torch autograd (CPU, fp32)."""
+    B, Dp, K = 2, 32, 2
+    ei = torch.from_numpy(O.patch_graph_edges(128, 128, 16))
+    Np = 64
+    gp = O.make_gat_params(Dp, 16, Dp, 2, 1, seed=31)
+    pp = O.make_segment_predictor_params(Dp, K, 16, True, 2, seed=32)
+    feats = [torch.from_numpy(O.formula_normal(f"e2e/{b}/patch", (Np, Dp), seed=33 + b)) * 0.4 for b in range(B)]   # :326 placeholder
+    funet = [torch.from_numpy(O.formula_normal(f"e2e/{b}/funet", (Np, Dp), seed=43 + b)) * 0.4 for b in range(B)]   # :338 placeholder
+    ylab = [torch.from_numpy((O.formula_uniform(f"e2e/{b}/y", (Np,), 0.0, 1.0, 53 + b) > 0.5).astype(np.int64)) for b in range(B)]  # :342
+
+    # oracle composition
+    q = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    r = {k: v.clone().requires_grad_(True) for k, v in pp.items()}
+    lf, lp = 0.0, 0.0
+    for b in range(B):
+        h = O.gat_network_forward(q, feats[b], ei, 2, 1)
+        lf = lf + O.feature_consistency_loss(funet[b][None], h[None], ylab[b][None])
+        l, _, _ = O.mincut_forward(h, ei, K, O.segment_predictor_forward(r, h, ei, True, 2))
+        lp = lp + l
+    tot = 0.1 * lf / B + 0.5 * lp / B
+    tot.backward()
+
+    # HIP path
+    gat = mgunet.GATNetwork(Dp, 16, Dp, 2, num_gat_layers=1, dropout_rate=0.0)
+    gat.load_state_dict(gp)
+    gat = gat.to(cuda).train()
+    pred = build_predictor(cuda, Dp, K, 16, True, 2, pp)
+    mc, fl = mgunet.MinCutRefinement(), mgunet.FeatureConsistencyLoss(margin=1.0)
+    eid = ei.to(cuda)
+    hlf, hlp = 0.0, 0.0
+    for b in range(B):
+        h = gat(feats[b].to(cuda), eid)
+        hlf = hlf + fl(funet[b].to(cuda)[None], h[None], ylab[b].to(cuda)[None])
+        l, soft = mc(h, eid, K, pred)
+        hlp = hlp + l
+    htot = 0.1 * hlf / B + 0.5 * hlp / B
+    htot.backward()
+    assert abs(float(hlf.detach()) - float(lf.detach())) <= 2e-5 * max(1.0, float(lf.detach()))
+    assert abs(float(hlp.detach()) - float(lp.detach())) <= 2e-5 * max(1.0, float(lp.detach()))
+    for k, v in gat.named_parameters():
+        close(v.grad, q[k].grad.numpy().astype(np.float64), "gat." + k)
+    for k, v in pred.named_parameters():
+        close(v.grad, r[k].grad.numpy().astype(np.float64), k)
