@@ -509,49 +509,51 @@ hipError_t launch_pack_convt_dgrad_w(const float* w, float* wp, int Cin, int Cou
 
 // ---- gradient panels -> the reference's parameter layouts ---------------------------------------------
 // conv: panel [Cout][Kp], k = tap*Cp + c  ->  OIHW (Cout, Cin, KS, KS)
-// Sums `groups` partial panels in a fixed order (the atomics-free wgrad path writes one panel per patch group).
-// A workgroup owns 32 consecutive panel elements (128-byte coalesced reads of every partial panel) and splits the
-// group loop over 8 slices, so a small panel with 512 partials still fills the chip.
+// Sums `groups` partial panels in a fixed order (the atomics-free wgrad path writes one panel per patch group) and writes OIHW.
+// A workgroup owns one output channel and 32 consecutive input channels with all KS*KS taps: per tap a 128-byte coalesced read of
+// every partial panel, the group loop split over 8 slices (a small panel with 512 partials still fills the chip), and -- the part
+// that was missing: the OIHW destination of those 32 x 9 values is ONE contiguous 1152-byte run, written from LDS in order
+// (a thread per panel element wrote 4 bytes at a 36-byte stride: 56 us for the 512 x 512 layer, whose reads take 10).
+template <int TAPS>
 __global__ __launch_bounds__(256) void unpack_conv_grad_kernel(const float* __restrict__ dwp, int groups, size_t panel_stride,
-                                                               float* __restrict__ g, int Cout, int Cin, int Cp, int KS,
-                                                               int Kp) {
-  __shared__ float part[8][32];
-  const int kk = KS * KS * Cp;
-  const int64_t total = (int64_t)Cout * kk;
+                                                               float* __restrict__ g, int Cout, int Cin, int Cp, int Kp) {
+  __shared__ float part[8][TAPS][33];
   const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  for (int64_t i0 = (int64_t)blockIdx.x * 32; i0 < total; i0 += (int64_t)gridDim.x * 32) {
-    const int64_t i = i0 + e;
-    const bool ok = i < total;
-    const int k = ok ? (int)(i % kk) : 0;
-    const int co = ok ? (int)(i / kk) : 0;
-    const float* p = dwp + (int64_t)co * Kp + k;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int q = sl;
-    for (; q + 24 < groups; q += 32) {   // 4 independent loads in flight
-      s0 += p[(size_t)q * panel_stride];
-      s1 += p[(size_t)(q + 8) * panel_stride];
-      s2 += p[(size_t)(q + 16) * panel_stride];
-      s3 += p[(size_t)(q + 24) * panel_stride];
+  const int nchunk = (Cp + 31) / 32;
+  for (int item = blockIdx.x; item < Cout * nchunk; item += gridDim.x) {
+    const int co = item / nchunk, ci0 = (item - co * nchunk) * 32;
+    const bool ok = ci0 + e < Cp;
+    const float* p = dwp + (int64_t)co * Kp + (ok ? ci0 + e : 0);
+    float s[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) s[t] = 0.f;
+    for (int q = sl; q < groups; q += 8) {   // TAPS independent loads in flight
+      const float* pq = p + (size_t)q * panel_stride;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) s[t] += pq[t * Cp];
     }
-    for (; q < groups; q += 8) s0 += p[(size_t)q * panel_stride];
-    part[sl][e] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) part[sl][t][e] = s[t];
     __syncthreads();
-    if (sl == 0 && ok) {
+    const int nci = min(32, Cin - ci0);   // channels of this chunk that exist in the OIHW tensor (Cp pads to a multiple of 4)
+    for (int o = threadIdx.x; o < nci * TAPS; o += 256) {
+      const int cl = o / TAPS, t = o - cl * TAPS;
       float sum = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sum += part[j][e];
-      const int tap = k / Cp, ci = k - tap * Cp;
-      if (ci < Cin) g[((int64_t)co * Cin + ci) * KS * KS + tap] = sum;
+      for (int j = 0; j < 8; ++j) sum += part[j][t][cl];
+      g[((int64_t)co * Cin + ci0) * TAPS + o] = sum;
     }
     __syncthreads();
   }
 }
 hipError_t launch_unpack_conv_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cout, int Cin, int Cp, int KS,
                                    int Kp, hipStream_t s) {
-  int64_t blocks = ((int64_t)Cout * KS * KS * Cp + 31) / 32;
+  int64_t blocks = (int64_t)Cout * ((Cp + 31) / 32);
   if (blocks > 65535) blocks = 65535;
-  hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dwp, groups, panel_stride, g, Cout, Cin,
-                     Cp, KS, Kp);
+  if (KS == 3)
+    hipLaunchKernelGGL(unpack_conv_grad_kernel<9>, dim3((unsigned)blocks), dim3(256), 0, s, dwp, groups, panel_stride, g, Cout, Cin, Cp, Kp);
+  else
+    hipLaunchKernelGGL(unpack_conv_grad_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, dwp, groups, panel_stride, g, Cout, Cin, Cp, Kp);
   return hipGetLastError();
 }
 // convT: partial panels [groups][Cin][Kp], k = q*Cout + co  ->  (Cin, Cout, 2, 2), the panels added in a fixed order.
