@@ -328,8 +328,10 @@ def bench_train(a, world, rank, local_rank, dev, dist):
         stats = merge_stats(_lib.read_kernel_stats(ctx))
         L.mgu_profile_enable(ctx.handle, 0)
         dom = next((k for k in stats if k["pipe"] >= 0 and k["flops_mfma"] > 0), None)
+        x3w = any(k["name"].startswith("wino_wgrad") and k["pipe"] == 1 for k in stats)
         roof = roofline_from(stats, nprof, "fp32 operands split exactly into 3 bf16 pieces (6 bf16 MFMA products per fp32 product), fp32 "
-                             "accumulate, for the forward / data-gradient Winograd convolutions; exact fp32 MFMA for the weight gradients",
+                             "accumulate, for the forward / data-gradient Winograd convolutions" +
+                             (" and the Winograd weight gradients" if x3w else "; exact fp32 MFMA for the weight gradients"),
                              load_traffic(dom["name"], "train") if dom else None)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline_train(H, W, 4)

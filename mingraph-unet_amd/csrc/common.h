@@ -34,6 +34,7 @@ struct Tuning {
   int wino_ppb_cap = 32;
   bool wgrad_halo = true;   // MGU_NO_WGRAD_HALO=1
   bool wino_wgrad = true;   // MGU_NO_WINO_WGRAD=1
+  bool wgrad_x3 = true;     // MGU_NO_WGRAD_X3=1: Winograd weight gradient on the fp32 MFMA instead of the three-piece bf16 products
   bool wgrad_thin = true;   // MGU_NO_THIN_WGRAD=1
   bool wino_dgrad = true;   // MGU_NO_WINO_DGRAD=1
   bool gat_fused = true;    // MGU_NO_GAT_FUSED=1

@@ -135,8 +135,10 @@ int conv_wgrad(Bwd& w, const Layer& L, const float* dz) {
   {
     const double alg = 2.0 * d.M * (double)L.KS * L.KS * L.Cin * L.Cout;
     const bool ww = wino_wgrad_applicable(d) && !wgrad_thin_applicable(d);
-    ProfScope ps(c, w.s, wgrad_thin_applicable(d) ? "wgrad_thin kernels" : ww ? "wino_wgrad_f32_kernel" : "wgrad (direct) kernels", alg,
-                 ww ? alg * 16.0 / 36.0 : alg, wgrad_thin_applicable(d) ? -1 : 0);
+    const bool x3 = ww && c->tn.wgrad_x3;   // three-piece mode: six bf16 MFMA products per Winograd multiply, on the bf16 pipe
+    ProfScope ps(c, w.s,
+                 wgrad_thin_applicable(d) ? "wgrad_thin kernels" : x3 ? "wino_wgrad_f32_kernel<X3>" : ww ? "wino_wgrad_f32_kernel" : "wgrad (direct) kernels",
+                 alg, ww ? alg * 16.0 / 36.0 * (x3 ? 6.0 : 1.0) : alg, wgrad_thin_applicable(d) ? -1 : x3 ? 1 : 0);
     HIPCHK(c, launch_wgrad_f32(d, w.s));
   }
   HIPCHK(c, launch_unpack_conv_grad(w.dwp, d.groups, (size_t)d.N * d.Kp, w.flat + L.off_w, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, w.s));

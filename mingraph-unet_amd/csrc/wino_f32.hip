@@ -25,27 +25,13 @@
 //   * inverse transform: each wave folds its own row (M[i][.] A) in registers, the four row waves meet through a
 //     small LDS exchange, and lanes store one channel each (32 lanes = one 128-byte line of a pixel).
 #include "common.h"
+#include "x3.h"
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
 namespace mgu {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// exact three-way split of two fp32 values into packed bf16 pieces (low half: a, high half: b)
-__device__ __forceinline__ void split3_pack(const float a, const float b, unsigned& p0, unsigned& p1, unsigned& p2) {
-  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-  p0 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-  const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
-  const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
-  p1 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
-  const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
-  p2 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
-}
 // a * b + c as ONE v_fma_f32 the backend cannot pair with a neighbour into v_pk_fma_f32
 __device__ __forceinline__ float scalar_fma(float a, float b, float c) {
   float d;
@@ -58,9 +44,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     f(std::integral_constant<int, I>{});
     static_for<I + 1, N>(f);
   }
-}
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // Workgroup barrier for LDS hand-offs ONLY.  __syncthreads() is a workgroup-scope fence + barrier, and the fence makes

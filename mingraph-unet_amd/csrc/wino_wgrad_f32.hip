@@ -25,17 +25,15 @@
 #include <type_traits>
 
 #include "common.h"
+#include "x3.h"
 
 namespace mgu {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
 __device__ __forceinline__ void ww_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int CO_T, int CI_T>
-__global__ __launch_bounds__(256 * CI_T) void wino_wgrad_f32_kernel(const WgradDesc d, const int tiles_x, const int tiles_y,
+template <int CO_T, int CI_T, bool X3>
+__global__ __launch_bounds__(256 * CI_T, (X3 && CI_T == 1 && CO_T == 2) ? 2 : 1) void wino_wgrad_f32_kernel(const WgradDesc d, const int tiles_x, const int tiles_y,
                                                                     const int total_patches, const int patches_per_block,
                                                                     const int nci) {
   constexpr int NT = 256 * CI_T;               // threads
@@ -66,6 +64,7 @@ __global__ __launch_bounds__(256 * CI_T) void wino_wgrad_f32_kernel(const WgradD
   const float sgn = wi == 1 ? 1.f : -1.f;
   const float a0 = wi == 0 ? 1.f : (wi == 3 ? 0.f : 0.5f);
   const float a1 = wi == 0 ? 0.f : (wi == 1 ? 0.5f : (wi == 2 ? -0.5f : -1.f));
+  const float h0 = 0.5f * a0, h1 = 0.5f * a1;
 
   // ---- staging: thread -> (pixel, float4) of the halo and of the dz patch ----
   const int hq = tid % QI, hp0 = tid / QI;
@@ -111,39 +110,135 @@ __global__ __launch_bounds__(256 * CI_T) void wino_wgrad_f32_kernel(const WgradD
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][ct][r] = 0.f;
 
-  load_patch(p_begin);
+  // PF: the next patch is prefetched into registers while this one computes.  The three-piece 64 x 32 tile gives those 56 registers
+  // to the operand pieces instead (256 incl. the accumulators = two workgroups per CU, which cover each other's load phase).
+  constexpr bool PF = !(X3 && CI_T == 1 && CO_T == 2);
+  if (PF) load_patch(p_begin);
   for (int pi = 0; pi < npatch; ++pi) {
+    if (!PF) load_patch(p_begin + pi);
     ww_barrier();            // every wave is done with the previous patch
     store_patch();
     ww_barrier();            // patch visible
     // prefetch into registers while this patch computes -- UNCONDITIONAL (the last trip re-reads its own patch): a branch
     // around the loads makes hipcc wait for them at the join, i.e. before the MFMA loop instead of after it
-    load_patch(p_begin + min(pi + 1, npatch - 1));
+    if (PF) load_patch(p_begin + min(pi + 1, npatch - 1));
+    if constexpr (X3) {
+      // Three-piece mode (the default): the SAME sums on the bf16 matrix pipe.  v_mfma_f32_32x32x16_bf16 reduces over 16 tiles per
+      // instruction, a lane holding 8 of them per operand: lane half lh owns tiles (row 2ks + a, column 2u + lh), a = 0..1,
+      // u = 0..3 -> k = 8 lh + 4a + u (the two halves stay two pixels apart, so the LDS reads keep their bank-half split).
+      // S and V are formed as above, each value is split exactly into three bf16 pieces (x3.h) and a product is the six piece
+      // products of weight >= 2^-16: 24 CO_T MFMAs of 32 cycles per 16 tiles instead of 32 CO_T of 64, paid for with ~700 VALU
+      // operations -- the fp32 MFMA blocks the VALU while it runs, the bf16 one does not.
+#pragma unroll 1
+      for (int ks = 0; ks < 2; ++ks) {
+        // V values of this lane's 8 tiles, all four components of row i
+        float vv[4][8];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int ty = 2 * ks + a, tx = 2 * u + lh, t = 4 * a + u;
+            const float* hb = Hs + ((2 * ty) * HWID + 2 * tx) * PH + wg * 32 + lr;
+            float rr[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) rr[s4] = x3_fma(sgn, hb[(rb * HWID + s4) * PH], hb[(ra * HWID + s4) * PH]);
+            vv[0][t] = x3_sub(rr[0], rr[2]), vv[1][t] = x3_add(rr[1], rr[2]), vv[2][t] = x3_sub(rr[2], rr[1]), vv[3][t] = x3_sub(rr[1], rr[3]);
+          }
+        // HALF of (G dz)[i][0], [i][1] per tile and output-channel tile: the 1/2 of the column step is folded in (exact)
+        float cc[CO_T][2][8];
+        auto load_c = [&](const int ct) {
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int ty = 2 * ks + a, tx = 2 * u + lh, t = 4 * a + u;
+              const float* zb = Zs + ((2 * ty) * TW + 2 * tx) * PZ + ct * 32 + lr;
+              cc[ct][0][t] = x3_fma(h1, zb[TW * PZ], h0 * zb[0]);
+              cc[ct][1][t] = x3_fma(h1, zb[TW * PZ + PZ], h0 * zb[PZ]);
+            }
+        };
+        load_c(0);
+        u32x4 vb[4][3];   // V pieces [component j][piece], 8 packed tiles each: formed during the ct = 0 steps, reused by ct = 1
+        u32x4 sa[2][3];   // S pieces of the step in flight / the next one
+        // step = (output-channel tile ct, component j): its six MFMAs are issued between the split of the NEXT step's operands --
+        // the wave issues in order, so six MFMAs back to back stall it for five MFMA times while the VALU idles (first version:
+        // 28 % slower than the fp32 kernel it replaces)
+        auto prep = [&](auto st_c) {
+          constexpr int st = decltype(st_c)::value, ct = st >> 2, j = st & 3;
+          if constexpr (ct == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              unsigned p0, p1, p2;
+              split3_pack_s(vv[j][2 * e], vv[j][2 * e + 1], p0, p1, p2);
+              vb[j][0][e] = p0, vb[j][1][e] = p1, vb[j][2][e] = p2;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x[2];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+              const float p = cc[ct][0][2 * e + o], q = cc[ct][1][2 * e + o];
+              x[o] = j == 0 ? x3_add(p, p) : j == 1 ? x3_add(p, q) : j == 2 ? x3_sub(p, q) : x3_sub(-q, q);
+            }
+            unsigned p0, p1, p2;
+            split3_pack_s(x[0], x[1], p0, p1, p2);
+            sa[st & 1][0][e] = p0, sa[st & 1][1][e] = p1, sa[st & 1][2][e] = p2;
+          }
+        };
+        prep(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NS = 4 * CO_T;
+        x3_static_for<0, NS>([&](auto st_c) {
+          constexpr int st = decltype(st_c)::value, ct = st >> 2, j = st & 3, sl = st & 1;
+          f32x16 t = acc[j][ct];   // smallest products first
+          t = mfma_bf16(sa[sl][2], vb[j][0], t);
+          t = mfma_bf16(sa[sl][0], vb[j][2], t);
+          t = mfma_bf16(sa[sl][1], vb[j][1], t);
+          t = mfma_bf16(sa[sl][1], vb[j][0], t);
+          t = mfma_bf16(sa[sl][0], vb[j][1], t);
+          t = mfma_bf16(sa[sl][0], vb[j][0], t);
+          acc[j][ct] = t;
+          if constexpr (st + 1 < NS) prep(std::integral_constant<int, st + 1>{});
+          if constexpr (CO_T == 2 && st == 1) load_c(1);
+          constexpr int nvalu = (st + 1 < NS ? 52 : 0) + (st + 1 < 4 ? 44 : 0) + ((CO_T == 2 && st == 1) ? 32 : 0);
+          constexpr int per = (nvalu + 5) / 6;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (CO_T == 2 && st == 1) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            if constexpr (per > 0) __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+    } else {
 #pragma unroll 2
-    for (int kk = 0; kk < 16; ++kk) {
-      const int T = 2 * kk + lh;                 // this lane's tile of the k step (adjacent in x: bank halves differ)
-      const int ty = T >> 3, tx = T & 7;
-      // V[i][0..3] for this lane's input channel
-      const float* hb = Hs + ((2 * ty) * HWID + 2 * tx) * PH + wg * 32 + lr;
-      float rr[4];
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) rr[s4] = hb[(ra * HWID + s4) * PH] + sgn * hb[(rb * HWID + s4) * PH];
-      const float v0 = rr[0] - rr[2], v1 = rr[1] + rr[2], v2 = rr[2] - rr[1], v3 = rr[1] - rr[3];
-#pragma unroll
-      for (int ct = 0; ct < CO_T; ++ct) {
-        // S[i][0..3] for this lane's output channel of tile ct
-        const float* zb = Zs + ((2 * ty) * TW + 2 * tx) * PZ + ct * 32 + lr;
-        const float c0 = a0 * zb[0] + a1 * zb[TW * PZ];
-        const float c1 = a0 * zb[PZ] + a1 * zb[TW * PZ + PZ];
-        const float s0 = c0, s1 = 0.5f * (c0 + c1), s2 = 0.5f * (c0 - c1), s3 = -c1;
-        acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, v0, acc[0][ct], 0, 0, 0);
-        acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, v1, acc[1][ct], 0, 0, 0);
-        acc[2][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, v2, acc[2][ct], 0, 0, 0);
-        acc[3][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s3, v3, acc[3][ct], 0, 0, 0);
+      for (int kk = 0; kk < 16; ++kk) {
+        const int T = 2 * kk + lh;                 // this lane's tile of the k step (adjacent in x: bank halves differ)
+        const int ty = T >> 3, tx = T & 7;
+        // V[i][0..3] for this lane's input channel
+        const float* hb = Hs + ((2 * ty) * HWID + 2 * tx) * PH + wg * 32 + lr;
+        float rr[4];
+  #pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) rr[s4] = hb[(ra * HWID + s4) * PH] + sgn * hb[(rb * HWID + s4) * PH];
+        const float v0 = rr[0] - rr[2], v1 = rr[1] + rr[2], v2 = rr[2] - rr[1], v3 = rr[1] - rr[3];
+  #pragma unroll
+        for (int ct = 0; ct < CO_T; ++ct) {
+          // S[i][0..3] for this lane's output channel of tile ct
+          const float* zb = Zs + ((2 * ty) * TW + 2 * tx) * PZ + ct * 32 + lr;
+          const float c0 = a0 * zb[0] + a1 * zb[TW * PZ];
+          const float c1 = a0 * zb[PZ] + a1 * zb[TW * PZ + PZ];
+          const float s0 = c0, s1 = 0.5f * (c0 + c1), s2 = 0.5f * (c0 - c1), s3 = -c1;
+          acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s0, v0, acc[0][ct], 0, 0, 0);
+          acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s1, v1, acc[1][ct], 0, 0, 0);
+          acc[2][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s2, v2, acc[2][ct], 0, 0, 0);
+          acc[3][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s3, v3, acc[3][ct], 0, 0, 0);
+        }
       }
     }
-  }
-
+  
+    }
   // ---- inverse transform dW = A^T M A, once per workgroup ---------------------------------------------------------
   // column part in registers (q = 0..2 over j), row part through LDS (p = 0..2 over i):
   //   [q0 q1 q2] = [M0+M1+M2, M1-M2, M1+M2+M3];   [p0 p1 p2] = [Z0+Z1+Z2, Z1-Z2, Z1+Z2+Z3]
@@ -192,8 +287,8 @@ bool wino_wgrad_applicable(const WgradDesc& d) {
          d.dw_capacity >= (size_t)d.N * d.Kp;
 }
 
-template <int CO_T, int CI_T>
-static hipError_t launch_ww(WgradDesc& d, hipStream_t s) {
+template <int CO_T, int CI_T, bool X3>
+static hipError_t launch_ww_x(WgradDesc& d, hipStream_t s) {
   const int tiles_x = (d.W + 15) / 16, tiles_y = (d.H + 7) / 8;
   const int B = d.M / (d.H * d.W);
   const int total = tiles_x * tiles_y * B;
@@ -209,15 +304,24 @@ static hipError_t launch_ww(WgradDesc& d, hipStream_t s) {
   d.groups = groups;
   const size_t lds = (size_t)((8 + 2) * 18 * (32 * CI_T + 16) + 8 * 16 * (32 * CO_T + 16)) * sizeof(float);
   static bool attr_done[64] = {};
-  hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&wino_wgrad_f32_kernel<CO_T, CI_T>), lds, attr_done);
+  hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&wino_wgrad_f32_kernel<CO_T, CI_T, X3>), lds, attr_done);
   if (ae != hipSuccess) return ae;
-  hipLaunchKernelGGL((wino_wgrad_f32_kernel<CO_T, CI_T>), dim3(groups, nci * nco), dim3(256 * CI_T), lds, s, d, tiles_x, tiles_y, total,
+  hipLaunchKernelGGL((wino_wgrad_f32_kernel<CO_T, CI_T, X3>), dim3(groups, nci * nco), dim3(256 * CI_T), lds, s, d, tiles_x, tiles_y, total,
                      ppb, nci);
   return hipGetLastError();
 }
 
+template <int CO_T, int CI_T>
+static hipError_t launch_ww(WgradDesc& d, hipStream_t s) {
+  return tun(d).wgrad_x3 ? launch_ww_x<CO_T, CI_T, true>(d, s) : launch_ww_x<CO_T, CI_T, false>(d, s);
+}
+
 hipError_t launch_wino_wgrad_f32(WgradDesc& d, hipStream_t s) {
   const bool co2 = d.N % 64 == 0, ci2 = d.Cp % 64 == 0;
+  // three-piece mode: the 64 x 64 tile needs 256 registers + spills (measured 28 % slower than its fp32-MFMA form), the 64 x 32
+  // tile does not (344 incl. accumulators, one wave per SIMD) and is the most efficient of the four -- 25 M wave-cycles per issued GFLOP
+  // against 44 for the fp32 64 x 64 tile
+  if (tun(d).wgrad_x3 && co2) return launch_ww_x<2, 1, true>(d, s);
   if (co2 && ci2) return launch_ww<2, 2>(d, s);
   if (co2) return launch_ww<2, 1>(d, s);
   if (ci2) return launch_ww<1, 2>(d, s);
