@@ -17,13 +17,26 @@ __device__ __forceinline__ void split3_pack(const float a, const float b, unsign
   const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);
   p2 = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
 }
+// round-to-nearest pieces via v_cvt_pk_bf16_f32 + remainders via v_dot2c_f32_bf16 (x3.h split3_pack_d): 7 VALU per pair instead of 11
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pack_d(const bf16x2 lo, const bf16x2 hi, const float a, const float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+  const bf16x2 q0 = {(__bf16)a, (__bf16)b};
+  const float ra = __builtin_amdgcn_fdot2_f32_bf16(q0, lo, a, false), rb = __builtin_amdgcn_fdot2_f32_bf16(q0, hi, b, false);
+  const bf16x2 q1 = {(__bf16)ra, (__bf16)rb};
+  const float sa = __builtin_amdgcn_fdot2_f32_bf16(q1, lo, ra, false), sb = __builtin_amdgcn_fdot2_f32_bf16(q1, hi, rb, false);
+  const bf16x2 q2 = {(__bf16)sa, (__bf16)sb};
+  p0 = __builtin_bit_cast(unsigned, q0), p1 = __builtin_bit_cast(unsigned, q1), p2 = __builtin_bit_cast(unsigned, q2);
+}
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // WHAT: 1 = split only, 2 = MFMA only, 3 = both (software pipelined: MFMAs of step s with the split of step s+1)
-template <int WHAT, int INTERLEAVE, int NCH>
+template <int WHAT, int INTERLEAVE, int NCH, int DOT>
 __global__ __launch_bounds__(512) void k(float* out, int iters, float seed, long long* cyc) {
+  unsigned klo = 0x0000BF80u, khi = 0xBF800000u;
+  asm volatile("" : "+v"(klo), "+v"(khi));
+  const bf16x2 lo = __builtin_bit_cast(bf16x2, klo), hi = __builtin_bit_cast(bf16x2, khi);
   f32x16 acc[8];
   for (int j = 0; j < 8; ++j)
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
@@ -60,7 +73,8 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, float seed, long
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             unsigned p0, p1, p2;
-            split3_pack(v[hf][2 * e], v[hf][2 * e + 1], p0, p1, p2);
+            if (DOT) split3_pack_d(lo, hi, v[hf][2 * e], v[hf][2 * e + 1], p0, p1, p2);
+            else split3_pack(v[hf][2 * e], v[hf][2 * e + 1], p0, p1, p2);
             pc[(st + 1) & 1][0][hf * 2 + e] = p0, pc[(st + 1) & 1][1][hf * 2 + e] = p1, pc[(st + 1) & 1][2][hf * 2 + e] = p2;
           }
         // make the next split depend on this one's input cheaply (keeps the compiler from hoisting it out of the loop)
@@ -71,7 +85,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, float seed, long
 #pragma unroll
         for (int q = 0; q < 6 * NCH; ++q) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, NCH == 2 ? 5 : 9, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, DOT ? (NCH == 2 ? 3 : 6) : (NCH == 2 ? 5 : 9), 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -87,16 +101,16 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, float seed, long
   if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
-template <int WHAT, int IL, int NCH>
+template <int WHAT, int IL, int NCH, int DOT = 0>
 static void run(int threads, float* d, long long* dc) {
   const int iters = 2000;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<WHAT, IL, NCH>), dim3(256), dim3(threads), 0, 0, d, 10, 1.f, dc);
+  hipLaunchKernelGGL((k<WHAT, IL, NCH, DOT>), dim3(256), dim3(threads), 0, 0, d, 10, 1.f, dc);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0);
-  hipLaunchKernelGGL((k<WHAT, IL, NCH>), dim3(256), dim3(threads), 0, 0, d, iters, 1.f, dc);
+  hipLaunchKernelGGL((k<WHAT, IL, NCH, DOT>), dim3(256), dim3(threads), 0, 0, d, iters, 1.f, dc);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms;
@@ -104,7 +118,7 @@ static void run(int threads, float* d, long long* dc) {
   long long c;
   (void)hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
   static const char* wn[] = {"", "split only (8 values: 44 VALU)", "6*chains MFMA only", "6*chains MFMA + split"};
-  printf("waves/SIMD=%d chains=%d %-32s interleave=%d  %7.1f ns per step per wave (wall)  %7.1f counter ticks per step\n", threads / 256, NCH, wn[WHAT], IL,
+  printf("%s waves/SIMD=%d chains=%d %-32s interleave=%d  %7.1f ns per step per wave (wall)  %7.1f counter ticks per step\n", DOT ? "dot2c" : "trunc", threads / 256, NCH, wn[WHAT], IL,
          ms * 1e6 / (iters * 4.0), (double)c / (iters * 4.0));
 }
 
@@ -121,6 +135,11 @@ int main() {
     run<2, 0, 2>(threads, d, dc);
     run<3, 0, 2>(threads, d, dc);
     run<3, 1, 2>(threads, d, dc);
+    run<1, 0, 1, 1>(threads, d, dc);
+    run<3, 0, 1, 1>(threads, d, dc);
+    run<3, 1, 1, 1>(threads, d, dc);
+    run<3, 0, 2, 1>(threads, d, dc);
+    run<3, 1, 2, 1>(threads, d, dc);
   }
   return 0;
 }
