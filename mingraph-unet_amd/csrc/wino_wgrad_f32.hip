@@ -32,6 +32,138 @@ namespace mgu {
 
 __device__ __forceinline__ void ww_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- inverse transform dW = A^T M A, once per workgroup: every wave is past its last LDS operand read when it gets here ----------
+template <int CO_T, int CI_T>
+__device__ __forceinline__ void ww_epilogue(const WgradDesc& d, float* smem, f32x16 (&acc)[4][CO_T], const int wi, const int wg, const int lane,
+                                            const int lr, const int lh, const int cob, const int cib) {
+  // column part in registers (q = 0..2 over j), row part through LDS (p = 0..2 over i):
+  //   [q0 q1 q2] = [M0+M1+M2, M1-M2, M1+M2+M3];   [p0 p1 p2] = [Z0+Z1+Z2, Z1-Z2, Z1+Z2+Z3]
+  float* Zx = smem;   // exchange: [4 rows i][CI_T g][4 register quads][64 lanes][4]   (<= 32 KB; the staging buffers are free)
+  float* const part = d.dw + (size_t)blockIdx.x * d.N * d.Kp;
+  const int co0 = cob * (32 * CO_T), ci0 = cib * (32 * CI_T) + wg * 32;
+#pragma unroll
+  for (int ct = 0; ct < CO_T; ++ct) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      ww_barrier();   // previous pass consumed (first pass: every wave is past its last LDS operand read)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rq + e;
+          z[e] = q == 0 ? acc[0][ct][r] + acc[1][ct][r] + acc[2][ct][r]
+               : q == 1 ? acc[1][ct][r] - acc[2][ct][r]
+                        : acc[1][ct][r] + acc[2][ct][r] + acc[3][ct][r];
+        }
+        *reinterpret_cast<f32x4*>(Zx + ((((wi * CI_T + wg) * 4 + rq) * 64) + lane) * 4) = z;
+      }
+      ww_barrier();
+      // wave i finishes accumulator registers 4i .. 4i+3: rows (co) 8i + 4*lh + (0..3) of output tile ct, column ci = lr
+      const f32x4 z0 = *reinterpret_cast<const f32x4*>(Zx + ((((0 * CI_T + wg) * 4 + wi) * 64) + lane) * 4);
+      const f32x4 z1 = *reinterpret_cast<const f32x4*>(Zx + ((((1 * CI_T + wg) * 4 + wi) * 64) + lane) * 4);
+      const f32x4 z2 = *reinterpret_cast<const f32x4*>(Zx + ((((2 * CI_T + wg) * 4 + wi) * 64) + lane) * 4);
+      const f32x4 z3 = *reinterpret_cast<const f32x4*>(Zx + ((((3 * CI_T + wg) * 4 + wi) * 64) + lane) * 4);
+      const f32x4 p0 = z0 + z1 + z2, p1 = z1 - z2, p2 = z1 + z2 + z3;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + ct * 32 + 8 * wi + 4 * lh + e;
+        float* row = part + (size_t)co * d.Kp + ci0 + lr;
+        row[(0 * 3 + q) * d.Cp] = p0[e];
+        row[(1 * 3 + q) * d.Cp] = p1[e];
+        row[(2 * 3 + q) * d.Cp] = p2[e];
+      }
+    }
+  }
+}
+
+// One k step (16 tiles: tile rows 2ks, 2ks+1) of the three-piece mode for wave (transform row i, input-channel tile g):
+//   hread(sel, a, u, s4): raw input of halo row 2a + (sel ? rb : ra), column 4u + s4 of this lane's tiles, channel = lane
+//   zread(ct, a, u, dy, dx): dz of pixel (2a + dy, 4u + dx), channel = lane of output tile ct
+// (the lane half's two-pixel shift and the k-step's row offset are in the callers' base pointers).
+template <int CO_T, class HRead, class ZRead>
+__device__ __forceinline__ void ww_x3_kstep(f32x16 (&acc)[4][CO_T], const HRead& hread, const ZRead& zread, const float sgn, const float h0,
+                                            const float h1) {
+    // V values of this lane's 8 tiles, all four components of row i
+    float vv[4][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = 4 * a + u;
+        float rr[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) rr[s4] = x3_fma(sgn, hread(1, a, u, s4), hread(0, a, u, s4));
+        vv[0][t] = x3_sub(rr[0], rr[2]), vv[1][t] = x3_add(rr[1], rr[2]), vv[2][t] = x3_sub(rr[2], rr[1]), vv[3][t] = x3_sub(rr[1], rr[3]);
+      }
+    // HALF of (G dz)[i][0], [i][1] per tile and output-channel tile: the 1/2 of the column step is folded in (exact)
+    float cc[CO_T][2][8];
+    auto load_c = [&](const int ct) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = 4 * a + u;
+          cc[ct][0][t] = x3_fma(h1, zread(ct, a, u, 1, 0), h0 * zread(ct, a, u, 0, 0));
+          cc[ct][1][t] = x3_fma(h1, zread(ct, a, u, 1, 1), h0 * zread(ct, a, u, 0, 1));
+        }
+    };
+    load_c(0);
+    u32x4 vb[4][3];   // V pieces [component j][piece], 8 packed tiles each: formed during the ct = 0 steps, reused by ct = 1
+    u32x4 sa[2][3];   // S pieces of the step in flight / the next one
+    // step = (output-channel tile ct, component j): its six MFMAs are issued between the split of the NEXT step's operands --
+    // the wave issues in order, so six MFMAs back to back stall it for five MFMA times while the VALU idles (first version:
+    // 28 % slower than the fp32 kernel it replaces)
+    auto prep = [&](auto st_c) {
+      constexpr int st = decltype(st_c)::value, ct = st >> 2, j = st & 3;
+      if constexpr (ct == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned p0, p1, p2;
+          split3_pack_s(vv[j][2 * e], vv[j][2 * e + 1], p0, p1, p2);
+          vb[j][0][e] = p0, vb[j][1][e] = p1, vb[j][2][e] = p2;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const float p = cc[ct][0][2 * e + o], q = cc[ct][1][2 * e + o];
+          x[o] = j == 0 ? x3_add(p, p) : j == 1 ? x3_add(p, q) : j == 2 ? x3_sub(p, q) : x3_sub(-q, q);
+        }
+        unsigned p0, p1, p2;
+        split3_pack_s(x[0], x[1], p0, p1, p2);
+        sa[st & 1][0][e] = p0, sa[st & 1][1][e] = p1, sa[st & 1][2][e] = p2;
+      }
+    };
+    prep(std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NS = 4 * CO_T;
+    x3_static_for<0, NS>([&](auto st_c) {
+      constexpr int st = decltype(st_c)::value, ct = st >> 2, j = st & 3, sl = st & 1;
+      f32x16 t = acc[j][ct];   // smallest products first
+      t = mfma_bf16(sa[sl][2], vb[j][0], t);
+      t = mfma_bf16(sa[sl][0], vb[j][2], t);
+      t = mfma_bf16(sa[sl][1], vb[j][1], t);
+      t = mfma_bf16(sa[sl][1], vb[j][0], t);
+      t = mfma_bf16(sa[sl][0], vb[j][1], t);
+      t = mfma_bf16(sa[sl][0], vb[j][0], t);
+      acc[j][ct] = t;
+      if constexpr (st + 1 < NS) prep(std::integral_constant<int, st + 1>{});
+      if constexpr (CO_T == 2 && st == 1) load_c(1);
+      constexpr int nvalu = (st + 1 < NS ? 52 : 0) + (st + 1 < 4 ? 44 : 0) + ((CO_T == 2 && st == 1) ? 32 : 0);
+      constexpr int per = (nvalu + 5) / 6;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (CO_T == 2 && st == 1) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        if constexpr (per > 0) __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
 template <int CO_T, int CI_T, bool X3>
 __global__ __launch_bounds__(256 * CI_T, (X3 && CI_T == 1 && CO_T == 2) ? 2 : 1) void wino_wgrad_f32_kernel(const WgradDesc d, const int tiles_x, const int tiles_y,
                                                                     const int total_patches, const int patches_per_block,
@@ -131,86 +263,11 @@ __global__ __launch_bounds__(256 * CI_T, (X3 && CI_T == 1 && CO_T == 2) ? 2 : 1)
       // operations -- the fp32 MFMA blocks the VALU while it runs, the bf16 one does not.
 #pragma unroll 1
       for (int ks = 0; ks < 2; ++ks) {
-        // V values of this lane's 8 tiles, all four components of row i
-        float vv[4][8];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int ty = 2 * ks + a, tx = 2 * u + lh, t = 4 * a + u;
-            const float* hb = Hs + ((2 * ty) * HWID + 2 * tx) * PH + wg * 32 + lr;
-            float rr[4];
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) rr[s4] = x3_fma(sgn, hb[(rb * HWID + s4) * PH], hb[(ra * HWID + s4) * PH]);
-            vv[0][t] = x3_sub(rr[0], rr[2]), vv[1][t] = x3_add(rr[1], rr[2]), vv[2][t] = x3_sub(rr[2], rr[1]), vv[3][t] = x3_sub(rr[1], rr[3]);
-          }
-        // HALF of (G dz)[i][0], [i][1] per tile and output-channel tile: the 1/2 of the column step is folded in (exact)
-        float cc[CO_T][2][8];
-        auto load_c = [&](const int ct) {
-#pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int ty = 2 * ks + a, tx = 2 * u + lh, t = 4 * a + u;
-              const float* zb = Zs + ((2 * ty) * TW + 2 * tx) * PZ + ct * 32 + lr;
-              cc[ct][0][t] = x3_fma(h1, zb[TW * PZ], h0 * zb[0]);
-              cc[ct][1][t] = x3_fma(h1, zb[TW * PZ + PZ], h0 * zb[PZ]);
-            }
-        };
-        load_c(0);
-        u32x4 vb[4][3];   // V pieces [component j][piece], 8 packed tiles each: formed during the ct = 0 steps, reused by ct = 1
-        u32x4 sa[2][3];   // S pieces of the step in flight / the next one
-        // step = (output-channel tile ct, component j): its six MFMAs are issued between the split of the NEXT step's operands --
-        // the wave issues in order, so six MFMAs back to back stall it for five MFMA times while the VALU idles (first version:
-        // 28 % slower than the fp32 kernel it replaces)
-        auto prep = [&](auto st_c) {
-          constexpr int st = decltype(st_c)::value, ct = st >> 2, j = st & 3;
-          if constexpr (ct == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              unsigned p0, p1, p2;
-              split3_pack_s(vv[j][2 * e], vv[j][2 * e + 1], p0, p1, p2);
-              vb[j][0][e] = p0, vb[j][1][e] = p1, vb[j][2][e] = p2;
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x[2];
-#pragma unroll
-            for (int o = 0; o < 2; ++o) {
-              const float p = cc[ct][0][2 * e + o], q = cc[ct][1][2 * e + o];
-              x[o] = j == 0 ? x3_add(p, p) : j == 1 ? x3_add(p, q) : j == 2 ? x3_sub(p, q) : x3_sub(-q, q);
-            }
-            unsigned p0, p1, p2;
-            split3_pack_s(x[0], x[1], p0, p1, p2);
-            sa[st & 1][0][e] = p0, sa[st & 1][1][e] = p1, sa[st & 1][2][e] = p2;
-          }
-        };
-        prep(std::integral_constant<int, 0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int NS = 4 * CO_T;
-        x3_static_for<0, NS>([&](auto st_c) {
-          constexpr int st = decltype(st_c)::value, ct = st >> 2, j = st & 3, sl = st & 1;
-          f32x16 t = acc[j][ct];   // smallest products first
-          t = mfma_bf16(sa[sl][2], vb[j][0], t);
-          t = mfma_bf16(sa[sl][0], vb[j][2], t);
-          t = mfma_bf16(sa[sl][1], vb[j][1], t);
-          t = mfma_bf16(sa[sl][1], vb[j][0], t);
-          t = mfma_bf16(sa[sl][0], vb[j][1], t);
-          t = mfma_bf16(sa[sl][0], vb[j][0], t);
-          acc[j][ct] = t;
-          if constexpr (st + 1 < NS) prep(std::integral_constant<int, st + 1>{});
-          if constexpr (CO_T == 2 && st == 1) load_c(1);
-          constexpr int nvalu = (st + 1 < NS ? 52 : 0) + (st + 1 < 4 ? 44 : 0) + ((CO_T == 2 && st == 1) ? 32 : 0);
-          constexpr int per = (nvalu + 5) / 6;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if constexpr (CO_T == 2 && st == 1) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            if constexpr (per > 0) __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        });
+        const float* const hks = Hs + (4 * ks * HWID + 2 * lh) * PH + wg * 32 + lr;   // tile rows 2ks, 2ks+1; this half's tile columns
+        const float* const zks = Zs + (4 * ks * TW + 2 * lh) * PZ + lr;
+        ww_x3_kstep<CO_T>(
+            acc, [&](int sel, int a, int u, int s4) { return hks[((2 * a + (sel ? rb : ra)) * HWID + 4 * u + s4) * PH]; },
+            [&](int ct, int a, int u, int dy, int dx) { return zks[((2 * a + dy) * TW + 4 * u + dx) * PZ + ct * 32]; }, sgn, h0, h1);
       }
     } else {
 #pragma unroll 2
@@ -239,46 +296,7 @@ __global__ __launch_bounds__(256 * CI_T, (X3 && CI_T == 1 && CO_T == 2) ? 2 : 1)
     }
   
     }
-  // ---- inverse transform dW = A^T M A, once per workgroup ---------------------------------------------------------
-  // column part in registers (q = 0..2 over j), row part through LDS (p = 0..2 over i):
-  //   [q0 q1 q2] = [M0+M1+M2, M1-M2, M1+M2+M3];   [p0 p1 p2] = [Z0+Z1+Z2, Z1-Z2, Z1+Z2+Z3]
-  float* Zx = smem;   // exchange: [4 rows i][CI_T g][4 register quads][64 lanes][4]   (<= 32 KB; the staging buffers are free)
-  float* const part = d.dw + (size_t)blockIdx.x * d.N * d.Kp;
-  const int co0 = cob * (32 * CO_T), ci0 = cib * (32 * CI_T) + wg * 32;
-#pragma unroll
-  for (int ct = 0; ct < CO_T; ++ct) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      ww_barrier();   // previous pass consumed (first pass: every wave is past its last LDS operand read)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        f32x4 z;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * rq + e;
-          z[e] = q == 0 ? acc[0][ct][r] + acc[1][ct][r] + acc[2][ct][r]
-               : q == 1 ? acc[1][ct][r] - acc[2][ct][r]
-                        : acc[1][ct][r] + acc[2][ct][r] + acc[3][ct][r];
-        }
-        *reinterpret_cast<f32x4*>(Zx + ((((wi * CI_T + wg) * 4 + rq) * 64) + lane) * 4) = z;
-      }
-      ww_barrier();
-      // wave i finishes accumulator registers 4i .. 4i+3: rows (co) 8i + 4*lh + (0..3) of output tile ct, column ci = lr
-      const f32x4 z0 = *reinterpret_cast<const f32x4*>(Zx + ((((0 * CI_T + wg) * 4 + wi) * 64) + lane) * 4);
-      const f32x4 z1 = *reinterpret_cast<const f32x4*>(Zx + ((((1 * CI_T + wg) * 4 + wi) * 64) + lane) * 4);
-      const f32x4 z2 = *reinterpret_cast<const f32x4*>(Zx + ((((2 * CI_T + wg) * 4 + wi) * 64) + lane) * 4);
-      const f32x4 z3 = *reinterpret_cast<const f32x4*>(Zx + ((((3 * CI_T + wg) * 4 + wi) * 64) + lane) * 4);
-      const f32x4 p0 = z0 + z1 + z2, p1 = z1 - z2, p2 = z1 + z2 + z3;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int co = co0 + ct * 32 + 8 * wi + 4 * lh + e;
-        float* row = part + (size_t)co * d.Kp + ci0 + lr;
-        row[(0 * 3 + q) * d.Cp] = p0[e];
-        row[(1 * 3 + q) * d.Cp] = p1[e];
-        row[(2 * 3 + q) * d.Cp] = p2[e];
-      }
-    }
-  }
+  ww_epilogue<CO_T, CI_T>(d, smem, acc, wi, wg, lane, lr, lh, cob, cib);
 }
 
 bool wino_wgrad_applicable(const WgradDesc& d) {
@@ -313,14 +331,16 @@ static hipError_t launch_ww_x(WgradDesc& d, hipStream_t s) {
 
 template <int CO_T, int CI_T>
 static hipError_t launch_ww(WgradDesc& d, hipStream_t s) {
-  return tun(d).wgrad_x3 ? launch_ww_x<CO_T, CI_T, true>(d, s) : launch_ww_x<CO_T, CI_T, false>(d, s);
+  if constexpr (CO_T == 2 && CI_T == 2) return launch_ww_x<2, 2, false>(d, s);   // three-piece mode never takes this tile (see below)
+  else return tun(d).wgrad_x3 ? launch_ww_x<CO_T, CI_T, true>(d, s) : launch_ww_x<CO_T, CI_T, false>(d, s);
 }
 
 hipError_t launch_wino_wgrad_f32(WgradDesc& d, hipStream_t s) {
   const bool co2 = d.N % 64 == 0, ci2 = d.Cp % 64 == 0;
   // three-piece mode: the 64 x 64 tile needs 256 registers + spills (measured 28 % slower than its fp32-MFMA form), the 64 x 32
-  // tile does not (344 incl. accumulators, one wave per SIMD) and is the most efficient of the four -- 25 M wave-cycles per issued GFLOP
-  // against 44 for the fp32 64 x 64 tile
+  // tile without register prefetch does not (254, two workgroups per CU cover each other's load phase).  A 64 x 64 tile with LDS-DMA
+  // staging into a second LDS buffer (global_load_lds_dwordx4, XOR-swizzled dense images, counted vmcnt) was built and measured EQUAL
+  // to it on every layer shape (88-92 us per 8.6 issued GFLOP either way): staging is not what bounds this kernel, VALU issue is
   if (tun(d).wgrad_x3 && co2) return launch_ww_x<2, 1, true>(d, s);
   if (co2 && ci2) return launch_ww<2, 2>(d, s);
   if (co2) return launch_ww<2, 1>(d, s);
