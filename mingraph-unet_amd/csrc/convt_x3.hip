@@ -70,11 +70,18 @@ __global__ void pack_convt_x3_kernel(const float* __restrict__ w, uint16_t* __re
   }
 }
 
+// LDS hand-off barrier without the workgroup fence of __syncthreads(), which makes hipcc wait vmcnt(0): the prefetched loads of the next
+// steps would be drained at every step (wino_f32.hip: lds_barrier)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __restrict__ in, const int ldin, const uint16_t* __restrict__ Wx,
                                                              const float* __restrict__ shift, float* __restrict__ out, const int M,
                                                              const int H, const int W, const int Cin, const int Cout, const int ldout,
                                                              const int coff, const int Hout, const int Wout, const int ntn,
                                                              const int nblocks) {
+  // A pieces of one K = 32 step: [2 buffers][3 pieces][128 rows][32 k + 8 pad] bf16 (80-byte rows: conflict-free ds_read_b128)
+  constexpr int AP = 40, ABUF = 3 * 128 * AP;
+  __shared__ __attribute__((aligned(16))) uint16_t As[2 * ABUF];
   __shared__ int rowoff[128];
   // XCD-aware order: hardware deals consecutive workgroup ids round-robin to the 8 XCDs; logical block lb runs on XCD
   // blockIdx % 8 and a contiguous range of logical blocks (all n tiles of a pixel tile, neighbouring pixel tiles) shares an L2
@@ -102,16 +109,43 @@ __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __rest
     }
     rowoff[tid] = off;
   }
-  __syncthreads();
 
-  const int ksteps = Cin >> 4;
-  const float* ap[2];
+  // ---- A staging: the 128 x 32 fp32 tile of a step is read ONCE per workgroup in whole 128-byte rows (8 lanes x 16 B per row, 32
+  // rows per instruction), split into its three bf16 pieces by the thread that loaded it, and the pieces go to LDS in the k order
+  // the MFMA fragments want.  (Round 2 loaded fragment-shaped pieces straight into registers: 16-byte pieces of 32 different lines
+  // per instruction, every row fetched and split by both n-halves of the workgroup, a one-step lead that did not cover an L2 round
+  // trip -- the four layers ran at 20-35 % of the matrix pipe with nothing else saturated.)
+  const int arow = tid >> 3, ach = (tid & 7) * 4;
+  const float* aptr[4];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int row = min(bm0 + wm * 64 + mi * 32 + lr, M - 1);   // rows past the end re-read the last pixel, never stored
-    ap[mi] = in + (size_t)row * ldin + lh * 8;
-  }
-  const u32x4* const bp = reinterpret_cast<const u32x4*>(Wx) + ((size_t)nt * ksteps * 12 + wn * 6) * 64 + lane;
+  for (int j = 0; j < 4; ++j) aptr[j] = in + (size_t)min(bm0 + j * 32 + arow, M - 1) * ldin + ach;   // rows past the end: re-read, never stored
+  const int nk = Cin >> 5;   // K = 32 steps
+  f32x4 areg[2][4];          // two steps in flight: an L2 / HBM round trip is longer than one step's 48 MFMAs
+  auto load_a = [&](int s, auto set_t) {
+    constexpr int set = decltype(set_t)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) areg[set][j] = *reinterpret_cast<const f32x4*>(aptr[j] + s * 32);
+  };
+  auto store_a = [&](int buf, auto set_t) {
+    constexpr int set = decltype(set_t)::value;
+    uint16_t* const base = As + buf * ABUF + arow * AP + ach;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned p[3][2];
+      split3_pack(areg[set][j][0], areg[set][j][1], p[0][0], p[1][0], p[2][0]);
+      split3_pack(areg[set][j][2], areg[set][j][3], p[0][1], p[1][1], p[2][1]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<uint2*>(base + (q * 128 + j * 32) * AP) = uint2{p[q][0], p[q][1]};
+    }
+  };
+
+  const u32x4* const bp = reinterpret_cast<const u32x4*>(Wx) + ((size_t)nt * (Cin >> 4) * 12 + wn * 6) * 64 + lane;
+  u32x4 br[2][6];      // [buffer][n tile * 3 + piece] of a K = 16 half step, one half step ahead
+  auto load_b = [&](int kk, auto buf_t) {
+    constexpr int buf = decltype(buf_t)::value;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) br[buf][f] = bp[((size_t)kk * 12 + f) * 64];
+  };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -121,65 +155,76 @@ __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  f32x4 ar[2][2][2];   // [buffer][m tile][k half]
-  u32x4 br[2][6];      // [buffer][n tile * 3 + piece]
-  auto load = [&](int s, auto buf_t) {
-    constexpr int buf = decltype(buf_t)::value;
-#pragma unroll
-    for (int f = 0; f < 6; ++f) br[buf][f] = bp[((size_t)s * 12 + f) * 64];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      ar[buf][mi][0] = *reinterpret_cast<const f32x4*>(ap[mi] + s * 16);
-      ar[buf][mi][1] = *reinterpret_cast<const f32x4*>(ap[mi] + s * 16 + 4);
-    }
-  };
-  auto compute = [&](auto buf_t) {
-    constexpr int buf = decltype(buf_t)::value;
+  const int aoff = (wm * 64 + lr) * AP + lh * 8;   // this lane's fragment: row wm*64 + mi*32 + lr, k = 16 ss + 8 lh .. + 7
+  auto half_step = [&](int buf, int ss, auto bb_t) {
+    constexpr int bb = decltype(bb_t)::value;
     u32x4 pa[2][3];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          unsigned p0, p1, p2;
-          split3_pack(ar[buf][mi][hf][2 * e], ar[buf][mi][hf][2 * e + 1], p0, p1, p2);
-          pa[mi][0][2 * hf + e] = p0, pa[mi][1][2 * hf + e] = p1, pa[mi][2][2 * hf + e] = p2;
-        }
+      for (int q = 0; q < 3; ++q)
+        pa[mi][q] = *reinterpret_cast<const u32x4*>(As + buf * ABUF + (q * 128 + mi * 32) * AP + aoff + ss * 16);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         f32x16 t = acc[mi][ni];
         // smallest terms first
-        t = mfma_bf16(pa[mi][2], br[buf][ni * 3 + 0], t);
-        t = mfma_bf16(pa[mi][0], br[buf][ni * 3 + 2], t);
-        t = mfma_bf16(pa[mi][1], br[buf][ni * 3 + 1], t);
-        t = mfma_bf16(pa[mi][1], br[buf][ni * 3 + 0], t);
-        t = mfma_bf16(pa[mi][0], br[buf][ni * 3 + 1], t);
-        t = mfma_bf16(pa[mi][0], br[buf][ni * 3 + 0], t);
+        t = mfma_bf16(pa[mi][2], br[bb][ni * 3 + 0], t);
+        t = mfma_bf16(pa[mi][0], br[bb][ni * 3 + 2], t);
+        t = mfma_bf16(pa[mi][1], br[bb][ni * 3 + 1], t);
+        t = mfma_bf16(pa[mi][1], br[bb][ni * 3 + 0], t);
+        t = mfma_bf16(pa[mi][0], br[bb][ni * 3 + 1], t);
+        t = mfma_bf16(pa[mi][0], br[bb][ni * 3 + 0], t);
         acc[mi][ni] = t;
       }
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  // two K steps per trip, both unconditional: a conditional half makes hipcc merge the pending-load state of the two paths at
-  // the loop top into s_waitcnt vmcnt(0) -- every step then waited for the NEXT step's loads and the double buffer hid nothing
-  load(0, B0{});
-  int s = 0;
-  for (; s + 2 <= ksteps; s += 2) {
-    // sched_barrier: hipcc otherwise sinks the loads of the next step behind the MFMAs of this one (next to their uses), i.e.
-    // undoes the double buffer
-    load(s + 1, B1{});
+  const int nkk = 2 * nk;
+  // prologue: step 0 in LDS, step 1 in register set 1, the first weight fragments on their way
+  load_a(0, B0{});
+  load_a(min(1, nk - 1), B1{});
+  load_b(0, B0{});
+  store_a(0, B0{});   // waits for set 0 only (loads retire in order)
+  lds_barrier();
+  // two steps per trip so that the register set of a load is a compile-time fact; every load and every LDS store is unconditional
+  // (clamped index; the last step re-stores its own tile into the buffer nobody reads any more), so a step is ONE basic block and the
+  // split of the next tile can be scheduled between the MFMAs of the second half step (a wave issues in order: 24 MFMAs back to back
+  // stall it for 23 MFMA times while its ~100 VALU operations wait behind them)
+  auto second_half_and_stage = [&](int buf, auto bb_t, auto set_t) {
+    half_step(buf, 1, bb_t);
+    store_a(buf ^ 1, set_t);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x200, 12, 0);
+  };
+  for (int s = 0; s < nk; s += 2) {
+    // ---- step s (LDS buffer 0); set 1 holds step s + 1, set 0 is free
+    load_a(min(s + 2, nk - 1), B0{});
+    load_b(min(2 * s + 1, nkk - 1), B1{});
     __builtin_amdgcn_sched_barrier(0);
-    compute(B0{});
+    half_step(0, 0, B0{});
+    load_b(min(2 * s + 2, nkk - 1), B0{});
     __builtin_amdgcn_sched_barrier(0);
-    load(min(s + 2, ksteps - 1), B0{});   // (the last trip of an even count re-reads its own step)
+    second_half_and_stage(0, B1{}, B1{});
     __builtin_amdgcn_sched_barrier(0);
-    compute(B1{});
+    lds_barrier();
+    if (s + 1 >= nk) break;
+    // ---- step s + 1 (LDS buffer 1); set 0 holds step s + 2, set 1 is free
+    load_a(min(s + 3, nk - 1), B1{});
+    load_b(min(2 * s + 3, nkk - 1), B1{});
     __builtin_amdgcn_sched_barrier(0);
+    half_step(1, 0, B0{});
+    load_b(min(2 * s + 4, nkk - 1), B0{});
+    __builtin_amdgcn_sched_barrier(0);
+    second_half_and_stage(1, B1{}, B0{});
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
   }
-  if (s < ksteps) compute(B0{});          // odd count: the last step was loaded by the previous trip (or is step 0)
 
   // ---- epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); 32 lanes store the 128
   // contiguous bytes of 32 output channels of one output pixel
@@ -235,7 +280,7 @@ hipError_t launch_pack_convt_x3(const float* w, float* Wx, int Cin, int Cout, hi
 }
 
 bool convt_x3_applicable(const IgemmDesc& d) {
-  return d.out_mode == 1 && d.wu && d.KS == 1 && d.K == d.Cp && (d.Cp & 15) == 0 && (d.ct_cout & 31) == 0 && d.N == 4 * d.ct_cout &&
+  return d.out_mode == 1 && d.wu && d.KS == 1 && d.K == d.Cp && (d.Cp & 31) == 0 && (d.ct_cout & 31) == 0 && d.N == 4 * d.ct_cout &&
          (d.ldin & 3) == 0 && !d.scale && !d.relu && !d.split_n && tun(d).wino_prec != 0 &&
          (9l * 128 + 8l * d.Wout) * d.ldout < (1l << 31);   // the output pixels of a tile's 128 rows span < 2^31 elements
 }
