@@ -158,16 +158,23 @@ int mgu_conv_transpose2x2_dgrad_nhwc(mgu_ctx* c, const void* dout_dev, int ld_d,
   hipStream_t s = (hipStream_t)hip_stream;
   const int Kt = 4 * Cout, Kpt = rup(Kt, 32);
   Scratch sc;
-  int rc = get_scratch(c, 0, (size_t)rup(Cin, 128) * Kpt, 0, 64, &sc);
+  const size_t dgp_floats = std::max((size_t)rup(Cin, 128) * Kpt, convt_x3_dgrad_floats(Cin, Cout));
+  int rc = get_scratch(c, 0, dgp_floats, 0, 64, &sc);
   if (rc) return rc;
-  HIPCHK(c, hipMemsetAsync(sc.dgp, 0, (size_t)rup(Cin, 128) * Kpt * sizeof(float), s));
-  HIPCHK(c, launch_pack_convt_dgrad_w((const float*)w_iohw_dev, sc.dgp, Cin, Cout, Kpt, s));
   IgemmDesc q;
   memset(&q, 0, sizeof q);
   q.tn = &c->tn;
   q.in = (const float*)dout_dev + c_off, q.w = sc.dgp, q.out = (float*)din_dev, q.M = B * H * W, q.H = H, q.W = W, q.Cp = Cout,
   q.ldin = ld_d;
   q.KS = 2, q.K = Kt, q.Kp = Kpt, q.N = Cin, q.ldout = Cin, q.Hout = 2 * H, q.Wout = 2 * W;
+  q.wu = sc.dgp;
+  if (c->tn.convt_dgrad_x3 && convt_x3_dgrad_applicable(q)) {   // the forward layer's three-piece kernel in its gather mode
+    HIPCHK(c, launch_pack_convt_x3_dgrad((const float*)w_iohw_dev, sc.dgp, Cin, Cout, s));
+  } else {
+    q.wu = nullptr;
+    HIPCHK(c, hipMemsetAsync(sc.dgp, 0, (size_t)rup(Cin, 128) * Kpt * sizeof(float), s));
+    HIPCHK(c, launch_pack_convt_dgrad_w((const float*)w_iohw_dev, sc.dgp, Cin, Cout, Kpt, s));
+  }
   HIPCHK(c, launch_igemm_f32(q, s));
   return MGU_OK;
 }

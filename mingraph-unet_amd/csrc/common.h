@@ -34,6 +34,7 @@ struct Tuning {
   int wino_ppb_cap = 32;
   bool wgrad_halo = true;   // MGU_NO_WGRAD_HALO=1
   bool wino_wgrad = true;   // MGU_NO_WINO_WGRAD=1
+  bool convt_dgrad_x3 = true;   // MGU_NO_CONVT_DGRAD_X3=1: ConvTranspose data gradient on the generic fp32 tile kernel
   bool wgrad_x3 = true;     // MGU_NO_WGRAD_X3=1: Winograd weight gradient on the fp32 MFMA instead of the three-piece bf16 products
   bool wgrad_thin = true;   // MGU_NO_THIN_WGRAD=1
   bool wino_dgrad = true;   // MGU_NO_WINO_DGRAD=1
@@ -91,6 +92,11 @@ size_t convt_x3_floats(int Cin, int Cout);
 hipError_t launch_pack_convt_x3(const float* w, float* Wx, int Cin, int Cout, hipStream_t s);
 bool convt_x3_applicable(const IgemmDesc& d);
 hipError_t launch_convt_x3(const IgemmDesc& d, hipStream_t s);
+// the same kernel as the layer's data gradient (KS = 2 gather descriptors whose d.wu holds launch_pack_convt_x3_dgrad's panel)
+size_t convt_x3_dgrad_floats(int Cin, int Cout);
+hipError_t launch_pack_convt_x3_dgrad(const float* w, float* Wx, int Cin, int Cout, hipStream_t s);
+bool convt_x3_dgrad_applicable(const IgemmDesc& d);
+hipError_t launch_convt_x3_dgrad(const IgemmDesc& d, hipStream_t s);
   // the kernel family launch_igemm_* will pick (profiling records)  // in / w / out point to bf16, sizes in elements
 // elementwise.hip: first convolution (<= 4 input channels on the packed NHWC4 input), VALU + scalar-cache weights
 hipError_t launch_pack_first_w(const float* w, float* wf, int Cout, int Cin, hipStream_t s);

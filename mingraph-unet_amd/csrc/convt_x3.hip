@@ -74,6 +74,13 @@ __global__ void pack_convt_x3_kernel(const float* __restrict__ w, uint16_t* __re
 // steps would be drained at every step (wino_f32.hip: lds_barrier)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// MODE 0: the forward layer.  Rows = input pixels (contiguous NHWC rows, K = Cin), columns n = (dy*2+dx)*Cout + co, pixel-shuffle store.
+// MODE 1: its data gradient (loss.backward() through unet_decoder.py:36): din[(y,x)][ci] = sum_{q,co} dout[(2y+qy, 2x+qx)][co] w[ci][co][q].
+//         Rows = pixels of the H x W input grid, K = 4 Cout with k = q*Cout + co: the K = 32 step s reads 32 channels of ONE of the four
+//         output pixels of its row (a different base pixel per tap, same whole-row staging), columns n = ci, plain row store.
+//         `Cin` is then the number of channels per tap (the layer's Cout), `Cout` the number of columns (the layer's Cin), `in` = dout.
+// NI = 32-column MFMA tiles per wave: 2 (128-column workgroup tile) or 1 (64 columns: the shallowest layer's gradient has only 64).
+template <int MODE, int NI>
 __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __restrict__ in, const int ldin, const uint16_t* __restrict__ Wx,
                                                              const float* __restrict__ shift, float* __restrict__ out, const int M,
                                                              const int H, const int W, const int Cin, const int Cout, const int ldout,
@@ -118,13 +125,28 @@ __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __rest
   const int arow = tid >> 3, ach = (tid & 7) * 4;
   const float* aptr[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) aptr[j] = in + (size_t)min(bm0 + j * 32 + arow, M - 1) * ldin + ach;   // rows past the end: re-read, never stored
-  const int nk = Cin >> 5;   // K = 32 steps
+  for (int j = 0; j < 4; ++j) {
+    const int m = min(bm0 + j * 32 + arow, M - 1);   // rows past the end: re-read, never stored
+    if (MODE == 0) {
+      aptr[j] = in + (size_t)m * ldin + ach;
+    } else {
+      const int img = m / HW, rem = m - img * HW, y = rem / W, x = rem - y * W;
+      aptr[j] = in + (((size_t)img * Hout + 2 * y) * Wout + 2 * x) * ldin + ach;   // output pixel (2y, 2x); the tap adds (qy Wout + qx) ldin
+    }
+  }
+  const int nk = (MODE == 0 ? Cin : 4 * Cin) >> 5;   // K = 32 steps
+  const int spq = Cin >> 5;                            // MODE 1: steps per tap
+  auto koff = [&](int s) -> int {                      // element offset of step s's 32 channels relative to aptr (wave-uniform)
+    if (MODE == 0) return s * 32;
+    const int q = s / spq;
+    return ((q >> 1) * Wout + (q & 1)) * ldin + (s - q * spq) * 32;
+  };
   f32x4 areg[2][4];          // two steps in flight: an L2 / HBM round trip is longer than one step's 48 MFMAs
   auto load_a = [&](int s, auto set_t) {
     constexpr int set = decltype(set_t)::value;
+    const int ko = koff(s);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) areg[set][j] = *reinterpret_cast<const f32x4*>(aptr[j] + s * 32);
+    for (int j = 0; j < 4; ++j) areg[set][j] = *reinterpret_cast<const f32x4*>(aptr[j] + ko);
   };
   auto store_a = [&](int buf, auto set_t) {
     constexpr int set = decltype(set_t)::value;
@@ -139,19 +161,21 @@ __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __rest
     }
   };
 
-  const u32x4* const bp = reinterpret_cast<const u32x4*>(Wx) + ((size_t)nt * (Cin >> 4) * 12 + wn * 6) * 64 + lane;
-  u32x4 br[2][6];      // [buffer][n tile * 3 + piece] of a K = 16 half step, one half step ahead
+  // a 128-column block of the packed weights holds 4 column tiles x 3 pieces per half step; a 64-column workgroup tile is half a block
+  const int nt128 = NI == 2 ? nt : nt >> 1, sub0 = NI == 2 ? wn * 2 : (nt & 1) * 2 + wn;
+  const u32x4* const bp = reinterpret_cast<const u32x4*>(Wx) + ((size_t)nt128 * (2 * nk) * 12 + sub0 * 3) * 64 + lane;
+  u32x4 br[2][3 * NI];      // [buffer][n tile * 3 + piece] of a K = 16 half step, one half step ahead
   auto load_b = [&](int kk, auto buf_t) {
     constexpr int buf = decltype(buf_t)::value;
 #pragma unroll
-    for (int f = 0; f < 6; ++f) br[buf][f] = bp[((size_t)kk * 12 + f) * 64];
+    for (int f = 0; f < 3 * NI; ++f) br[buf][f] = bp[((size_t)kk * 12 + f) * 64];
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NI];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
@@ -167,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __rest
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
+      for (int ni = 0; ni < NI; ++ni) {
         f32x16 t = acc[mi][ni];
         // smallest terms first
         t = mfma_bf16(pa[mi][2], br[bb][ni * 3 + 0], t);
@@ -196,9 +220,9 @@ __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __rest
     half_step(buf, 1, bb_t);
     store_a(buf ^ 1, set_t);
 #pragma unroll
-    for (int k = 0; k < 24; ++k) {
+    for (int k = 0; k < 12 * NI; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, NI == 2 ? 4 : 8, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x200, 12, 0);
   };
@@ -228,22 +252,25 @@ __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __rest
 
   // ---- epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); 32 lanes store the 128
   // contiguous bytes of 32 output channels of one output pixel
-  float* const tile_out = out + (size_t)pix0 * ldout + coff;
+  float* const tile_out = MODE == 0 ? out + (size_t)pix0 * ldout + coff : out + (size_t)bm0 * ldout + coff;
   const bool full_m = bm0 + 128 <= M;
   auto store_tile = [&](auto guarded_t) {
     constexpr bool GUARDED = decltype(guarded_t)::value;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int n = nt * 128 + wn * 64 + ni * 32 + lr;
-      const int q = n / Cout;
-      const int ncol = ((q >> 1) * Wout + (q & 1)) * ldout + (n - q * Cout);
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = nt * (64 * NI) + wn * (32 * NI) + ni * 32 + lr;
+      int ncol = n;
+      if (MODE == 0) {
+        const int q = n / Cout;
+        ncol = ((q >> 1) * Wout + (q & 1)) * ldout + (n - q * Cout);
+      }
       const float sh = shift ? shift[n] : 0.f;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rrow = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const unsigned idx = (unsigned)(rowoff[rrow] + ncol);
+          const unsigned idx = (unsigned)((MODE == 0 ? rowoff[rrow] : rrow * ldout) + ncol);
           const float v = acc[mi][ni][r] + sh;
           if (!GUARDED) tile_out[idx] = v;
           else if (bm0 + rrow < M) tile_out[idx] = v;
@@ -256,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __rest
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc += acc[mi][ni][r];
     if (sacc == 123.456f) tile_out[tid] = sacc;
@@ -271,6 +298,63 @@ __global__ __launch_bounds__(256, 2) void convt2x2_x3_kernel(const float* __rest
 
 size_t convt_x3_floats(int Cin, int Cout) { return (size_t)Cin * Cout * 6; }   // 4 Cout columns x Cin x 3 pieces x 2 bytes
 
+
+namespace {
+
+// Weights of the data gradient in the same fragment layout: k = q * Cout + co (q = qy*2 + qx), n = ci.  Columns past Cin inside the last
+// 128-column block are never read (a 64-column workgroup tile reads its own half).
+__global__ void pack_convt_x3_dgrad_kernel(const float* __restrict__ w, uint16_t* __restrict__ Wx, int Cin, int Cout) {
+  const int K = 4 * Cout;
+  const int64_t total = (int64_t)Cin * K;
+  const int ksteps = K >> 4;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % K), n = (int)(idx / K);
+    const int q = k / Cout, co = k - q * Cout;
+    const float x = w[(((int64_t)n * Cout + co) * 2 + (q >> 1)) * 2 + (q & 1)];
+    const unsigned b0 = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(b0);
+    const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(b1);
+    const int lane = ((k >> 3) & 1) * 32 + (n & 31);
+    uint16_t* dst = Wx + (((((int64_t)(n >> 7) * ksteps + (k >> 4)) * 4 + ((n >> 5) & 3)) * 3) * 64 + lane) * 8 + (k & 7);
+    dst[0] = (uint16_t)(b0 >> 16);
+    dst[512] = (uint16_t)(b1 >> 16);
+    dst[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
+  }
+}
+
+}  // namespace
+
+size_t convt_x3_dgrad_floats(int Cin, int Cout) { return (size_t)((Cin + 127) / 128 * 128) * Cout * 6; }   // x 4 taps x 3 pieces x 2 B / 4
+
+hipError_t launch_pack_convt_x3_dgrad(const float* w, float* Wx, int Cin, int Cout, hipStream_t s) {
+  if ((Cin & 63) || (Cout & 31)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_convt_x3_dgrad_kernel, dim3((unsigned)std::min<int64_t>(4096, ((int64_t)Cin * Cout * 4 + 255) / 256)), dim3(256), 0, s, w,
+                     reinterpret_cast<uint16_t*>(Wx), Cin, Cout);
+  return hipGetLastError();
+}
+
+// d: the KS = 2 gather descriptor of the generic path (in = dout + c_off with pitch ldin, Cp = the layer's Cout, N = the layer's Cin,
+// H x W the input grid, Hout x Wout the grid of dout), d.wu = launch_pack_convt_x3_dgrad's panel
+bool convt_x3_dgrad_applicable(const IgemmDesc& d) {
+  return d.KS == 2 && d.wu && d.out_mode == 0 && (d.Cp & 31) == 0 && d.K == 4 * d.Cp && (d.N & 63) == 0 && (d.ldin & 3) == 0 && !d.scale &&
+         !d.shift && !d.relu && !d.split_n && !d.pool && tun(d).wino_prec != 0 && (long)d.M * d.ldout < (1l << 31) &&
+         (long)d.Hout * d.Wout * d.ldin < (1l << 31);
+}
+
+hipError_t launch_convt_x3_dgrad(const IgemmDesc& d, hipStream_t s) {
+  const bool wide = (d.N & 127) == 0;
+  const int mtiles = (d.M + 127) / 128, ntn = d.N / (wide ? 128 : 64);
+  const int nb = mtiles * ntn;
+  const int chunk = (nb + 7) / 8;
+  if (wide)
+    hipLaunchKernelGGL((convt2x2_x3_kernel<1, 2>), dim3(chunk * 8), dim3(256), 0, s, d.in, d.ldin, reinterpret_cast<const uint16_t*>(d.wu),
+                       (const float*)nullptr, d.out, d.M, d.H, d.W, d.Cp, d.N, d.ldout, d.coff, d.Hout, d.Wout, ntn, nb);
+  else
+    hipLaunchKernelGGL((convt2x2_x3_kernel<1, 1>), dim3(chunk * 8), dim3(256), 0, s, d.in, d.ldin, reinterpret_cast<const uint16_t*>(d.wu),
+                       (const float*)nullptr, d.out, d.M, d.H, d.W, d.Cp, d.N, d.ldout, d.coff, d.Hout, d.Wout, ntn, nb);
+  return hipGetLastError();
+}
 
 hipError_t launch_pack_convt_x3(const float* w, float* Wx, int Cin, int Cout, hipStream_t s) {
   if ((Cin & 15) || (Cout & 31)) return hipErrorInvalidValue;
@@ -289,7 +373,7 @@ hipError_t launch_convt_x3(const IgemmDesc& d, hipStream_t s) {
   const int mtiles = (d.M + 127) / 128, ntn = d.N / 128;
   const int nb = mtiles * ntn;
   const int chunk = (nb + 7) / 8;
-  hipLaunchKernelGGL(convt2x2_x3_kernel, dim3(chunk * 8), dim3(256), 0, s, d.in, d.ldin, reinterpret_cast<const uint16_t*>(d.wu), d.shift, d.out,
+  hipLaunchKernelGGL((convt2x2_x3_kernel<0, 2>), dim3(chunk * 8), dim3(256), 0, s, d.in, d.ldin, reinterpret_cast<const uint16_t*>(d.wu), d.shift, d.out,
                      d.M, d.H, d.W, d.Cp, d.ct_cout, d.ldout, d.coff, d.Hout, d.Wout, ntn, nb);
   return hipGetLastError();
 }

@@ -631,7 +631,8 @@ const char* igemm_kernel_name(const IgemmDesc& d, int dtype) {
     return wide ? "wino3x3_f32_kernel<0,0>" : "wino3x3_f32_kernel<1,0>";
   }
   if (halo_np<float>(d) == 8) return "conv3x3_halo_kernel<f32>";
-  return d.KS == 2 ? "igemm_kernel<f32> (ConvTranspose dgrad)" : "igemm_kernel<f32>";
+  if (d.KS == 2) return convt_x3_dgrad_applicable(d) ? "convt2x2_x3_kernel<dgrad>" : "igemm_kernel<f32> (ConvTranspose dgrad)";
+  return "igemm_kernel<f32>";
 }
 
 hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s) {
@@ -642,6 +643,7 @@ hipError_t launch_igemm_f32(const IgemmDesc& d, hipStream_t s) {
     if (convt_x3_applicable(d)) return launch_convt_x3(d, s);
     return launch_tiles<float, 1, 1>(d, s);
   }
+  if (d.KS == 2 && convt_x3_dgrad_applicable(d)) return launch_convt_x3_dgrad(d, s);
   if (wino_applicable(d)) return launch_wino_f32(d, s);
   if (halo_np<float>(d) == 8) return launch_halo_tiles<float, 8>(d, s);
   if (d.KS == 3) return launch_tiles<float, 3, 0>(d, s);

@@ -81,6 +81,7 @@ int mgu_create(int device_id, mgu_ctx** out) {
   t.wgrad_halo = !flag("MGU_NO_WGRAD_HALO");
   t.wino_wgrad = !flag("MGU_NO_WINO_WGRAD");
   t.wgrad_x3 = !flag("MGU_NO_WGRAD_X3");
+  t.convt_dgrad_x3 = !flag("MGU_NO_CONVT_DGRAD_X3");
   t.wgrad_thin = !flag("MGU_NO_THIN_WGRAD");
   t.wino_dgrad = !flag("MGU_NO_WINO_DGRAD");
   t.gat_fused = !flag("MGU_NO_GAT_FUSED");

@@ -16,7 +16,7 @@ using namespace mgud;
 namespace {
 
 struct TPlan {
-  size_t xin = 0, bott = 0, ta = 0, tb = 0, tc = 0, dwp = 0, dwp_floats = 0, dgp = 0, wug = 0, sums = 0, total = 0;
+  size_t xin = 0, bott = 0, ta = 0, tb = 0, tc = 0, dwp = 0, dwp_floats = 0, dgp = 0, dgp_floats = 0, wug = 0, sums = 0, total = 0;
   std::vector<size_t> z, y1, pooled, dcat;
 };
 
@@ -58,10 +58,12 @@ TPlan plan_train(const mgu_ctx* c, int B, int H, int W) {
     pmax = std::max(pmax, (size_t)L.Np * L.Kp);                                              // wgrad panel (conv / convT)
     const size_t cop = rup(L.Cout, 4);
     pmax = std::max(pmax, (size_t)rup(L.Cp, 128) * rup(L.KS * L.KS * (int)cop * (L.convt ? 4 : 1), 32));  // dgrad panel
+    if (L.convt) pmax = std::max(pmax, convt_x3_dgrad_floats(L.Cin, L.Cout));                          // its three-piece form
   }
   p.dwp_floats = std::max(pmax, (size_t)12 << 20);   // >= 48 MB: room for the atomics-free wgrad's partial panels
   p.dwp = fl(p.dwp_floats);
   p.dgp = fl(pmax);
+  p.dgp_floats = pmax;
   size_t umax = 0;   // Winograd-transformed dgrad weights (conv_dgrad)
   for (const auto& L : c->layers)
     if (L.wino && rup(L.Cout, 4) % 16 == 0) umax = std::max(umax, wino_u_floats(L.Cin, rup(L.Cout, 4)));
@@ -115,6 +117,7 @@ struct Bwd {
   mgu_ctx* c;
   hipStream_t s;
   float *ta, *tb, *dwp, *dgp, *wug, *flat;
+  size_t dgp_floats = 0;
   size_t dwp_floats;
   double *sums, *red;
 };
@@ -353,6 +356,7 @@ static int backward_body(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_de
   Bwd w;
   w.c = c, w.s = s;
   w.ta = at(c, p.ta), w.tb = at(c, p.tb), w.dwp = at(c, p.dwp), w.dgp = at(c, p.dgp);
+  w.dgp_floats = p.dgp_floats;
   w.dwp_floats = p.dwp_floats;
   w.wug = at(c, p.wug);
   w.flat = (float*)flat_grad_dev;
@@ -419,13 +423,24 @@ static int backward_body(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_de
       HIPCHK(c, launch_wgrad_f32(g, s));
       HIPCHK(c, launch_unpack_convt_grad(w.dwp, g.groups, (size_t)g.N * g.Kp, w.flat + U.off_w, U.Cin, C, Kpt, s));
     }
-    HIPCHK(c, launch_pack_convt_dgrad_w(U.w_src, w.dgp, U.Cin, C, Kpt, s));
     IgemmDesc q;
     memset(&q, 0, sizeof q);
     q.tn = &c->tn;
     q.in = dcat + C, q.w = w.dgp, q.out = tc, q.M = U.t_B * U.t_H * U.t_W, q.H = U.t_H, q.W = U.t_W, q.Cp = C, q.ldin = 2 * C;
     q.KS = 2, q.K = Kt, q.Kp = Kpt, q.N = U.Cin, q.ldout = U.Cin, q.Hout = hs[i], q.Wout = ws[i];
-    HIPCHK(c, launch_igemm_f32(q, s));
+    // three-piece kernel of the forward layer in its gather mode (convt_x3.hip) where the shapes allow, else the generic tile kernel
+    q.wu = w.dgp;
+    if (c->tn.convt_dgrad_x3 && convt_x3_dgrad_applicable(q) && convt_x3_dgrad_floats(U.Cin, C) <= w.dgp_floats) {
+      HIPCHK(c, launch_pack_convt_x3_dgrad(U.w_src, w.dgp, U.Cin, C, s));
+    } else {
+      q.wu = nullptr;
+      HIPCHK(c, launch_pack_convt_dgrad_w(U.w_src, w.dgp, U.Cin, C, Kpt, s));
+    }
+    {
+      const double alg = 2.0 * q.M * (double)Kt * U.Cin;
+      ProfScope ps(c, s, q.wu ? "convt2x2_x3_kernel (dgrad)" : "igemm_kernel<f32> (ConvTranspose dgrad)", alg, q.wu ? 6.0 * alg : alg, q.wu ? 1 : 0);
+      HIPCHK(c, launch_igemm_f32(q, s));
+    }
     dy = tc, lddy = U.Cin;
     if ((rc = block_done(U.off_w, false))) return rc;
   }
