@@ -748,6 +748,26 @@ constexpr int WINO_CP_RAWF = 8192;
 // URES (DEEP with exactly two chunks, i.e. 32 input channels): the two register sets of weight pieces hold the layer's WHOLE
 // transformed filter slice of this wave, so they are loaded once per workgroup and never again -- no weight-piece load sits in
 // the in-order memory pipe behind the halo loads and the epilogue's stores.
+#if defined(MGU_DIAG) && MGU_DIAG == 20
+// diagnostic build: phase timeline of ONE workgroup of the selected layer (-DMGU_DIAG_H=.. -DMGU_DIAG_CP=.. -DMGU_DIAG_N=..), every wave's
+// lane 0 stamping s_memtime at the phase boundaries of every patch: mgu_diag_ts[wave][patch][slot]; tools/diag_timeline.py reads it
+#ifndef MGU_DIAG_H
+#define MGU_DIAG_H 512
+#endif
+#ifndef MGU_DIAG_CP
+#define MGU_DIAG_CP 32
+#endif
+#ifndef MGU_DIAG_N
+#define MGU_DIAG_N 32
+#endif
+__device__ unsigned long long mgu_diag_ts[8][64][32];
+#define DIAG_T(slot)                                                                                                       \
+  do {                                                                                                                     \
+    if (diag_on && (threadIdx.x & 63) == 0 && pi < 64) mgu_diag_ts[threadIdx.x >> 6][pi][slot] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define DIAG_T(slot) do {} while (0)
+#endif
 template <int NTB, bool STATS, bool DEEP, bool URES = false>
 __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y, const int total_patches,
                         const int patches_per_block, const int ngroups, const int nitems, const int per_xcd, const int flags) {
@@ -971,7 +991,11 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
 #pragma unroll
   for (int nt = 0; nt < NTB; ++nt) st1[nt] = f32x4{0.f, 0.f, 0.f, 0.f}, st2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   int buf = 0;
+#if defined(MGU_DIAG) && MGU_DIAG == 20
+  const bool diag_on = blockIdx.x == 100 && blockIdx.y == 0 && d.H == MGU_DIAG_H && d.Cp == MGU_DIAG_CP && d.N == MGU_DIAG_N;
+#endif
   for (int pi = 0; pi < npatch; ++pi) {
+    DIAG_T(0);
     auto chunk_body = [&](const int c, auto par_c) {
       constexpr int P = decltype(par_c)::value;                  // DEEP: parity of the chunk = its register set
       using SetNext = std::integral_constant<int, DEEP ? (P ^ 1) : 0>;   // set holding chunk c + 1 (stored now, then refilled)
@@ -985,6 +1009,7 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
       //   B1 (after step 1): chunk c + 1 is complete in LDS.
       prep_next();
       lds_barrier();                                     // B0
+      if (c < 4) DIAG_T(1 + 3 * c);
       const float* Hs = smem + buf * RAWF;               // chunk c
       const float* Hn = smem + (buf ^ 1) * RAWF;         // chunk c + 1 (or the next patch's first)
       store_halo(smem + (buf ^ 1) * RAWF, SetNext{});
@@ -993,7 +1018,11 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
       static_for<0, 4>([&](auto st_c) {
         constexpr int st = decltype(st_c)::value;
         constexpr int jj = st >> 1, mi = st & 1, slot = st & 1;
-        if constexpr (st == 2) lds_barrier();            // B1
+        if constexpr (st == 2) {
+          if (c < 4) DIAG_T(2 + 3 * c);                  // arrival at B1
+          lds_barrier();                                 // B1
+          if (c < 4) DIAG_T(3 + 3 * c);
+        }
 #if defined(MGU_DIAG) && MGU_DIAG == 11   // diagnostic build: no MFMAs in the chunk loop (operands folded into one register each)
 #pragma unroll
         for (int nt = 0; nt < NTB; ++nt)
@@ -1068,7 +1097,9 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
     const int cq = et & 7, T = et >> 3;              // finishing unit of this thread: (tile, channel quad of the pass's n tile)
     int zb = (wi * 64 + 4 * ((et >> 5) & 1)) * ZP + (et & 31);
     asm volatile("" : "+v"(zb));
+    DIAG_T(13);      // main loop done (arrival at the epilogue's first barrier)
     lds_barrier();   // every wave has finished reading the consumed raw buffer, which is exchange region 0 from here on
+    DIAG_T(14);
     // Exchange regions Z[q][jp] ([4 rows i][64 tiles][32 channels] each): the column part of Z[i][q] = sum_j M[i][j] A[j][q]
     // (A^T = [1 1 1 0; 0 1 -1 -1]) is split over the two component-pair waves of a row,
     //   jp = 0 (M0, M1): q = 0: M0 + M1, q = 1: M1;      jp = 1 (M2, M3): q = 0: M2, q = 1: -M2 - M3,
@@ -1123,7 +1154,9 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
             z1p[o] = (jp == 0 ? m1 : -m0 - m1) * scw[nt] + shw[nt];
           }
       }
+      if (nt == 0) DIAG_T(15);   // shares written (arrival)
       lds_barrier();
+      if (nt == 0) DIAG_T(16);
 #if defined(MGU_DIAG) && MGU_DIAG == 5   // diagnostic build: exchange writes and barriers only
       lds_barrier();
       continue;
@@ -1196,7 +1229,9 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
           }
         }
       }
+      if (nt == 0) DIAG_T(17);   // finishing pass issued (arrival)
       lds_barrier();   // the regions are rewritten by the next pass / region 0 receives the next raw chunk
+      if (nt == NTB - 1) DIAG_T(18);
     }
 #endif
 #pragma unroll
@@ -1317,3 +1352,10 @@ hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
 }
 
 }  // namespace mgu
+
+#if defined(MGU_DIAG) && MGU_DIAG == 20
+extern "C" int mgu_diag_read(unsigned long long* out, int n) {
+  if (n > 8 * 64 * 32) n = 8 * 64 * 32;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mgu::mgu_diag_ts), (size_t)n * sizeof(unsigned long long));
+}
+#endif
