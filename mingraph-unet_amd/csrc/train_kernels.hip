@@ -510,37 +510,40 @@ hipError_t launch_pack_convt_dgrad_w(const float* w, float* wp, int Cin, int Cou
 // ---- gradient panels -> the reference's parameter layouts ---------------------------------------------
 // conv: panel [Cout][Kp], k = tap*Cp + c  ->  OIHW (Cout, Cin, KS, KS)
 // Sums `groups` partial panels in a fixed order (the atomics-free wgrad path writes one panel per patch group) and writes OIHW.
-// A workgroup owns one output channel and 32 consecutive input channels with all KS*KS taps: per tap a 128-byte coalesced read of
-// every partial panel, the group loop split over 8 slices (a small panel with 512 partials still fills the chip), and -- the part
-// that was missing: the OIHW destination of those 32 x 9 values is ONE contiguous 1152-byte run, written from LDS in order
-// (a thread per panel element wrote 4 bytes at a 36-byte stride: 56 us for the 512 x 512 layer, whose reads take 10).
+// A workgroup owns one output channel and 32 consecutive input channels with all KS*KS taps.  Thread = (group slice sl of 32, channel
+// quad cq of 8): per tap ONE 16-byte load of every partial panel of its slice (8 lanes = the 128-byte row piece; the scalar-load
+// version moved 128 bytes per instruction and ran at 2.7 TB/s), the 32 slice sums meet in LDS, and the OIHW destination of those
+// 32 x TAPS values is ONE contiguous run written in order (a thread per panel element wrote 4 bytes at a 36-byte stride: 56 us for
+// the 512 x 512 layer, whose reads take 10).
 template <int TAPS>
 __global__ __launch_bounds__(256) void unpack_conv_grad_kernel(const float* __restrict__ dwp, int groups, size_t panel_stride,
                                                                float* __restrict__ g, int Cout, int Cin, int Cp, int Kp) {
-  __shared__ float part[8][TAPS][33];
-  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  __shared__ float part[32][TAPS][33];
+  const int cq = threadIdx.x & 7, sl = threadIdx.x >> 3;
   const int nchunk = (Cp + 31) / 32;
   for (int item = blockIdx.x; item < Cout * nchunk; item += gridDim.x) {
     const int co = item / nchunk, ci0 = (item - co * nchunk) * 32;
-    const bool ok = ci0 + e < Cp;
-    const float* p = dwp + (int64_t)co * Kp + (ok ? ci0 + e : 0);
-    float s[TAPS];
+    const bool ok = ci0 + cq * 4 < Cp;   // Cp is a multiple of 4: a quad is whole or absent
+    const float* p = dwp + (int64_t)co * Kp + (ok ? ci0 + cq * 4 : 0);
+    f32x4 s[TAPS];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) s[t] = 0.f;
-    for (int q = sl; q < groups; q += 8) {   // TAPS independent loads in flight
+    for (int t = 0; t < TAPS; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = sl; q < groups; q += 32) {   // TAPS independent 16-byte loads in flight
       const float* pq = p + (size_t)q * panel_stride;
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) s[t] += pq[t * Cp];
+      for (int t = 0; t < TAPS; ++t) s[t] += *reinterpret_cast<const f32x4*>(pq + t * Cp);
     }
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) part[sl][t][e] = s[t];
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part[sl][t][cq * 4 + e] = ok ? s[t][e] : 0.f;
     __syncthreads();
     const int nci = min(32, Cin - ci0);   // channels of this chunk that exist in the OIHW tensor (Cp pads to a multiple of 4)
     for (int o = threadIdx.x; o < nci * TAPS; o += 256) {
       const int cl = o / TAPS, t = o - cl * TAPS;
       float sum = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sum += part[j][t][cl];
+      for (int j = 0; j < 32; ++j) sum += part[j][t][cl];
       g[((int64_t)co * Cin + ci0) * TAPS + o] = sum;
     }
     __syncthreads();
