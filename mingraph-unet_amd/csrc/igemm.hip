@@ -292,6 +292,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDesc d) {
 // double-buffered LDS panel, so there is a single s_barrier per tap.  The halo of the next chunk is
 // prefetched into registers while the current chunk computes.
 // =================================================================================================
+#if defined(MGU_DIAG) && MGU_DIAG == 23   // diagnostic build: step timeline of one workgroup of the selected layer (tools/diag_timeline.py --halo)
+#ifndef MGU_DIAG_H
+#define MGU_DIAG_H 128
+#endif
+#ifndef MGU_DIAG_CP
+#define MGU_DIAG_CP 128
+#endif
+#ifndef MGU_DIAG_N
+#define MGU_DIAG_N 128
+#endif
+__device__ unsigned long long mgu_halo_ts[4][256][4];
+#define HALO_T(slot)                                                                                                   \
+  do {                                                                                                                 \
+    if (diag_on && (threadIdx.x & 63) == 0 && st < 256) mgu_halo_ts[threadIdx.x >> 6][st][slot] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define HALO_T(slot) do {} while (0)
+#endif
 template <typename T, int NP, int TH, int WAVES_M, int WAVES_N, int WMT, int WNT, int TPS>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y,
                                                            const int total_patches, const int patches_per_block, const int yfast) {
@@ -423,8 +441,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
   load_b(0, 1);              // nsteps >= 3
   int c = 0, tap = 0, pi = 0;   // chunk / step-in-item / patch of the step being computed
   int c2 = 0, t2 = 2;           // chunk / step-in-item of step st + 2 (weights depend on (chunk, step) only)
+#if defined(MGU_DIAG) && MGU_DIAG == 23
+  const bool diag_on = blockIdx.x == 40 && blockIdx.y == 0 && d.H == MGU_DIAG_H && d.Cp == MGU_DIAG_CP && d.N == MGU_DIAG_N && sizeof(T) == 2;
+#endif
   for (int st = 0; st < nsteps; ++st) {
+    HALO_T(0);
     __syncthreads();  // Bs[st&1] (and a fresh halo when tap == 0) visible; Bs[(st+1)&1] no longer read
+    HALO_T(1);
     if (st + 1 < nsteps) store_b((st + 1) & 1);
     if (st + 2 < nsteps) load_b(c2, t2);
     if (++t2 == SPI) {
@@ -466,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
           for (int ni = 0; ni < WNT; ++ni) acc[mi][ni] = mma_chunk<T>(a[gidx & 1][mi], b[gidx & 1][ni], acc[mi][ni]);
       }
     }
+    HALO_T(2);   // MFMAs of the step issued
     if (++tap == SPI) {
       tap = 0;
       const bool patch_done = (c + 1 == nchunks);
@@ -551,6 +575,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
         ++c;
       }
     }
+    HALO_T(3);
   }
 }
 
@@ -670,3 +695,10 @@ hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s) {
 }
 
 }  // namespace mgu
+
+#if defined(MGU_DIAG) && MGU_DIAG == 23
+extern "C" int mgu_diag_read(unsigned long long* out, int n) {
+  if (n > 4 * 256 * 4) n = 4 * 256 * 4;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mgu::mgu_halo_ts), (size_t)n * sizeof(unsigned long long));
+}
+#endif
