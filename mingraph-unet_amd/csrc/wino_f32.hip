@@ -855,7 +855,11 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
       const int r = hp / RW, cc = hp - r * RW;
       const int y = y0 - 1 + r, x = x0 - 1 + cc;
       const bool ok = hp < HPIX && y >= 0 && y < d.H && x >= 0 && x < d.W;
-      hoff[i] = ((ok ? (y * d.W + x) * d.ldin : 0) + kq * 4) * (int)sizeof(float);
+      // a pixel outside the image gets an offset past the descriptor's range: the buffer load returns zeros by itself (no mask,
+      // no select when the registers are written to LDS)
+      // (narrow kernel only: in the wide one, at the 256-register limit, the change moved the allocation from 3 to 10 spilled registers
+      // and cost 12 %)
+      hoff[i] = (NTB == 1 && !ok) ? 0x7fff0000 : ((ok ? (y * d.W + x) * d.ldin : 0) + kq * 4) * (int)sizeof(float);
       mk |= ok ? (1u << i) : 0u;
     }
     hmask_next = mk;
@@ -882,7 +886,7 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
       const int hp = hp0 + HSTRIDE * i;
       const int r = hp / RW, cc = hp - r * RW;
       *reinterpret_cast<f32x4*>(Hs + ((r * 2 + (cc & 1)) * 17 + (cc >> 1)) * PLD + kq * 4) =
-          ((hmask_set[set] >> i) & 1u) ? hreg[set][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+          (NTB == 1 || ((hmask_set[set] >> i) & 1u)) ? hreg[set][i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   int lp = 0, lc = 0;
