@@ -185,7 +185,7 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     // fp32 ConvTranspose on fragment-ordered three-piece weights (convt_x3.hip).  (A bf16-storage sibling of that kernel -- one
     // fragment per operand straight from global memory -- was measured SLOWER than the LDS-tiled generic kernel, 0.178 vs 0.163 ms per
     // step: 32-byte row segments per K slice; not kept.)
-    L.ctx3 = dtype == MGU_DTYPE_F32 && L.convt && L.Cin % 16 == 0 && L.Cout % 32 == 0 && c->tn.wino_prec != 0 && c->tn.convt_frag;
+    L.ctx3 = dtype == MGU_DTYPE_F32 && L.convt && L.Cin % 32 == 0 && L.Cout % 32 == 0 && c->tn.wino_prec != 0 && c->tn.convt_frag;
     if (L.ctx3) total += convt_x3_floats(L.Cin, L.Cout);
     L.first = !L.convt && L.KS == 3 && first_conv_applicable(dtype, L.Cin, L.Cp, L.Cout, 8, 0);
     if (L.first) total += 9 * 4 * (size_t)L.Cout;
@@ -745,7 +745,7 @@ int mgu_conv_transpose2x2_nhwc(mgu_ctx* c, const void* in_dev, int B, int H, int
   // the layer shape is eligible and the context's switches allow it (MGU_NO_CONVT_FRAG, MGU_WINO_PREC) -- the fragment-order
   // three-piece weights of convt2x2_x3_kernel.  Which kernel runs is decided by the dispatcher (convt_x3_applicable) on the
   // COMPLETE descriptor; a launch it rejects falls back to the tile kernel, which then finds a real panel in d.w.
-  const bool x3_shape = Cin % 16 == 0 && Cout % 32 == 0 && c->tn.wino_prec != 0 && c->tn.convt_frag;
+  const bool x3_shape = Cin % 32 == 0 && Cout % 32 == 0 && c->tn.wino_prec != 0 && c->tn.convt_frag;
   const size_t panel = (size_t)Np * Kp + 2 * (size_t)Np;
   int rc = ensure(c, &c->gws, &c->gws_bytes, (panel + (x3_shape ? convt_x3_floats(Cin, Cout) : 0)) * sizeof(float));
   if (rc) return rc;
