@@ -47,7 +47,7 @@ def rel(got, ref):
 
 
 VARIANTS = {"default": {}, "no_wino_wgrad": {"MGU_NO_WINO_WGRAD": 1}, "tiles": {"MGU_NO_WINO_WGRAD": 1, "MGU_NO_WGRAD_HALO": 1, "MGU_NO_THIN_WGRAD": 1},
-            "fp32_mfma": {"MGU_WINO_PREC": 0}}
+            "fp32_mfma": {"MGU_WINO_PREC": 0}, "wgrad_fp32_mfma": {"MGU_NO_WGRAD_X3": 1}, "convt_dgrad_tiles": {"MGU_NO_CONVT_DGRAD_X3": 1}}
 
 WGRAD_CASES = [  # B, H, W, Cin, Cout, k
     (2, 13, 17, 8, 32, 3),      # generic tile kernel, ragged
@@ -59,10 +59,13 @@ WGRAD_CASES = [  # B, H, W, Cin, Cout, k
     (2, 64, 64, 3, 32, 3),      # first conv (Cin 3 on the packed NHWC4 input): streaming kernel
     (2, 64, 64, 32, 2, 1),      # 1x1 head: streaming kernel
     (3, 7, 5, 16, 8, 1),        # 1x1, tile kernel
+    (2, 37, 45, 64, 64, 3),     # three-piece Winograd weight gradient, 64 x 32 tile, ragged patches on both axes
+    (2, 35, 18, 64, 32, 3),     # ... 32 x 64 tile (N = 32)
+    (1, 20, 50, 32, 96, 3),     # ... 32 x 32 tile (N = 96 is not a multiple of 64)
 ]
 
 
-@pytest.mark.parametrize("variant", ["default", "no_wino_wgrad", "tiles", "fp32_mfma"])
+@pytest.mark.parametrize("variant", ["default", "no_wino_wgrad", "tiles", "fp32_mfma", "wgrad_fp32_mfma"])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k", WGRAD_CASES)
 def test_conv_wgrad_vs_float64(cuda, variant, B, H, W, Cin, Cout, k):
     x = torch.from_numpy(O.formula_normal("bk/x", (B, Cin, H, W), seed=Cin + H))
@@ -120,8 +123,9 @@ def test_conv_dgrad_vs_float64(cuda, variant, B, H, W, Cin, Cout, k):
     assert e <= TOL, e
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 9, 64, 32), (1, 16, 16, 512, 256), (2, 33, 20, 128, 64), (4, 256, 256, 64, 32)])
-def test_conv_transpose_backward_vs_float64(cuda, B, H, W, Cin, Cout):
+@pytest.mark.parametrize("variant", ["default", "convt_dgrad_tiles"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 9, 64, 32), (1, 16, 16, 512, 256), (2, 33, 20, 128, 64), (4, 256, 256, 64, 32), (1, 9, 7, 16, 32)])
+def test_conv_transpose_backward_vs_float64(cuda, variant, B, H, W, Cin, Cout):
     """ConvTranspose2d(k2,s2) weight, bias and data gradients (unet_decoder.py:25,36) with the gradient arriving in the upper
     channel half of a concat-shaped buffer, as in mgu_unet_backward."""
     g = torch.Generator().manual_seed(Cin + H)
@@ -138,7 +142,7 @@ def test_conv_transpose_backward_vs_float64(cuda, B, H, W, Cin, Cout):
     dw = torch.full((Cin, Cout, 2, 2), float("nan"), device=cuda)
     db = torch.full((Cout,), float("nan"), device=cuda)
     din = torch.full((B, H, W, Cin), float("nan"), device=cuda)
-    with context(cuda) as ctx:
+    with context(cuda, **VARIANTS[variant]) as ctx:
         L, s = _lib.lib(), _lib.current_stream_ptr(cuda)
         _lib.check(L.mgu_conv_transpose2x2_wgrad_nhwc(ctx.handle, xin.data_ptr(), dcat.data_ptr(), ld, coff, B, H, W, Cin, Cout, dw.data_ptr(),
                                                       db.data_ptr(), s), ctx.handle)
