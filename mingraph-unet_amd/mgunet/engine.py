@@ -401,3 +401,95 @@ class Trainer:
         scale = allreduce_mean_(self.grad, self.group) if self.comm is not None else 1.0   # torch.distributed (RCCL / gloo); 1 rank: no-op
         self.optimizer_step(scale)
         return loss
+
+
+class FlatAdam:
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay) (the optimizer of both reference loops, train_end_to_end.py:228) for the
+    parameters of ANY modules on the HIP path: they are re-homed as views of one flat fp32 buffer, their .grad as views of a flat
+    gradient buffer that autograd accumulates into, and step() is one mgu_adam_step launch.  (`Trainer` does the same for the U-Net,
+    whose flat order the library fixes; this is the graph branch's half.)"""
+
+    def __init__(self, modules, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        seen, params = set(), []
+        for m in modules:
+            for q in m.parameters():
+                if id(q) not in seen and q.requires_grad:
+                    seen.add(id(q))
+                    params.append(q)
+        if not params or not params[0].is_cuda:
+            raise RuntimeError("move the modules to a HIP device before building the optimizer (no CPU fallback)")
+        self.params, self.device = params, params[0].device
+        self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
+        n = sum(q.numel() for q in params)
+        self.flat = torch.empty(n, device=self.device, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=self.device, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n, device=self.device, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=self.device, dtype=torch.float32)
+        off = 0
+        for q in params:
+            k = q.numel()
+            self.flat[off:off + k].copy_(q.detach().reshape(-1))
+            q.data = self.flat[off:off + k].view_as(q)
+            q.grad = self.grad[off:off + k].view_as(q)
+            off += k
+        self.step_count = 0
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()          # the .grad views stay in place (set_to_none would detach them from the flat buffer)
+
+    def step(self, grad_scale: float = 1.0) -> None:
+        from .gat import _context
+        ctx = _context(self.device)
+        self.step_count += 1
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mgu_adam_step(ctx.handle, self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                self.exp_avg_sq.data_ptr(), self.flat.numel(), self.lr, self.betas[0], self.betas[1],
+                                                self.eps, self.wd, self.step_count, grad_scale, _lib.current_stream_ptr(self.device)),
+                       ctx.handle)
+        for q in self.params:      # the kernel wrote the parameters behind torch's back: the packed-weight caches key on _version
+            torch.autograd.graph.increment_version(q)
+
+
+class E2ETrainer:
+    """One iteration of scripts/train_end_to_end.py:262-480 on the HIP path, as far as the reference's loss reaches:
+
+        total = L_unet_seg + 0.1 * L_shape (the constant 0, :287) + w_f * L_feature + w_p * L_partition + w_s * L_smooth
+
+    `L_unet_seg` (CrossEntropy of the U-Net logits) is the U-Net's only gradient source -- the script feeds the graph branch torch.randn
+    placeholders (:326, :338, :342), not U-Net features -- and goes through `Trainer` (mgu_unet_forward / mgu_cross_entropy /
+    mgu_unet_backward).  `L_feature` (FeatureConsistencyLoss on the patch GAT's output, with the batch dimension the script forgets,
+    SURVEY appendix A) and `L_partition` (MinCutRefinement) differentiate the patch GAT and the segment predictor through the autograd
+    nodes of mgunet.GATNetwork / MinCutRefinement / FeatureConsistencyLoss (mgu_gat_layer_backward, mgu_ncut_backward,
+    mgu_feature_consistency_loss_backward).  `L_smooth` is the TV of a constant map (:455) and `L_shape` a constant: zero gradient, not
+    evaluated.  Both parameter sets take one Adam step with the script's single (lr, weight_decay) (:228): the U-Net's in `Trainer`,
+    the graph branch's in `FlatAdam`.  The placeholders are ARGUMENTS here (the script draws them from torch's RNG per image)."""
+
+    def __init__(self, unet_trainer: Trainer, patch_gat: GATNetwork, segment_predictor, mincut, feature_loss, num_segments: int = 2,
+                 l_feature_weight: float = 0.1, l_partition_weight: float = 0.5):
+        self.unet = unet_trainer
+        self.patch_gat, self.predictor, self.mincut, self.feature_loss = patch_gat, segment_predictor, mincut, feature_loss
+        self.K, self.wf, self.wp = num_segments, l_feature_weight, l_partition_weight
+        self.graph_opt = FlatAdam([patch_gat, segment_predictor], lr=unet_trainer.lr, weight_decay=unet_trainer.wd,
+                                  betas=unet_trainer.betas, eps=unet_trainer.eps)
+
+    def step(self, images, masks, patch_features, f_unet_patches, patch_labels, edge_index) -> dict:
+        """images (B,3,H,W), masks (B,H,W) int64; per image b: patch_features[b] (Np, D_in) -> patch GAT, f_unet_patches[b] (Np, D) and
+        patch_labels[b] (Np,) for L_feature; edge_index: the patch graph (2, E).  Returns the script's running-loss entries."""
+        B = images.shape[0]
+        loss_seg = self.unet.forward_backward(images, masks)
+        self.graph_opt.zero_grad()
+        lf = lp = 0.0
+        for b in range(B):   # the per-image loop of :300-437
+            h = self.patch_gat(patch_features[b], edge_index)                                          # :332
+            lf = lf + self.feature_loss(f_unet_patches[b][None], h[None], patch_labels[b][None])      # :344 (with the batch dimension)
+            l, _soft = self.mincut(h, edge_index, self.K, self.predictor)                             # :348-351
+            lp = lp + l
+        lf, lp = lf / B, lp / B                                                                       # :440-441
+        (self.wf * lf + self.wp * lp).backward()                                                      # the graph-branch part of :478
+        scale = allreduce_mean_(self.unet.grad, self.unet.group) if self.unet.comm is not None else 1.0
+        self.unet.optimizer_step(scale)
+        self.graph_opt.step()
+        total = loss_seg.detach() + self.wf * lf.detach() + self.wp * lp.detach()
+        return {"total": total, "l_unet_seg": loss_seg.detach(), "l_shape": torch.zeros((), device=images.device),
+                "l_feature": lf.detach(), "l_partition": lp.detach(), "l_smooth": torch.zeros((), device=images.device)}
+

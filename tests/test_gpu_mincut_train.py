@@ -179,3 +179,68 @@ def test_graph_branch_losses_of_the_e2e_step_vs_oracle_composition(cuda):
         close(v.grad, q[k].grad.numpy().astype(np.float64), "gat." + k)
     for k, v in pred.named_parameters():
         close(v.grad, r[k].grad.numpy().astype(np.float64), k)
+
+
+def test_e2e_trainer_iteration_vs_oracle_and_torch_adam(cuda):
+    """mgunet.E2ETrainer.step = one iteration of scripts/train_end_to_end.py:262-480: the U-Net half is Trainer's CE step, the graph
+    half the composition checked above, and BOTH parameter sets take the script's single Adam(lr, weight_decay) step (:228).  Graph
+    branch against the oracle composition + torch.optim.Adam on the CPU; U-Net half against a plain Trainer on the same inputs."""
+    torch.manual_seed(0)
+    B, Dp, K, H = 2, 32, 2, 64
+    ei = torch.from_numpy(O.patch_graph_edges(H, H, 16))
+    Np = (H // 16) ** 2
+    gp = O.make_gat_params(Dp, 16, Dp, 2, 1, seed=61)
+    pp = O.make_segment_predictor_params(Dp, K, 16, True, 2, seed=62)
+    feats = [torch.from_numpy(O.formula_normal(f"e2et/{b}/patch", (Np, Dp), seed=63 + b)) * 0.4 for b in range(B)]
+    funet = [torch.from_numpy(O.formula_normal(f"e2et/{b}/funet", (Np, Dp), seed=73 + b)) * 0.4 for b in range(B)]
+    ylab = [torch.from_numpy((O.formula_uniform(f"e2et/{b}/y", (Np,), 0.0, 1.0, 83 + b) > 0.5).astype(np.int64)) for b in range(B)]
+    lr, wd = 1e-3, 1e-4
+    # oracle: graph branch under torch autograd + torch's Adam
+    q = {k: torch.nn.Parameter(v.clone()) for k, v in gp.items()}
+    r = {k: torch.nn.Parameter(v.clone()) for k, v in pp.items()}
+    opt = torch.optim.Adam(list(q.values()) + list(r.values()), lr=lr, weight_decay=wd)
+    lf = lp = 0.0
+    for b in range(B):
+        h = O.gat_network_forward(q, feats[b], ei, 2, 1)
+        lf = lf + O.feature_consistency_loss(funet[b][None], h[None], ylab[b][None])
+        l, _, _ = O.mincut_forward(h, ei, K, O.segment_predictor_forward(r, h, ei, True, 2))
+        lp = lp + l
+    lf, lp = lf / B, lp / B
+    (0.1 * lf + 0.5 * lp).backward()
+    g_ref = {**{"gat." + k: v.grad.clone() for k, v in q.items()}, **{k: v.grad.clone() for k, v in r.items()}}
+    opt.step()
+    # HIP path
+    up = O.make_unet_params(3, 2, 8, 2, seed=9)
+    images = torch.from_numpy(O.formula_normal("e2et/img", (B, 3, H, H), seed=5)).to(cuda)
+    masks = torch.from_numpy((O.formula_uniform("e2et/mask", (B, H, H), 0.0, 1.0, 6) > 0.5).astype(np.int64)).to(cuda)
+
+    def unet():
+        m = mgunet.UNet(3, 2, 8, 2)
+        m.load_state_dict(up)
+        return m.to(cuda)
+    plain = mgunet.Trainer(unet(), lr=lr, weight_decay=wd)
+    loss_plain = plain.train_step(images, masks)
+    gat = mgunet.GATNetwork(Dp, 16, Dp, 2, num_gat_layers=1, dropout_rate=0.0)
+    gat.load_state_dict(gp)
+    gat = gat.to(cuda).train()
+    pred = build_predictor(cuda, Dp, K, 16, True, 2, pp)
+    tr = mgunet.E2ETrainer(mgunet.Trainer(unet(), lr=lr, weight_decay=wd), gat, pred, mgunet.MinCutRefinement(),
+                           mgunet.FeatureConsistencyLoss(margin=1.0), num_segments=K)
+    out = tr.step(images, masks, [f.to(cuda) for f in feats], [f.to(cuda) for f in funet], [y.to(cuda) for y in ylab], ei.to(cuda))
+    assert set(out) == {"total", "l_unet_seg", "l_shape", "l_feature", "l_partition", "l_smooth"}
+    assert abs(float(out["l_unet_seg"]) - float(loss_plain)) <= 1e-6                       # same step as the U-Net-only trainer ...
+    assert torch.equal(tr.unet.flat, plain.flat)                                            # ... bit for bit (deterministic kernels)
+    assert abs(float(out["l_feature"]) - float(lf.detach())) <= 2e-5 * max(1.0, float(lf.detach()))
+    assert abs(float(out["l_partition"]) - float(lp.detach())) <= 2e-5 * max(1.0, float(lp.detach()))
+    assert abs(float(out["total"]) - (float(loss_plain) + 0.1 * float(lf.detach()) + 0.5 * float(lp.detach()))) <= 1e-4
+    # Adam's first step moves every parameter by ~lr * sign(g): compare where the gradient is not at rounding level
+    new = {**{"gat." + k: v for k, v in gat.state_dict().items()}, **dict(pred.state_dict())}
+    ref_new = {**{"gat." + k: v.detach() for k, v in q.items()}, **{k: v.detach() for k, v in r.items()}}
+    for k, v in new.items():
+        solid = g_ref[k].abs() > 1e-6
+        d = (v.cpu() - ref_new[k]).abs()
+        assert float(d[solid].max() if solid.any() else 0.0) <= 2e-6, (k, float(d[solid].max()))
+        assert float(d.max()) <= 2.1 * lr, k
+    # and a second iteration runs on the updated parameters (packed-weight caches follow the in-place update)
+    out2 = tr.step(images, masks, [f.to(cuda) for f in feats], [f.to(cuda) for f in funet], [y.to(cuda) for y in ylab], ei.to(cuda))
+    assert float(out2["l_partition"]) != float(out["l_partition"]) and torch.isfinite(out2["total"])
