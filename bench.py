@@ -549,6 +549,50 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(2, H, W, 14) if not c4 else cpu_baseline(1, H, W, 4)   # ~12 s of host work on the GPU box's 16-core share
 
+    # The two other single-GPU configurations of BASELINE.json, measured in the same run so that the driver's record carries them too
+    # (each also has its own full line: --dtype bf16 / --mode train).  Diagnostics: never lose the headline line over them.
+    other = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not c4 and a.dtype == "f32" and (B, H, W) == (8, 512, 512):
+        other = {}
+        try:
+            del out
+            ub = mgunet.UNet(3, 2, 32, 4, compute_dtype=torch.bfloat16)
+            ub.load_state_dict(O.make_unet_params(3, 2, 32, 4, seed=0))
+            mb = mgunet.MinGraphUNet(ub.to(dev).eval(), gat, 16).eval()
+            with torch.no_grad():
+                for _ in range(5):
+                    mb(x)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(40):
+                    mb(x)
+                torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t1) / 40 * 1e3
+            other["configs[2] precision (bf16 storage, fp32 accumulate), 8 x 3x512x512 full forward"] = {
+                "ms_per_step": round(ms, 4), "mpix_per_s": round(B * H * W / ms / 1e3, 2), "steps": 40, "own_line": "bench.py --dtype bf16"}
+            del mb, ub
+        except Exception as e:
+            other["bf16_error"] = repr(e)
+        try:
+            ut = mgunet.UNet(3, 2, 32, 4)
+            ut.load_state_dict(O.make_unet_params(3, 2, 32, 4, seed=0))
+            tr = mgunet.Trainer(ut.to(dev), lr=1e-3, weight_decay=1e-4, comm=None)
+            xt = x[:4].contiguous()
+            yt = torch.randint(0, 2, (4, H, W), device=dev, generator=gen)
+            for _ in range(3):
+                tr.train_step(xt, yt)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                tr.train_step(xt, yt)
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t1) / 10 * 1e3
+            tr.check()
+            other["configs[4] shard (4 images/GPU train step: fwd + CE + bwd + Adam, no exchange at 1 GPU)"] = {
+                "ms_per_step": round(ms, 4), "mpix_per_s": round(4 * H * W / ms / 1e3, 2), "steps": 10, "own_line": "bench.py --mode train"}
+        except Exception as e:
+            other["train_error"] = repr(e)
+
     if rank == 0:
         line = {"metric": ("segmented Mpix/sec, full MinGraph-UNet forward (U-Net + patch-graph GAT), 512x512 batch" if not c4 else
                            "segmented Mpix/sec, MinGraph-UNet forward (U-Net + stress-graph GAT), 1024x1024 batch"),
@@ -565,7 +609,7 @@ def main():
                 "gpu_event_ms_per_step": round(ev0.elapsed_time(ev1) / a.steps, 4),
                 "spread": {"windows": len(windows), "steps_per_window": a.steps, "min_ms": round(min(windows), 4),
                            "median_ms": round(statistics.median(windows), 4), "max_ms": round(max(windows), 4)},
-                "sustained": sustained, "timing": timing, "roofline": roof, "gat": gatrec, "cpu_baseline": cpu}
+                "sustained": sustained, "timing": timing, "roofline": roof, "gat": gatrec, "cpu_baseline": cpu, "other_configs": other}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -39,3 +39,14 @@ def test_train_line(cuda):
     assert j["unit"] == "Mpix/s" and j["steps"] == 2 and "configs[4]" in j["config"]["workload"]
     assert j["roofline"]["kernel"].startswith("wino") and 0.0 < j["roofline"]["frac"] < 1.0
     assert 0.0 < j["final_loss"] < 10.0
+
+
+def test_plain_run_carries_cpu_baseline_and_other_configs(cuda):
+    """What the driver runs at round end (no extra flags): the headline line plus the CPU baseline and the bf16 / train-step side measurements."""
+    j = run_bench("--steps", "3", "--warmup", "1", "--sustained-seconds", "0")
+    assert KEYS <= set(j)
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == j["unit"] and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    o = j["other_configs"]
+    assert not any(k.endswith("_error") for k in o), o
+    assert len(o) == 2 and all(v["ms_per_step"] > 0 and v["mpix_per_s"] > 0 for v in o.values())
