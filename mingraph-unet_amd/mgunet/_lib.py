@@ -11,7 +11,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)                      # .../mingraph-unet_amd
 CSRC = os.path.join(PKG_ROOT, "csrc")
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libmgunet.so")
+# MGU_LIB_PATH: developer hook for A/B runs of two builds of the SAME sources tree (tools/gpu_r03_ab.sh); the default is the in-tree build
+LIB_PATH = os.environ.get("MGU_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libmgunet.so")
 
 MGU_OK, MGU_ERR_INVALID, MGU_ERR_HIP, MGU_ERR_STATE, MGU_ERR_NOMEM = 0, -1, -2, -3, -4
 
