@@ -1178,26 +1178,33 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
     for (int nt = 0; nt < NTB; ++nt) {
       const int n0 = nblock * NC + nt * 32 + cq * 4;
       {
-        auto share = [&](const int q, const int mi, const int r) {
-          const float m0 = acc[0][nt][mi][r], m1 = acc[1][nt][mi][r];
-          return q == 0 ? (jp == 0 ? m0 + m1 : m0) * scw[nt] + shw[nt] : (jp == 0 ? m1 : -m0 - m1) * scw[nt] + shw[nt];
-        };
-        if (!top0) {
+        // the wave's role jp is uniform: one branch around two specialised copies instead of a select per value (3 instead of 6
+        // VALU per register pair; with the add-TID stores the share arithmetic is what this phase takes)
+        auto write_shares = [&](auto JP0) {
+          constexpr bool jp0 = decltype(JP0)::value;
+          auto share = [&](const int q, const int mi, const int r) {
+            const float m0 = acc[0][nt][mi][r], m1 = acc[1][nt][mi][r];
+            return q == 0 ? (jp0 ? m0 + m1 : m0) * scw[nt] + shw[nt] : (jp0 ? m1 : -m0 - m1) * scw[nt] + shw[nt];
+          };
+          if (!(jp0 && top0)) {
+            static_for<0, MT * 4>([&](auto G) {
+              constexpr int mi = decltype(G)::value >> 2, r = 4 * (decltype(G)::value & 3);
+              lds_store4_addtid<(32 * mi + 2 * r) * ZP * 4>(mz0, share(0, mi, r), share(0, mi, r + 1), share(0, mi, r + 2), share(0, mi, r + 3));
+            });
+          } else {
+            float* const z0p = zreg0 + (wi * 64 + ((et >> 5) & 1)) * ZP + (et & 31);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) z0p[(32 * mi + 2 * r) * ZP] = share(0, mi, r);
+          }
           static_for<0, MT * 4>([&](auto G) {
             constexpr int mi = decltype(G)::value >> 2, r = 4 * (decltype(G)::value & 3);
-            lds_store4_addtid<(32 * mi + 2 * r) * ZP * 4>(mz0, share(0, mi, r), share(0, mi, r + 1), share(0, mi, r + 2), share(0, mi, r + 3));
+            lds_store4_addtid<ZBIAS + (32 * mi + 2 * r) * ZP * 4>(mz1, share(1, mi, r), share(1, mi, r + 1), share(1, mi, r + 2), share(1, mi, r + 3));
           });
-        } else {
-          float* const z0p = zreg0 + (wi * 64 + ((et >> 5) & 1)) * ZP + (et & 31);
-#pragma unroll
-          for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z0p[(32 * mi + 2 * r) * ZP] = share(0, mi, r);
-        }
-        static_for<0, MT * 4>([&](auto G) {
-          constexpr int mi = decltype(G)::value >> 2, r = 4 * (decltype(G)::value & 3);
-          lds_store4_addtid<ZBIAS + (32 * mi + 2 * r) * ZP * 4>(mz1, share(1, mi, r), share(1, mi, r + 1), share(1, mi, r + 2), share(1, mi, r + 3));
-        });
+        };
+        if (jp == 0) write_shares(std::true_type{});
+        else write_shares(std::false_type{});
       }
       if (nt == 0) DIAG_T(15);   // shares written (arrival)
       lds_barrier();

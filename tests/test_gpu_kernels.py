@@ -89,6 +89,9 @@ def test_conv2d_exact_integer_data_asymmetric(cuda):
     (1, 9, 70, 32, 96),     # three patch columns (last ragged), N tail inside a 64-channel n block
     (3, 16, 32, 48, 40),    # exact patches, Cin = 3 chunks, N tail of the second n tile
     (1, 31, 33, 128, 160),  # odd sizes both ways, three n blocks
+    (4, 256, 256, 48, 32),  # four patches per workgroup with an ODD chunk count: the consumed raw buffer (= exchange region 0) alternates
+                            # between the add-TID-reachable slot and the top slot of the LDS map (ordinary stores) from patch to patch
+    (4, 256, 128, 80, 64),  # the same on the 64-channel work split (five chunks, two patches per workgroup)
 ])
 def test_winograd_conv_vs_torch_and_direct(cuda, B, H, W, Cin, Cout, monkeypatch):
     """The fp32 3x3 layers with Cin % 16 == 0 route to wino3x3_f32_kernel (Winograd F(2x2,3x3), csrc/wino_f32.hip):
