@@ -1127,6 +1127,20 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
     // Slot of tile T inside a region row: the writers store register r of m tile mi at slot 32 mi + 2 r + h (h = lane >> 5: the two
     // half waves of a store are adjacent 128-byte rows, the add-TID form), and register r of half h is tile (r & 3) + 8 (r >> 2) + 4 h.
     const int Tslot = (T & 32) + 2 * ((T & 3) + 4 * ((T & 31) >> 3)) + ((T >> 2) & 1);
+    // Per-channel scale / shift ride on the WRITER side: the epilogue is linear up to the ReLU, so a wave scales its shares by
+    // the channel of its lane (one register per n tile) and the (row 1, jp 0) wave -- Z1 enters both output rows with + -- adds
+    // the shift; the finishing pass then needs no per-channel data at all.  Loaded per patch (not held through the main loop),
+    // in front of the epilogue's first barrier (the barrier wait covers the L2 round trip: issued behind it, the first share waited for it),
+    // unconditionally (clamped index) and BEFORE the first output store of the patch: the wait for a load is a wait for every
+    // older memory operation of the wave (vmcnt retires in order), so a load -- or a scratch reload of one -- behind the
+    // previous pass's stores waits for their HBM round trip (measured: the whole gain of the barrier-light exchange).
+    float scw[NTB], shw[NTB];
+#pragma unroll
+    for (int nt = 0; nt < NTB; ++nt) {
+      const int n = min(nblock * NC + nt * 32 + (et & 31), d.N - 1);
+      scw[nt] = d.scale ? d.scale[n] : 1.f;
+      shw[nt] = (d.shift && wi == 1 && jp == 0) ? d.shift[n] : 0.f;
+    }
     DIAG_T(13);      // main loop done (arrival at the epilogue's first barrier)
     lds_barrier();   // every wave has finished reading the consumed raw buffer, which is exchange region 0 from here on
     DIAG_T(14);
@@ -1161,19 +1175,6 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
       if (sacc == 123.456f) img_out[et] = sacc;
     }
 #else
-    // Per-channel scale / shift ride on the WRITER side: the epilogue is linear up to the ReLU, so a wave scales its shares by
-    // the channel of its lane (one register per n tile) and the (row 1, jp 0) wave -- Z1 enters both output rows with + -- adds
-    // the shift; the finishing pass then needs no per-channel data at all.  Loaded per patch (not held through the main loop),
-    // unconditionally (clamped index) and BEFORE the first output store of the patch: the wait for a load is a wait for every
-    // older memory operation of the wave (vmcnt retires in order), so a load -- or a scratch reload of one -- behind the
-    // previous pass's stores waits for their HBM round trip (measured: the whole gain of the barrier-light exchange).
-    float scw[NTB], shw[NTB];
-#pragma unroll
-    for (int nt = 0; nt < NTB; ++nt) {
-      const int n = min(nblock * NC + nt * 32 + (et & 31), d.N - 1);
-      scw[nt] = d.scale ? d.scale[n] : 1.f;
-      shw[nt] = (d.shift && wi == 1 && jp == 0) ? d.shift[n] : 0.f;
-    }
 #pragma unroll
     for (int nt = 0; nt < NTB; ++nt) {
       const int n0 = nblock * NC + nt * 32 + cq * 4;
