@@ -1216,14 +1216,22 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
 #endif
       // row part + epilogue of unit (T, cq): y(2tr, .) = Z0 + Z1 + Z2, y(2tr+1, .) = Z1 - Z2 - Z3, both output columns q
       f32x4 ya[2], yb[2];
+      // all sixteen share reads of the unit in flight before the first add (the epilogue has the registers; two waves per SIMD do not
+      // cover an LDS round trip per output column)
+      f32x4 zs[2][2][4];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) zs[q][j][i] = *reinterpret_cast<const f32x4*>(zregion(q, j) + (i * 64 + Tslot) * ZP + cq * 4);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const float* za = zregion(q, 0) + Tslot * ZP + cq * 4;
-        const float* zc = zregion(q, 1) + Tslot * ZP + cq * 4;
-        const f32x4 z0 = *reinterpret_cast<const f32x4*>(za) + *reinterpret_cast<const f32x4*>(zc);
-        const f32x4 z1 = *reinterpret_cast<const f32x4*>(za + 64 * ZP) + *reinterpret_cast<const f32x4*>(zc + 64 * ZP);
-        const f32x4 z2 = *reinterpret_cast<const f32x4*>(za + 128 * ZP) + *reinterpret_cast<const f32x4*>(zc + 128 * ZP);
-        const f32x4 z3 = *reinterpret_cast<const f32x4*>(za + 192 * ZP) + *reinterpret_cast<const f32x4*>(zc + 192 * ZP);
+        const f32x4 z0 = zs[q][0][0] + zs[q][1][0];
+        const f32x4 z1 = zs[q][0][1] + zs[q][1][1];
+        const f32x4 z2 = zs[q][0][2] + zs[q][1][2];
+        const f32x4 z3 = zs[q][0][3] + zs[q][1][3];
         ya[q] = z0 + z1 + z2;
         yb[q] = z1 - z2 - z3;
         if (d.relu) {
