@@ -1135,19 +1135,39 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
     // Slot of tile T inside a region row: the writers store register r of m tile mi at slot 32 mi + 2 r + h (h = lane >> 5: the two
     // half waves of a store are adjacent 128-byte rows, the add-TID form), and register r of half h is tile (r & 3) + 8 (r >> 2) + 4 h.
     const int Tslot = (T & 32) + 2 * ((T & 3) + 4 * ((T & 31) >> 3)) + ((T >> 2) & 1);
-    // Per-channel scale / shift ride on the WRITER side: the epilogue is linear up to the ReLU, so a wave scales its shares by
-    // the channel of its lane (one register per n tile) and the (row 1, jp 0) wave -- Z1 enters both output rows with + -- adds
-    // the shift; the finishing pass then needs no per-channel data at all.  Loaded per patch (not held through the main loop),
-    // in front of the epilogue's first barrier (the barrier wait covers the L2 round trip: issued behind it, the first share waited for it),
+    // Per-channel scale / shift of the finishing unit's channel quad (y = scale * (Z0 + Z1 + Z2) + shift: 16 FMAs per unit; on the
+    // writer side -- every share scaled by its lane's channel, as rounds 2-3 had it so that the finishing pass needed no per-channel
+    // data -- it was 64 per thread, and with the add-TID stores the share arithmetic is what the write phase takes).  Loaded per patch
+    // (not held through the main loop), in front of the epilogue's first barrier (the barrier wait covers the L2 round trip),
     // unconditionally (clamped index) and BEFORE the first output store of the patch: the wait for a load is a wait for every
     // older memory operation of the wave (vmcnt retires in order), so a load -- or a scratch reload of one -- behind the
     // previous pass's stores waits for their HBM round trip (measured: the whole gain of the barrier-light exchange).
+    // Narrow inference variants only: the wide kernel and the train-mode (STATS) variants keep the writer-side form -- they sit at 256
+    // registers with spills, and the eight extra live registers per n tile add to those (wide: 12 -> 28 bytes of scratch per lane
+    // and +0.6 % per launch, measured; STATS: 72 -> 136 bytes).
+    constexpr bool RSC = !STATS && NTB == 1;
+    f32x4 sc4[NTB], sh4[NTB];
     float scw[NTB], shw[NTB];
 #pragma unroll
     for (int nt = 0; nt < NTB; ++nt) {
-      const int n = min(nblock * NC + nt * 32 + (et & 31), d.N - 1);
-      scw[nt] = d.scale ? d.scale[n] : 1.f;
-      shw[nt] = (d.shift && wi == 1 && jp == 0) ? d.shift[n] : 0.f;
+      const int n0 = nblock * NC + nt * 32 + cq * 4;
+      sc4[nt] = f32x4{1.f, 1.f, 1.f, 1.f}, sh4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      scw[nt] = 1.f, shw[nt] = 0.f;
+      if constexpr (!RSC) {
+        const int n = min(nblock * NC + nt * 32 + (et & 31), d.N - 1);
+        scw[nt] = d.scale ? d.scale[n] : 1.f;
+        shw[nt] = (d.shift && wi == 1 && jp == 0) ? d.shift[n] : 0.f;   // Z1 enters both output rows with +: the shift is added once
+      } else if (fast_n) {
+        if (d.scale) sc4[nt] = *reinterpret_cast<const f32x4*>(d.scale + n0);
+        if (d.shift) sh4[nt] = *reinterpret_cast<const f32x4*>(d.shift + n0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = min(n0 + e, d.N - 1);
+          if (d.scale) sc4[nt][e] = d.scale[n];
+          if (d.shift) sh4[nt][e] = d.shift[n];
+        }
+      }
     }
     DIAG_T(13);      // main loop done (arrival at the epilogue's first barrier)
     lds_barrier();   // every wave has finished reading the consumed raw buffer, which is exchange region 0 from here on
@@ -1187,13 +1207,14 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
     for (int nt = 0; nt < NTB; ++nt) {
       const int n0 = nblock * NC + nt * 32 + cq * 4;
       {
-        // the wave's role jp is uniform: one branch around two specialised copies instead of a select per value (3 instead of 6
+        // the wave's role jp is uniform: one branch around two specialised copies instead of a select per value (1 instead of 4
         // VALU per register pair; with the add-TID stores the share arithmetic is what this phase takes)
         auto write_shares = [&](auto JP0) {
           constexpr bool jp0 = decltype(JP0)::value;
           auto share = [&](const int q, const int mi, const int r) {
             const float m0 = acc[0][nt][mi][r], m1 = acc[1][nt][mi][r];
-            return q == 0 ? (jp0 ? m0 + m1 : m0) * scw[nt] + shw[nt] : (jp0 ? m1 : -m0 - m1) * scw[nt] + shw[nt];
+            if constexpr (RSC) return q == 0 ? (jp0 ? m0 + m1 : m0) : (jp0 ? m1 : -m0 - m1);   // two of the four shares are plain copies
+            else return q == 0 ? (jp0 ? m0 + m1 : m0) * scw[nt] + shw[nt] : (jp0 ? m1 : -m0 - m1) * scw[nt] + shw[nt];
           };
           if (!(jp0 && top0)) {
             static_for<0, MT * 4>([&](auto G) {
@@ -1242,6 +1263,7 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
         const f32x4 z3 = zs[q][0][3] + zs[q][1][3];
         ya[q] = z0 + z1 + z2;
         yb[q] = z1 - z2 - z3;
+        if constexpr (RSC) ya[q] = ya[q] * sc4[nt] + sh4[nt], yb[q] = yb[q] * sc4[nt] + sh4[nt];
         if (d.relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) ya[q][e] = relu_1op(ya[q][e]), yb[q][e] = relu_1op(yb[q][e]);
