@@ -909,7 +909,12 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
 #if defined(MGU_DIAG) && MGU_DIAG == 3   // diagnostic build: no halo loads
       hreg[set][i] = f32x4{1.f, 1.f, 1.f, 1.f};
 #else
+#if defined(MGU_DIAG) && MGU_DIAG == 30   // diagnostic build (timing only): every chunk loads the channels of chunk c & 1 -- after the first
+      // pair of a pixel every halo load hits in L2: what the kernel would take if no chunk waited for an HBM miss
+      hreg[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, hoff[i], (c & 1) * 64, 0));
+#else
       hreg[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, hoff[i], c * 64, 0));
+#endif
 #endif
   };
   auto store_halo = [&](float* Hs, auto set_c) {
