@@ -310,6 +310,13 @@ __device__ unsigned long long mgu_halo_ts[4][256][4];
 #else
 #define HALO_T(slot) do {} while (0)
 #endif
+// max(lo, x) as ONE v_max_f32 (fmaxf() is two: the backend first quiets a possible signalling NaN); same result for every input
+__device__ __forceinline__ float max_1op(const float lo, const float x) {
+  float r;
+  asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(x));
+  return r;
+}
+
 template <typename T, int NP, int TH, int WAVES_M, int WAVES_N, int WMT, int WNT, int TPS>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y,
                                                            const int total_patches, const int patches_per_block, const int yfast) {
@@ -348,12 +355,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
   const int npatch = min(patches_per_block, total_patches - p_begin);
   if (npatch <= 0) return;
 
-  // halo staging map of the patch being LOADED: thread -> (halo pixel r0 + 32 i, float4 kq).  Out-of-image
-  // pixels keep offset 0 (a mapped address: the loads stay unconditional, see the note in igemm_kernel)
-  // and are zeroed by hmask when the registers are written to LDS.
+  // halo staging map of the patch being LOADED: thread -> (halo pixel r0 + 32 i, 16-byte piece kq), as BYTE offsets into a buffer
+  // descriptor of the patch's image.  An out-of-image pixel gets an offset past the descriptor's range: the load returns zeros by
+  // itself -- no mask, no select when the registers go to LDS (44 v_cndmask per item of the 64-channel-chunk tiles before).
   int hoff[HR];
-  unsigned hmask = 0u, hmask_next = 0u;
-  const T* load_base = in_t;
+  auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in_t), 0, 0x7ffffff0, 0x00020000);
+  const unsigned img_bytes = (unsigned)((size_t)d.H * d.W * d.ldin * sizeof(T));
   // x fastest by default; y fastest (MGU_WINO_YFAST=1, as in wino3x3_cp_kernel) measured neutral (+-0.5 %) in the bf16 mode
   auto setup_patch = [&](int p, int& img, int& y0, int& x0) {
     const int ty = yfast ? p % tiles_y : (p / tiles_x) % tiles_y;
@@ -365,18 +372,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
   auto setup_load = [&](int p) {
     int img, y0, x0;
     setup_patch(p, img, y0, x0);
-    load_base = in_t + (size_t)img * d.H * d.W * d.ldin + kq * VEC;
-    unsigned mk = 0u;
+    in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in_t) + (size_t)img * d.H * d.W * d.ldin, 0, img_bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
       const int hp = r0 + RPP * i;
       const int hy = hp / HWID, hx = hp - hy * HWID;
       const int y = y0 - 1 + hy, x = x0 - 1 + hx;
       const bool ok = hp < HP && y >= 0 && y < d.H && x >= 0 && x < d.W;
-      hoff[i] = ok ? (y * d.W + x) * d.ldin : 0;
-      mk |= ok ? (1u << i) : 0u;
+      hoff[i] = ok ? ((y * d.W + x) * d.ldin + kq * VEC) * (int)sizeof(T) : 0x7fff0000;
     }
-    hmask_next = mk;
   };
   const T* wrow[BR];
 #pragma unroll
@@ -385,15 +389,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
   f32x4 hreg[HR];
   f32x4 breg[TPS][BR];
   auto load_halo = [&](int c) {
-    hmask = hmask_next;   // the mask of the patch these registers belong to
 #pragma unroll
-    for (int i = 0; i < HR; ++i) hreg[i] = *reinterpret_cast<const f32x4*>(load_base + hoff[i] + c * CK);
+    for (int i = 0; i < HR; ++i)
+      hreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, hoff[i], c * CK * (int)sizeof(T), 0));
   };
   auto store_halo = [&]() {
 #pragma unroll
     for (int i = 0; i < HR; ++i)
-      if (r0 + RPP * i < HP)
-        *reinterpret_cast<f32x4*>(Hs + (r0 + RPP * i) * LDS_LD + kq * VEC) = ((hmask >> i) & 1u) ? hreg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (r0 + RPP * i < HP) *reinterpret_cast<f32x4*>(Hs + (r0 + RPP * i) * LDS_LD + kq * VEC) = hreg[i];
   };
   auto load_b = [&](int c, int stp) {   // the TPS weight tiles of step `stp` of chunk c
 #pragma unroll
@@ -509,6 +512,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
         // (hipcc puts an s_waitcnt vmcnt(0) in front of every conditional store: serialised store round trips)
         const bool interior = (y0 + TH <= d.H) && (x0 + TW <= d.W) && (bn0 + BN <= d.N);
         const unsigned sA = (unsigned)(d.W * d.ldout), sB = (unsigned)d.ldout;
+        // interior patches store through a buffer descriptor: the lane part of the address (pixel column half + channel) is ONE
+        // 32-bit VGPR offset per n tile and the accumulator register's pixel rides in the SCALAR offset (computed on the SALU), so a
+        // stored value costs no address VALU at all (the flat form took an add and a 64-bit shift-add per value: with scale, ReLU and
+        // the conversion 6-7 VALU per value, 17 % of a 64-channel layer's patch time on the two waves of a SIMD)
+        const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(img_out, 0, 0x7ffffff0, 0x00020000);
+        const int wm_s = __builtin_amdgcn_readfirstlane(wm);   // wave-uniform by construction: tell the compiler (the scalar offset below)
+        const float relu_lo = d.relu ? 0.f : -__builtin_inff();   // y = max(relu_lo, y): one instruction whether the layer has a ReLU or not
         auto store_patch = [&](auto guarded_t) {
           constexpr bool GUARDED = decltype(guarded_t)::value;
 #pragma unroll
@@ -527,11 +537,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
                 const int pyc = 2 * (wm * WMT + mi) + (rr >> 3);            // patch row    (lane independent)
                 const int pxc = 8 * ((rr >> 2) & 1) + (rr & 3);             // patch column (without the 4*lh part)
                 float v = acc[mi][ni][rr] * sc + sh;
-                if (d.relu) v = fmaxf(v, 0.f);
+                v = max_1op(relu_lo, v);
                 vv[rr] = v;
                 const unsigned idx = lane_idx + (unsigned)pyc * sA + (unsigned)pxc * sB;
                 if (!GUARDED) {
-                  img_out[idx] = (T)v;
+                  const int soff = (int)(((unsigned)(2 * (wm_s * WMT + mi) + (rr >> 3)) * sA + (unsigned)pxc * sB) * (unsigned)sizeof(T));
+                  if constexpr (sizeof(T) == 2)
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (T)v), out_rsrc, (int)(lane_idx * 2u), soff, 0);
+                  else
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rsrc, (int)(lane_idx * 4u), soff, 0);
                 } else if (nvalid && y0 + pyc < d.H && x0 + pxc + 4 * lh < d.W) {
                   img_out[idx] = (T)v;
                 }
@@ -544,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
                 T* const pool_img = reinterpret_cast<T*>(d.pool) + (size_t)img * (d.H >> 1) * (d.W >> 1) * d.ldpool;
 #pragma unroll
                 for (int a = 0; a < 8; a += 2) {   // rr with bit 0 and bit 3 clear: 0, 2, 4, 6
-                  const float m = fmaxf(fmaxf(vv[a], vv[a + 1]), fmaxf(vv[a + 8], vv[a + 9]));
+                  const float m = max_1op(max_1op(vv[a], vv[a + 1]), max_1op(vv[a + 8], vv[a + 9]));
                   const int pyc = 2 * (wm * WMT + mi), pxc = 8 * ((a >> 2) & 1) + (a & 3) + 4 * lh;
                   const int py = (y0 + pyc) >> 1, px = (x0 + pxc) >> 1;
                   if (!GUARDED || (nvalid && y0 + pyc + 1 < d.H && x0 + pxc + 1 < d.W))
