@@ -617,8 +617,10 @@ static hipError_t launch_halo(const IgemmDesc& d, hipStream_t s) {
 template <typename T>
 static int halo_np(const IgemmDesc& d) {   // 16-byte pieces per pixel chunk the halo kernel can use, 0 = not applicable
   constexpr int VEC = Elem<T>::VEC;
-  if (!(d.KS == 3 && d.out_mode == 0 && d.K == 9 * d.Cp && d.ldin == d.Cp && (long)d.H * d.W * d.ldin < (1l << 31) &&
-        (long)d.H * d.W * d.ldout < (1l << 31) && tun(d).use_halo))
+  // one image in BYTES below the buffer descriptors' reach: the input offsets must stay under the out-of-image marker (0x7fff0000), the
+  // interior stores under the output descriptor's num_records (0x7ffffff0) -- a store past it would be dropped silently
+  if (!(d.KS == 3 && d.out_mode == 0 && d.K == 9 * d.Cp && d.ldin == d.Cp && (long)d.H * d.W * d.ldin * (long)sizeof(T) < 0x7fff0000l &&
+        (long)d.H * d.W * d.ldout * (long)sizeof(T) < 0x7ffffff0l && tun(d).use_halo))
     return 0;
   if (d.Cp % (8 * VEC) == 0) return 8;
   if (sizeof(T) == 2 && d.Cp % (4 * VEC) == 0) return 4;   // bf16 layers with 32 input channels

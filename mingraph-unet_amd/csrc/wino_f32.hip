@@ -1434,7 +1434,7 @@ bool wino_applicable(const IgemmDesc& d) {
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
   const bool wide = d.N > 32 && tun(d).wino_mode != 1;
   if (tun(d).wino_prec && tun(d).wino_cp && (wide || tun(d).wino_cp_narrow) &&
-      (long)d.H * d.W * d.ldin * 4 < (1l << 31)) {   // image bytes fit a buffer descriptor
+      (long)d.H * d.W * d.ldin * 4 < 0x7fff0000l) {   // image bytes below the out-of-image marker offset of the buffer descriptor
     // narrow layers: raw-operand prefetch always (RPF in the kernel) + the two-chunk load lead (DEEP) for an even chunk count; the
     // training forward (fused statistics) keeps the one-chunk lead (DEEP + RPF + statistics spills 4 registers)
     const bool deep = !wide && ((d.Cp >> 4) & 1) == 0 && tun(d).wino_deep && !d.stat_slots;
