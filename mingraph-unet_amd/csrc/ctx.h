@@ -152,6 +152,24 @@ inline int ensure(mgu_ctx* c, void** p, size_t* have, size_t need) {
   return MGU_OK;
 }
 
+// device pointer of the context's host-mapped data-error word (allocated on first use).  Bits: 1 = a label outside [0, num_classes)
+// reached a loss kernel; 2 = the GAT backward found no edge equal to the forward's graph-wide maximum (gat_bwd.hip)
+inline int err_word_dev(mgu_ctx* c, int** dev) {
+  if (!c->err_word) {
+    HIPCHK(c, hipHostMalloc((void**)&c->err_word, sizeof(int), hipHostMallocMapped));
+    *c->err_word = 0;
+  }
+  HIPCHK(c, hipHostGetDevicePointer((void**)dev, c->err_word, 0));
+  return MGU_OK;
+}
+// message of a pending data error (word value w)
+inline const char* err_word_message(int w) {
+  return (w & 2) ? "the GAT backward found no edge whose score equals the forward's graph-wide maximum (mgu_gat_layer_backward): its "
+                   "max term was not applied"
+                 : "a label outside [0, num_classes) (and != ignore_index -100) reached a loss kernel of this context (mgu_cross_entropy / "
+                   "mgu_dice_loss; F.one_hot / CrossEntropyLoss raise on it)";
+}
+
 struct ProfScope {  // records an event pair around one launch when profiling is on
   mgu_ctx* c;
   hipStream_t s;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void gatb_max_term_kernel(const float* __restr
                                                             const int32_t* __restrict__ col, const int32_t* __restrict__ tgt_e,
                                                             const int32_t* __restrict__ graph_ptr, int N, int heads, float slope,
                                                             const float* __restrict__ gm_f, const float* __restrict__ gmrow,
-                                                            float* __restrict__ gz_e, float* __restrict__ gt) {
+                                                            float* __restrict__ gz_e, float* __restrict__ gt, int* __restrict__ err_word) {
   __shared__ double red[256];
   __shared__ int cnt;
   const int g = blockIdx.x / heads, h = blockIdx.x - g * heads, t = threadIdx.x, H2 = 2 * heads;
@@ -154,22 +154,41 @@ __global__ __launch_bounds__(256) void gatb_max_term_kernel(const float* __restr
   }
   const float gm = (float)red[0], m = gm_f[g * heads + h];
   if (gm == 0.f) return;   // block-uniform
+  // arg-max edges: compared in the ENCODED domain the forward's reduction works in (gat_enc_ordered: the maximum went through
+  // encode -> atomicMax -> decode, a bijection on the bit pattern, so equal bits here == the edge that won there)
+  const unsigned m_enc = gat_enc_ordered(m);
   const int e0 = rowptr[n0], e1 = rowptr[n1];
   int mine = 0;
   for (int k = e0 + t; k < e1; k += 256) {
     const float z = st[(size_t)col[k] * H2 + h] + st[(size_t)tgt_e[k] * H2 + heads + h];
-    mine += ((z > 0.f ? z : slope * z) == m) ? 1 : 0;
+    mine += (gat_enc_ordered(z > 0.f ? z : slope * z) == m_enc) ? 1 : 0;
   }
   if (mine) atomicAdd(&cnt, mine);
   __syncthreads();
-  if (cnt == 0) return;
+  if (cnt == 0) {
+    // no edge reproduces the forward's maximum (the score arithmetic here and in gat_edge_max_kernel must stay the same expression):
+    // the term cannot be placed -- report it instead of dropping it silently
+    if (t == 0 && err_word) atomicOr(err_word, 2);
+    return;
+  }
   const float share = gm / (float)cnt;   // evenly over ties (torch.max() backward)
-  for (int k = e0 + t; k < e1; k += 256) {
-    const float z = st[(size_t)col[k] * H2 + h] + st[(size_t)tgt_e[k] * H2 + heads + h];
-    if ((z > 0.f ? z : slope * z) == m) {
-      const float v = share * (z > 0.f ? 1.f : slope);
-      gz_e[(size_t)k * heads + h] += v;                       // one writer per edge
-      atomicAdd(gt + (size_t)tgt_e[k] * heads + h, v);        // ties that share a target are the only unordered sum of the layer
+  if (cnt == 1) {   // the usual case: one arg-max edge, one writer per element
+    for (int k = e0 + t; k < e1; k += 256) {
+      const float z = st[(size_t)col[k] * H2 + h] + st[(size_t)tgt_e[k] * H2 + heads + h];
+      if (gat_enc_ordered(z > 0.f ? z : slope * z) == m_enc) {
+        const float v = share * (z > 0.f ? 1.f : slope);
+        gz_e[(size_t)k * heads + h] += v;
+        gt[(size_t)tgt_e[k] * heads + h] += v;
+      }
+    }
+  } else if (t == 0) {   // ties: one thread walks the graph's edges in order, so ties that share a target add in a fixed order
+    for (int k = e0; k < e1; ++k) {
+      const float z = st[(size_t)col[k] * H2 + h] + st[(size_t)tgt_e[k] * H2 + heads + h];
+      if (gat_enc_ordered(z > 0.f ? z : slope * z) == m_enc) {
+        const float v = share * (z > 0.f ? 1.f : slope);
+        gz_e[(size_t)k * heads + h] += v;
+        gt[(size_t)tgt_e[k] * heads + h] += v;
+      }
     }
   }
 }
@@ -313,9 +332,12 @@ int mgu_gat_layer_backward(mgu_ctx* c, const void* X_dev, int N, int Fin, const 
   // ---- attention backward ----
   hipLaunchKernelGGL(gatb_target_kernel, dim3((N + 3) / 4), dim3(256), 0, s, wh, st, rowptr_dev, col_dev, node_graph, gm_f,
                      (const float*)dout_dev, N, heads, Fh, concat, alpha, ghp, al, gz, gt, gmr);
-  if (E > 0)
+  if (E > 0) {
+    int* err_dev = nullptr;
+    if ((rc = err_word_dev(c, &err_dev))) return rc;
     hipLaunchKernelGGL(gatb_max_term_kernel, dim3(num_graphs * heads), dim3(256), 0, s, st, rowptr_dev, col_dev, tgt_of_edge_dev, graph_ptr_dev, N,
-                       heads, alpha, gm_f, gmr, gz, gt);
+                       heads, alpha, gm_f, gmr, gz, gt, err_dev);
+  }
   if (E > 0) {
     hipLaunchKernelGGL(gatb_source_kernel, dim3((N + 3) / 4), dim3(256), 0, s, ghp, al, gz, gt, rowptr_src_dev, eid_src_dev, tgt_of_edge_dev,
                        (const float*)a_dev, N, heads, Fh, gwh, gs);

@@ -310,7 +310,8 @@ __device__ unsigned long long mgu_halo_ts[4][256][4];
 #else
 #define HALO_T(slot) do {} while (0)
 #endif
-// max(lo, x) as ONE v_max_f32 (fmaxf() is two: the backend first quiets a possible signalling NaN); same result for every input
+// max(lo, x) as ONE v_max_f32 (fmaxf() is two: the backend first quiets a possible signalling NaN).  A NaN operand yields the OTHER
+// operand (IEEE mode), a NaN only if both are: callers that must pass x through untouched hand in lo = quiet NaN.
 __device__ __forceinline__ float max_1op(const float lo, const float x) {
   float r;
   asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(x));
@@ -518,7 +519,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
         // the conversion 6-7 VALU per value, 17 % of a 64-channel layer's patch time on the two waves of a SIMD)
         const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(img_out, 0, 0x7ffffff0, 0x00020000);
         const int wm_s = __builtin_amdgcn_readfirstlane(wm);   // wave-uniform by construction: tell the compiler (the scalar offset below)
-        const float relu_lo = d.relu ? 0.f : -__builtin_inff();   // y = max(relu_lo, y): one instruction whether the layer has a ReLU or not
+        // y = max(relu_lo, y): one instruction whether the layer has a ReLU or not.  Without a ReLU the bound is a quiet NaN: v_max_f32
+        // then returns y for EVERY y, a NaN included (with -inf as the bound a NaN accumulator was stored as -inf and no longer showed
+        // in the output)
+        const float relu_lo = d.relu ? 0.f : __builtin_nanf("");
         auto store_patch = [&](auto guarded_t) {
           constexpr bool GUARDED = decltype(guarded_t)::value;
 #pragma unroll

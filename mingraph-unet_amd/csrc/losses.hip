@@ -524,8 +524,9 @@ int mgu_loss_sync_check(mgu_ctx* c, void* hip_stream) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize((hipStream_t)hip_stream));
   if (c->err_word && *(volatile int*)c->err_word) {
+    const int w = *(volatile int*)c->err_word;
     *(volatile int*)c->err_word = 0;
-    return fail(c, MGU_ERR_INVALID, "a label outside [0, num_classes) reached a loss kernel of this context (F.one_hot / CrossEntropyLoss raise on it)");
+    return fail(c, MGU_ERR_INVALID, "%s", mgud::err_word_message(w));
   }
   return MGU_OK;
 }

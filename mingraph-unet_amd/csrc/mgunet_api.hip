@@ -437,7 +437,10 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
     HIPCHK(c, launch_first_conv(c->dtype, in_v, L.wf, scale, shift, out_v, B, H, W, L.Cin, L.Cout, ldout, coff, relu, s));
     return MGU_OK;
   }
-  if (stat_slots && c->dtype == MGU_DTYPE_F32 && wino_applicable(d)) {   // the Winograd epilogue also accumulates sum z, sum z^2
+  // the Winograd epilogue also accumulates sum z, sum z^2: one accumulator row per workgroup, so only while the launch's grid fits
+  // the table (>= 19 images of 512^2 or 5 of 1024^2 per GPU on the full-resolution 32-channel layer, or a small MGU_WINO_PPB_CAP, do
+  // not: the caller then takes the separate statistics pass, launch_bn_stats)
+  if (stat_slots && c->dtype == MGU_DTYPE_F32 && wino_applicable(d) && wino_grid_blocks(d) <= STAT_ROWS) {
     d.stat_slots = stat_slots;
     c->last_stat_rows = wino_grid_blocks(d);
     if (stat_fused) *stat_fused = true;

@@ -298,8 +298,9 @@ extern "C" {
 // invalid data seen by an EARLIER kernel of this context (the word is host-mapped: no synchronisation needed to read it)
 static int pending_data_error(mgu_ctx* c) {
   if (c->err_word && *(volatile int*)c->err_word) {
+    const int w = *(volatile int*)c->err_word;
     *(volatile int*)c->err_word = 0;
-    return fail(c, MGU_ERR_INVALID, "a label outside [0, num_classes) (and != ignore_index -100) reached a loss kernel of this context (mgu_cross_entropy / mgu_dice_loss)");
+    return fail(c, MGU_ERR_INVALID, "%s", err_word_message(w));
   }
   return MGU_OK;
 }

@@ -166,6 +166,12 @@ class UNet(nn.Module):
         launch for all Winograd sets) instead of a full mgu_unet_load_weights.  Falls back to the full path if this context
         has not been loaded yet."""
         ctx = self._context(device)
+        # every OTHER context this model was loaded into (another device, the other storage dtype) still holds the old packed
+        # weights under a matching (data_ptr, _version) signature -- the Adam kernel bumps no version: drop their signatures so
+        # that they reload on their next forward
+        for key in list(self._loaded_sig):
+            if key != ctx.key:
+                del self._loaded_sig[key]
         if self._loaded_sig.get(ctx.key) is None:
             return
         with torch.cuda.device(device):

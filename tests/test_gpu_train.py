@@ -246,3 +246,51 @@ def test_checkpoint_dict_resume_and_torch_adam_interchange(cuda, tmp_path):
     sd = dict(tr.model.named_parameters())
     d = torch.cat([(sd[k].detach().cpu() - p_ref[k]).abs().reshape(-1) for k in names])
     assert float(torch.quantile(d, 0.999)) <= 6e-5
+
+
+def test_train_forward_when_winograd_grid_exceeds_statistics_rows(cuda, monkeypatch):
+    """The Winograd epilogue accumulates BatchNorm batch statistics into one table row per workgroup (STAT_ROWS = 576).  A launch
+    whose grid is larger (>= 19 images of 512^2 per GPU, or a small MGU_WINO_PPB_CAP as here: 4 x 192 x 256 at one patch per
+    workgroup = 768 workgroups on the full-resolution layer) must take the separate statistics pass instead of failing, and give
+    the same logits and running statistics (model/unet/unet_encoder.py:12-13, train mode)."""
+    cfg, shape = (3, 2, 16, 2), (4, 3, 192, 256)
+    x = torch.from_numpy(O.formula_normal("statrows/x", shape, seed=31)).to(cuda)
+    out = {}
+    for tag, capv in (("fused", None), ("capped", "1")):
+        if capv is None:
+            monkeypatch.delenv("MGU_WINO_PPB_CAP", raising=False)
+        else:
+            monkeypatch.setenv("MGU_WINO_PPB_CAP", capv)
+        m = build(cfg, 31, cuda).train()   # a new model = a new mgu_ctx: the switch is read by mgu_create
+        lg = m(x)[0].clone()
+        out[tag] = (lg, {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    monkeypatch.delenv("MGU_WINO_PPB_CAP", raising=False)
+    a, b = out["fused"], out["capped"]
+    assert float((a[0] - b[0]).abs().max()) <= 2e-5 * float(a[0].abs().max())
+    for k in a[1]:
+        assert float((a[1][k] - b[1][k]).abs().max()) <= 1e-6 + 1e-5 * float(a[1][k].abs().max()), k
+
+
+def test_optimizer_step_invalidates_the_models_other_contexts(cuda):
+    """A model holds one library context per (device, storage dtype).  The Adam kernel updates the parameters in place without a
+    version bump, and Trainer.optimizer_step repacks only the training context: the bf16-storage context the same model used
+    before the step must not keep serving the old packed weights."""
+    cfg, shape = (3, 2, 8, 2), (2, 3, 32, 32)
+    x = torch.from_numpy(O.formula_normal("ctxinv/x", shape, seed=41)).to(cuda)
+    y = torch.from_numpy(O.formula_labels("ctxinv/y", (2, 32, 32), 2, seed=42)).to(cuda)
+    model = build(cfg, 41, cuda)
+    tr = mgunet.Trainer(model, lr=5e-2, weight_decay=0.0)   # a step large enough to show in the logits
+    model.eval().set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        before = model(x)[0].clone()                         # the bf16 context is created and loaded here
+    model.set_compute_dtype(torch.float32)
+    tr.train_step(x, y)
+    model.eval().set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        after = model(x)[0].clone()
+    fresh = mgunet.UNet(*cfg, compute_dtype=torch.bfloat16)
+    fresh.load_state_dict({k: v.detach().clone() for k, v in model.state_dict().items()})
+    with torch.no_grad():
+        want = fresh.to(cuda).eval()(x)[0]
+    assert float((after - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))
+    assert float((after - before).abs().max()) > 1e-3   # the step really changed the output
