@@ -212,15 +212,13 @@ hipError_t launch_gat_wa_rows(const float* W, const float* a, float* panel, int 
 // gat_fused.hip: aggregate-first path (Fin <= F')
 bool gat_fused_applicable(int Fin, int heads, int Fh, int64_t E);
 size_t gat_fused_scratch_floats(int Fin, int heads, int Fh);
-hipError_t launch_gat_prep(const float* W, const float* a, float* wa, float* Wf, int heads, int Fh, int Fin, hipStream_t s);
+hipError_t launch_gat_prep(const float* W, const float* a, float* wa, unsigned* Wx, int heads, int Fh, int Fin, hipStream_t s);
 hipError_t launch_gat_stmax(const float* x, const float* wa, int N, int Fin, int heads, const int32_t* rowptr, const int32_t* col,
                             const int32_t* gp, int G, float alpha, float* st, int32_t* node_graph, unsigned long long* gmax, int gstride,
                             unsigned gen, hipStream_t s);
-hipError_t launch_gat_st(const float* x, const float* wa, int N, int Fin, int heads, float* st, hipStream_t s);
-hipError_t launch_pack_gat_wf(const float* W, float* Wf, int heads, int Fh, int Fin, hipStream_t s);
-hipError_t launch_gat_fused(const float* x, int Fin, const float* st, const int32_t* rowptr, const int32_t* col,
-                            const int32_t* node_graph, const unsigned long long* gmax, const float* Wf, int N, int heads, int Fh, int concat,
-                            float alpha, float* out, int gstride, unsigned gen, hipStream_t s);
+hipError_t launch_gat_fused(const float* x, int Fin, const float* st, const int32_t* rowptr, const int32_t* col, const int32_t* gp, int G,
+                            const unsigned long long* gmax, const unsigned* Wx, int N, int heads, int Fh, int concat, float alpha, float* out,
+                            int gstride, unsigned gen, hipStream_t s);
 hipError_t launch_gat_node_graph(const int32_t* gp, int G, int nodes_per_graph, int N, int32_t* node_graph, hipStream_t s);
 hipError_t launch_gat_edge_max(const float* st, const int32_t* rowptr, const int32_t* col, const int32_t* node_graph, int N,
                                int heads, float alpha, unsigned long long* gmax_enc, int gstride, unsigned gen, hipStream_t s);

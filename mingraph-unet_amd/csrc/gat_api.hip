@@ -15,7 +15,7 @@ using namespace mgud;
 struct mgu_gat_weights {
   int heads = 0, Fh = 0, Fin = 0;
   bool fused = false;
-  float* buf = nullptr;   // fused: [wa (2H, Fin) | Wf (H*Fh*Fin, fragment order)];  gather: packed panel [NPp][Kp]
+  float* buf = nullptr;   // fused: [wa (2H, Fin) | Wx (three bf16 pieces of W^T, fragment order)];  gather: packed panel [NPp][Kp]
   int Kp = 0, NPp = 0;
 };
 
@@ -27,7 +27,7 @@ int prepare_into(mgu_ctx* c, mgu_gat_weights* p, const float* W, const float* a,
   p->fused = c->tn.gat_fused && gat_fused_applicable(Fin, heads, Fh, E_hint);
   size_t floats;
   if (p->fused) {
-    floats = (size_t)2 * heads * Fin + (size_t)HF * Fin + 64;
+    floats = gat_fused_scratch_floats(Fin, heads, Fh);
   } else {
     p->Kp = rup(Fin, 32), p->NPp = rup(HF + 2 * heads, 128);
     floats = (size_t)p->NPp * p->Kp;
@@ -37,9 +37,7 @@ int prepare_into(mgu_ctx* c, mgu_gat_weights* p, const float* W, const float* a,
   hipError_t e = hipMalloc((void**)&p->buf, floats * sizeof(float));
   if (e != hipSuccess) return fail(c, MGU_ERR_NOMEM, "hipMalloc(%zu) failed: %s", floats * sizeof(float), hipGetErrorString(e));
   if (p->fused) {
-    float* wa = p->buf;
-    float* wf = p->buf + (size_t)2 * heads * Fin;
-    HIPCHK(c, launch_gat_prep(W, a, wa, wf, heads, Fh, Fin, s));
+    HIPCHK(c, launch_gat_prep(W, a, p->buf, reinterpret_cast<unsigned*>(p->buf + (size_t)2 * heads * Fin), heads, Fh, Fin, s));
   } else {
     // nn.Linear weight (F',Fin) stacked over heads is already the [N][K] panel (K padded to 32); rows HF.. hold
     // W^T a_src / W^T a_tgt so the same GEMM emits the attention scalars s, t (graph_attention.py:53,57-64)
@@ -125,19 +123,19 @@ int forward_prepared(mgu_ctx* c, const mgu_gat_weights* p, const float* X, int N
   };
   if (p->fused && E > 0) {
     // aggregate-first path (gat_fused.hip): no (N, heads*F') node table, the gather moves Fin floats per edge
-    const size_t o_st = take((size_t)N * 2 * heads * 4), o_ng = take((size_t)N * 4);
+    const size_t o_st = take((size_t)N * 2 * heads * 4);
     if ((rc = ensure(c, &c->gws, &c->gws_bytes, off))) return rc;
     char* g = (char*)c->gws;
     float* st = (float*)(g + o_st);
-    int32_t* node_graph = num_graphs > 1 ? (int32_t*)(g + o_ng) : nullptr;   // node -> graph id (NULL: one graph)
+    int32_t* node_graph = nullptr;   // (no node -> graph table on this path: both kernels walk graph_ptr on the scalar unit)
     const float* wa = p->buf;
-    const float* wf = p->buf + (size_t)2 * heads * Fin;
+    const unsigned* wx = reinterpret_cast<const unsigned*>(p->buf + (size_t)2 * heads * Fin);
     {
       ProfScope ps(c, s, "gat_stmax_kernel");
       HIPCHK(c, launch_gat_stmax(X, wa, N, Fin, heads, rowptr, col, graph_ptr, num_graphs, alpha, st, node_graph, gmax, c->gmax_cap, gen, s));
     }
-    ProfScope ps(c, s, "gat_fused_kernel");
-    HIPCHK(c, launch_gat_fused(X, Fin, st, rowptr, col, node_graph, gmax, wf, N, heads, Fh, concat, alpha, out, c->gmax_cap, gen, s));
+    ProfScope ps(c, s, "gat_fused2_kernel");
+    HIPCHK(c, launch_gat_fused(X, Fin, st, rowptr, col, graph_ptr, num_graphs, gmax, wx, N, heads, Fh, concat, alpha, out, c->gmax_cap, gen, s));
     return MGU_OK;
   }
   // gather path: Wh (N, HF) node table | st (N, 2H) attention scalars from ONE GEMM, then per-graph max, then the row gather
@@ -238,7 +236,8 @@ int mgu_gat_layer_forward(mgu_ctx* c, const void* X_dev, int N, int Fin, const i
   const bool same_shape = p->buf && p->heads == heads && p->Fh == Fout_head && p->Fin == Fin && p->fused == fused;
   if (same_shape) {   // reuse the allocation, rebuild the contents (the weights may have changed)
     if (fused) {
-      HIPCHK(c, launch_gat_prep((const float*)W_dev, (const float*)a_dev, p->buf, p->buf + (size_t)2 * heads * Fin, heads, Fout_head, Fin, s));
+      HIPCHK(c, launch_gat_prep((const float*)W_dev, (const float*)a_dev, p->buf, reinterpret_cast<unsigned*>(p->buf + (size_t)2 * heads * Fin), heads,
+                                Fout_head, Fin, s));
     } else {
       HIPCHK(c, launch_pack_conv_w((const float*)W_dev, p->buf, 0, heads * Fout_head, Fin, Fin, 1, p->Kp, s));
       HIPCHK(c, launch_gat_wa_rows((const float*)W_dev, (const float*)a_dev, p->buf, heads * Fout_head, heads, Fout_head, Fin, p->Kp, s));

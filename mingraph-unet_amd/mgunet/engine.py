@@ -460,36 +460,75 @@ class E2ETrainer:
     mgu_unet_backward).  `L_feature` (FeatureConsistencyLoss on the patch GAT's output, with the batch dimension the script forgets,
     SURVEY appendix A) and `L_partition` (MinCutRefinement) differentiate the patch GAT and the segment predictor through the autograd
     nodes of mgunet.GATNetwork / MinCutRefinement / FeatureConsistencyLoss (mgu_gat_layer_backward, mgu_ncut_backward,
-    mgu_feature_consistency_loss_backward).  `L_smooth` is the TV of a constant map (:455) and `L_shape` a constant: zero gradient, not
-    evaluated.  Both parameter sets take one Adam step with the script's single (lr, weight_decay) (:228): the U-Net's in `Trainer`,
-    the graph branch's in `FlatAdam`.  The placeholders are ARGUMENTS here (the script draws them from torch's RNG per image)."""
+    mgu_feature_consistency_loss_backward).  `L_smooth` is the TV of a constant map (:455) and `L_shape` a constant: their gradient
+    is exactly zero and they are not evaluated.
+    The whole batch runs as ONE block-diagonal graph (the script loops over the images, :300-437): one patch-GAT launch sequence, one
+    segment-predictor sequence and one feature loss for the B images, B normalized-cut nodes (the loss is a per-image quotient, :440).
+    Every sub-model of the script's single Adam (:219-229) takes the step: the U-Net in `Trainer`, the patch GAT and the segment
+    predictor in `FlatAdam` -- and, when they are handed in, the region GAT, FeatureFusion and DetectionHead too: in the reference
+    they hang on the loss through `L_smooth`, whose gradient is zero, so torch gives them zero .grad tensors and Adam still applies
+    the L2 term (g = weight_decay * p).
+    With more than one rank BOTH flat gradients are averaged over the ranks before the step (the U-Net's by the Trainer's own
+    exchange -- torch.distributed or the in-library RCCL buckets -- the graph branch's as one more all-reduce), so every rank holds
+    the same parameters after it.  The placeholders are ARGUMENTS here (the script draws them from torch's RNG per image)."""
 
     def __init__(self, unet_trainer: Trainer, patch_gat: GATNetwork, segment_predictor, mincut, feature_loss, num_segments: int = 2,
-                 l_feature_weight: float = 0.1, l_partition_weight: float = 0.5):
+                 l_feature_weight: float = 0.1, l_partition_weight: float = 0.5, extra_modules=()):
+        """extra_modules: the sub-models the loss does not reach but the script's optimizer holds (region GAT, FeatureFusion,
+        DetectionHead, train_end_to_end.py:223-226): stepped with zero gradients, i.e. the weight-decay term alone."""
         self.unet = unet_trainer
         self.patch_gat, self.predictor, self.mincut, self.feature_loss = patch_gat, segment_predictor, mincut, feature_loss
         self.K, self.wf, self.wp = num_segments, l_feature_weight, l_partition_weight
-        self.graph_opt = FlatAdam([patch_gat, segment_predictor], lr=unet_trainer.lr, weight_decay=unet_trainer.wd,
+        self.extra_modules = [m for m in extra_modules if any(True for _ in m.parameters())]
+        self.graph_opt = FlatAdam([patch_gat, segment_predictor, *self.extra_modules], lr=unet_trainer.lr, weight_decay=unet_trainer.wd,
                                   betas=unet_trainer.betas, eps=unet_trainer.eps)
+        self._batch_graph = None
+
+    def _block_diagonal(self, edge_index: torch.Tensor, Np: int, B: int):
+        """(edge_index of the B-image batch, graph_ptr): image b's nodes are [b * Np, (b + 1) * Np).  Cached per (edge_index, B)."""
+        key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, Np, B)
+        if self._batch_graph is None or self._batch_graph[0] != key:
+            off = (torch.arange(B, device=edge_index.device, dtype=edge_index.dtype) * Np).view(B, 1, 1)
+            ei = (edge_index.unsqueeze(0) + off).permute(1, 0, 2).reshape(2, -1).contiguous()
+            gp = (torch.arange(B + 1, device=edge_index.device, dtype=torch.int64) * Np).to(torch.int32)
+            self._batch_graph = (key, ei, gp, edge_index)
+        return self._batch_graph[1], self._batch_graph[2]
+
+    @staticmethod
+    def exchange_gradients_(unet_grad: torch.Tensor, graph_grad: torch.Tensor, group=None, unet_exchanged: bool = False):
+        """Mean all-reduce of both flat gradients over the ranks; returns the factors (1 / world, or 1.0 where nothing is left to
+        scale) for the two Adam steps.  `unet_exchanged`: the U-Net gradient already came back averaged (in-library RCCL exchange)."""
+        su = 1.0 if unet_exchanged else allreduce_mean_(unet_grad, group)
+        sg = allreduce_mean_(graph_grad, group)
+        return su, sg
 
     def step(self, images, masks, patch_features, f_unet_patches, patch_labels, edge_index) -> dict:
-        """images (B,3,H,W), masks (B,H,W) int64; per image b: patch_features[b] (Np, D_in) -> patch GAT, f_unet_patches[b] (Np, D) and
-        patch_labels[b] (Np,) for L_feature; edge_index: the patch graph (2, E).  Returns the script's running-loss entries."""
+        """images (B,3,H,W), masks (B,H,W) int64; per image b (lists of B tensors, or stacked (B, Np, .) tensors): patch_features[b]
+        (Np, D_in) -> patch GAT, f_unet_patches[b] (Np, D) and patch_labels[b] (Np,) for L_feature; edge_index: ONE image's patch
+        graph (2, E), shared by the batch.  Returns the script's running-loss entries."""
         B = images.shape[0]
-        loss_seg = self.unet.forward_backward(images, masks)
+        stack = lambda v: v if isinstance(v, torch.Tensor) else torch.stack(list(v), 0)   # noqa: E731
+        X, FU, Y = stack(patch_features), stack(f_unet_patches), stack(patch_labels)
+        Np = X.shape[1]
+        exchange = self.unet._rccl
+        loss_seg = self.unet.forward_backward(images, masks, exchange=exchange)
         self.graph_opt.zero_grad()
-        lf = lp = 0.0
-        for b in range(B):   # the per-image loop of :300-437
-            h = self.patch_gat(patch_features[b], edge_index)                                          # :332
-            lf = lf + self.feature_loss(f_unet_patches[b][None], h[None], patch_labels[b][None])      # :344 (with the batch dimension)
-            l, _soft = self.mincut(h, edge_index, self.K, self.predictor)                             # :348-351
-            lp = lp + l
-        lf, lp = lf / B, lp / B                                                                       # :440-441
+        ei_all, gp = self._block_diagonal(edge_index, Np, B)
+        h = self.patch_gat(X.reshape(B * Np, -1), ei_all, graph_ptr=gp)                               # :332, all images
+        lf = self.feature_loss(FU, h.view(B, Np, -1), Y)                                              # :344 (sum over patches, mean over the batch = :440)
+        if getattr(self.predictor, "use_gnn", False):
+            seg_logits = self.predictor.gnn_predictor(h, ei_all, graph_ptr=gp)                        # :348-351 (:190)
+        else:
+            seg_logits = self.predictor(h)
+        losses, _soft, _hard = self.mincut.forward_batched(h, edge_index, B, self.K, seg_logits.contiguous())
+        lp = losses.mean()                                                                            # :441
         (self.wf * lf + self.wp * lp).backward()                                                      # the graph-branch part of :478
-        scale = allreduce_mean_(self.unet.grad, self.unet.group) if self.unet.comm is not None else 1.0
-        self.unet.optimizer_step(scale)
-        self.graph_opt.step()
+        if self.unet.comm is not None:
+            su, sg = self.exchange_gradients_(self.unet.grad, self.graph_opt.grad, self.unet.group, unet_exchanged=exchange)
+        else:
+            su = sg = 1.0
+        self.unet.optimizer_step(su)
+        self.graph_opt.step(sg)
         total = loss_seg.detach() + self.wf * lf.detach() + self.wp * lp.detach()
         return {"total": total, "l_unet_seg": loss_seg.detach(), "l_shape": torch.zeros((), device=images.device),
                 "l_feature": lf.detach(), "l_partition": lp.detach(), "l_smooth": torch.zeros((), device=images.device)}
-

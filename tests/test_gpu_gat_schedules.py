@@ -1,6 +1,6 @@
 """Both GAT layer schedules through the prepared-weights entry points (mgu_gat_prepare / mgu_gat_layer_forward_prepared)
 against the oracle's per-head forward (model/gat/graph_attention.py:40-118, 150-160):
-  aggregate-first (Fin <= F': gat_stmax_kernel + gat_fused_kernel, 2 launches) and the Wh-row gather (GEMM + gat_edge_max +
+  aggregate-first (Fin <= F': gat_stmax_kernel + gat_fused2_kernel, 2 launches) and the Wh-row gather (GEMM + gat_edge_max +
   gat_aggregate, forced with MGU_NO_GAT_FUSED=1 in a context of its own), on block-diagonal patch graphs (the fast path of the
   gather kernel: every row <= 4 in-edges), a ragged random graph (rows with 0..11 in-edges, isolated nodes, a tail that is not
   a multiple of the kernels' row groups) and repeated calls (the two alternating per-graph max arrays)."""
@@ -166,3 +166,78 @@ def test_patch_graph_index_maps_bit_exact_vs_reference_fixtures(cuda, golden, ta
     orp, ocol, _ = O.coo_to_csr(big, B * N)
     assert np.array_equal(brp.cpu().numpy(), orp) and np.array_equal(bcol.cpu().numpy(), ocol)
     assert np.array_equal(pgc.edge_index(H, W, cuda, B).cpu().numpy(), big)
+
+
+@pytest.mark.parametrize("kind", ["patch", "stress"])
+def test_persistent_walk_equals_graph_by_graph(cuda, kind):
+    """gat_fused2_kernel is persistent and software-pipelined over node tiles (rows / source ids / source rows of later tiles are
+    requested while earlier tiles compute).  At BASELINE sizes a workgroup walks several tiles: 72 patch graphs of the 512^2 grid
+    (2304 tiles) and configs[3]'s 32 stress graphs (2048 tiles, Fin = 64, in-degree 8).  A graph's rows must be bit-identical
+    whether it runs inside the batch or alone (one tile per workgroup: no pipeline), and match the oracle on one graph."""
+    ctx = make_ctx({})
+    heads, Fh = 4, 64
+    if kind == "patch":
+        Fin, G = 32, 72
+        rowptr, col, gp, N1, E1 = mgunet.PatchGraphConstructor(16).batched_csr(512, 512, G, cuda)
+        ei1 = torch.from_numpy(O.patch_graph_edges(512, 512, 16))
+    else:
+        Fin, G, N1, deg = 64, 32, 2048, 8
+        rng = np.random.default_rng(3)
+        src = rng.integers(0, N1, size=(G, N1 * deg))
+        col = torch.from_numpy((src + (np.arange(G) * N1)[:, None]).reshape(-1).astype(np.int32)).to(cuda)
+        rowptr = torch.from_numpy((np.arange(G * N1 + 1) * deg).astype(np.int32)).to(cuda)
+        gp = torch.from_numpy((np.arange(G + 1) * N1).astype(np.int32)).to(cuda)
+        E1 = N1 * deg
+        ei1 = torch.from_numpy(np.stack([src[G - 1], np.repeat(np.arange(N1), deg)]).astype(np.int64))
+    N = N1 * G
+    X = torch.from_numpy(O.formula_normal("gs/big", (N, Fin), seed=11))
+    W = torch.from_numpy(O.formula_uniform("gs/w", (heads * Fh, Fin), -0.4, 0.4, seed=1))
+    a = torch.from_numpy(O.formula_uniform("gs/a", (heads, 2 * Fh), -0.4, 0.4, seed=2))
+    Xd = X.to(cuda)
+    full = run(ctx, cuda, Xd, rowptr, col, gp, W, a, heads, Fh, 0)
+    for g in (0, G // 2, G - 1):
+        rp1 = (rowptr[g * N1:(g + 1) * N1 + 1] - rowptr[g * N1]).contiguous()
+        c1 = (col[g * E1:(g + 1) * E1] - g * N1).contiguous()
+        one = run(ctx, cuda, Xd[g * N1:(g + 1) * N1].contiguous(), rp1, c1, None, W, a, heads, Fh, 0)
+        assert torch.equal(one, full[g * N1:(g + 1) * N1]), g
+    ref = oracle_layer(X[(G - 1) * N1:], [(ei1, 0, N1)], W, a, heads, Fh, 0)
+    assert float((full[(G - 1) * N1:] - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("kind", ["patch", "stress"])
+def test_repeated_calls_are_bitwise_identical(cuda, kind):
+    """40 consecutive calls of the aggregate-first layer on BASELINE-size batches (64 patch graphs; configs[3]'s 32 stress graphs)
+    give the same bytes: no unordered sum, no timing-dependent hand-off (an earlier barrier form produced single wrong rows in
+    about every fourth call here)."""
+    ctx = make_ctx({})
+    heads, Fh = 4, 64
+    if kind == "patch":
+        Fin, G = 32, 64
+        rowptr, col, gp, N1, E1 = mgunet.PatchGraphConstructor(16).batched_csr(512, 512, G, cuda)
+    else:
+        Fin, G, N1, deg = 64, 32, 2048, 8
+        rng = np.random.default_rng(3)
+        src = rng.integers(0, N1, size=(G, N1 * deg))
+        col = torch.from_numpy((src + (np.arange(G) * N1)[:, None]).reshape(-1).astype(np.int32)).to(cuda)
+        rowptr = torch.from_numpy((np.arange(G * N1 + 1) * deg).astype(np.int32)).to(cuda)
+        gp = torch.from_numpy((np.arange(G + 1) * N1).astype(np.int32)).to(cuda)
+    N = N1 * G
+    X = torch.from_numpy(O.formula_normal("gs/rep", (N, Fin), seed=13)).to(cuda)
+    W = torch.from_numpy(O.formula_uniform("gs/w", (heads * Fh, Fin), -0.4, 0.4, seed=1)).to(cuda)
+    a = torch.from_numpy(O.formula_uniform("gs/a", (heads, 2 * Fh), -0.4, 0.4, seed=2)).to(cuda)
+    L = _lib.lib()
+    h = C.c_void_p()
+    s = _lib.current_stream_ptr(cuda)
+    _lib.check(L.mgu_gat_prepare(ctx.handle, W.data_ptr(), a.data_ptr(), heads, Fh, Fin, 1, C.byref(h), s), ctx.handle)
+    first = None
+    for i in range(40):
+        out = torch.full((N, Fh), float("nan"), device=cuda)
+        _lib.check(L.mgu_gat_layer_forward_prepared(ctx.handle, h, X.data_ptr(), N, rowptr.data_ptr(), col.data_ptr(), col.numel(), gp.data_ptr(), G,
+                                                    0, 0.2, out.data_ptr(), s), ctx.handle)
+        if first is None:
+            first = out
+        else:
+            bad = (out != first).any(1).nonzero().flatten()
+            assert bad.numel() == 0, (i, bad[:8].tolist())
+    torch.cuda.synchronize()
+    L.mgu_gat_release(ctx.handle, h)

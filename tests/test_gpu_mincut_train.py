@@ -224,9 +224,19 @@ def test_e2e_trainer_iteration_vs_oracle_and_torch_adam(cuda):
     gat.load_state_dict(gp)
     gat = gat.to(cuda).train()
     pred = build_predictor(cuda, Dp, K, 16, True, 2, pp)
+    # the sub-models the loss does not reach but the script's optimizer holds (:223-226): zero gradient, weight decay only
+    region_gat = mgunet.GATNetwork(Dp, 16, Dp, 2, num_gat_layers=1, dropout_rate=0.0)
+    region_gat.load_state_dict(O.make_gat_params(Dp, 16, Dp, 2, 1, seed=64))
+    region_gat = region_gat.to(cuda).train()
+    region_before = {k: v.detach().clone() for k, v in region_gat.state_dict().items()}
     tr = mgunet.E2ETrainer(mgunet.Trainer(unet(), lr=lr, weight_decay=wd), gat, pred, mgunet.MinCutRefinement(),
-                           mgunet.FeatureConsistencyLoss(margin=1.0), num_segments=K)
+                           mgunet.FeatureConsistencyLoss(margin=1.0), num_segments=K, extra_modules=[region_gat])
     out = tr.step(images, masks, [f.to(cuda) for f in feats], [f.to(cuda) for f in funet], [y.to(cuda) for y in ylab], ei.to(cuda))
+    # torch.optim.Adam on a zero gradient with weight decay: g = wd * p, first step = -lr * sign(p) (where |wd p| >> eps)
+    for k, v in region_gat.state_dict().items():
+        p0 = region_before[k]
+        want = p0 - lr * (wd * p0) / ((wd * p0).abs() + 1e-8)
+        assert float((v - want).abs().max()) <= 1e-7, k
     assert set(out) == {"total", "l_unet_seg", "l_shape", "l_feature", "l_partition", "l_smooth"}
     assert abs(float(out["l_unet_seg"]) - float(loss_plain)) <= 1e-6                       # same step as the U-Net-only trainer ...
     assert torch.equal(tr.unet.flat, plain.flat)                                            # ... bit for bit (deterministic kernels)
@@ -242,5 +252,6 @@ def test_e2e_trainer_iteration_vs_oracle_and_torch_adam(cuda):
         assert float(d[solid].max() if solid.any() else 0.0) <= 2e-6, (k, float(d[solid].max()))
         assert float(d.max()) <= 2.1 * lr, k
     # and a second iteration runs on the updated parameters (packed-weight caches follow the in-place update)
-    out2 = tr.step(images, masks, [f.to(cuda) for f in feats], [f.to(cuda) for f in funet], [y.to(cuda) for y in ylab], ei.to(cuda))
+    # (stacked (B, Np, .) tensors are accepted like lists of per-image tensors)
+    out2 = tr.step(images, masks, torch.stack(feats).to(cuda), torch.stack(funet).to(cuda), torch.stack(ylab).to(cuda), ei.to(cuda))
     assert float(out2["l_partition"]) != float(out["l_partition"]) and torch.isfinite(out2["total"])
