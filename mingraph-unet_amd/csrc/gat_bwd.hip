@@ -78,7 +78,11 @@ __global__ __launch_bounds__(256) void gatb_target_kernel(const float* __restric
                                                           const int32_t* __restrict__ node_graph, const float* __restrict__ gm_f,
                                                           const float* __restrict__ dout, int N, int heads, int Fh, int concat, float slope,
                                                           float* __restrict__ ghp, float* __restrict__ alpha_e, float* __restrict__ gz_e,
-                                                          float* __restrict__ gt, float* __restrict__ gmrow) {
+                                                          float* __restrict__ gt, float* __restrict__ gmrow,
+                                                          const float* __restrict__ edge_mask, const float* __restrict__ out_mask) {
+  // edge_mask (E, heads), out_mask (N, F_out): the train-mode dropout masks of the attention coefficients and of the layer output
+  // (graph_attention.py:97, :160; values 0 or 1 / (1 - p), NULL = none): h' = sum alpha_k m_k Wh_src, so d/d alpha_k carries m_k and
+  // the softmax backward is unchanged (alpha itself is not masked)
   const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (j >= N) return;   // wave-uniform
   const int HF = heads * Fh, nq = HF >> 2, qh = Fh >> 2, H2 = 2 * heads;
@@ -96,12 +100,17 @@ __global__ __launch_bounds__(256) void gatb_target_kernel(const float* __restric
     const float z = st[(size_t)src * H2 + head] + tj;
     const float x = on ? __expf((z > 0.f ? z : slope * z) - m) : 0.f;
     D += x;
-    acc += x * *reinterpret_cast<const f32x4*>(wh + (size_t)src * HF + (on ? lane * 4 : 0));
+    const float xm = edge_mask ? x * edge_mask[(size_t)k * heads + head] : x;
+    acc += xm * *reinterpret_cast<const f32x4*>(wh + (size_t)src * HF + (on ? lane * 4 : 0));
   }
   const float inv = 1.f / (D + 1e-10f);
   f32x4 go = {0.f, 0.f, 0.f, 0.f};
-  if (on) go = concat ? *reinterpret_cast<const f32x4*>(dout + (size_t)j * HF + lane * 4)
-                      : *reinterpret_cast<const f32x4*>(dout + (size_t)j * Fh + cin * 4) * (1.f / (float)heads);
+  if (on) {
+    go = concat ? *reinterpret_cast<const f32x4*>(dout + (size_t)j * HF + lane * 4)
+                : *reinterpret_cast<const f32x4*>(dout + (size_t)j * Fh + cin * 4) * (1.f / (float)heads);
+    if (out_mask) go *= concat ? *reinterpret_cast<const f32x4*>(out_mask + (size_t)j * HF + lane * 4)
+                               : *reinterpret_cast<const f32x4*>(out_mask + (size_t)j * Fh + cin * 4);
+  }
   f32x4 gh;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -114,7 +123,8 @@ __global__ __launch_bounds__(256) void gatb_target_kernel(const float* __restric
   for (int k = s0; k < s1; ++k) {
     const int src = col[k];
     const f32x4 w = *reinterpret_cast<const f32x4*>(wh + (size_t)src * HF + (on ? lane * 4 : 0));
-    const float ga = head_sum(on ? gh[0] * w[0] + gh[1] * w[1] + gh[2] * w[2] + gh[3] * w[3] : 0.f, cin, qh);   // lead lane
+    float ga = head_sum(on ? gh[0] * w[0] + gh[1] * w[1] + gh[2] * w[2] + gh[3] * w[3] : 0.f, cin, qh);   // lead lane
+    if (edge_mask) ga *= edge_mask[(size_t)k * heads + head];
     const float z = st[(size_t)src * H2 + head] + tj;
     const float al = __expf((z > 0.f ? z : slope * z) - m) * inv;
     c += al * ga;
@@ -129,8 +139,87 @@ __global__ __launch_bounds__(256) void gatb_target_kernel(const float* __restric
       const float gz = alpha_e[(size_t)k * heads + head] * (gz_e[(size_t)k * heads + head] - c) * (z > 0.f ? 1.f : slope);
       gz_e[(size_t)k * heads + head] = gz;
       gtv += gz;
+      // the source pass sums alpha_k m_k gh'_tgt: hand it the masked coefficient
+      if (edge_mask) alpha_e[(size_t)k * heads + head] *= edge_mask[(size_t)k * heads + head];
     }
   if (lead) gt[(size_t)j * heads + head] = gtv, gmrow[(size_t)j * heads + head] = -c * 1e-10f * inv;
+}
+
+// ---- train-mode forward with explicit dropout masks (graph_attention.py:97, :160): one wavefront per target row -------------------
+// h'_j = sum_k (alpha_k m_k) Wh_src(k), ELU, concat or head mean, times the output mask.  The same per-row walk as the backward's
+// target pass (which recomputes exactly these values); the eval-mode schedules (gat_fused.hip, gat.hip) are not touched.
+__global__ __launch_bounds__(256) void gatf_train_kernel(const float* __restrict__ wh, const float* __restrict__ st,
+                                                         const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                         const int32_t* __restrict__ node_graph, const float* __restrict__ gm_f, int N,
+                                                         int heads, int Fh, int concat, float slope, const float* __restrict__ edge_mask,
+                                                         const float* __restrict__ out_mask, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float stage[4][256];
+  const int wv = threadIdx.x >> 6, j = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
+  const bool row = j < N;                                  // wave-uniform; every wave reaches the barrier below
+  const int jj = row ? j : N - 1;
+  const int HF = heads * Fh, nq = HF >> 2, qh = Fh >> 2, H2 = 2 * heads;
+  const bool on = lane < nq;
+  const int head = on ? lane / qh : 0, cin = on ? lane - head * qh : 0;
+  const int s0 = rowptr[jj], s1 = rowptr[jj + 1];
+  const int g = node_graph ? node_graph[jj] : 0;
+  const float tj = st[(size_t)jj * H2 + heads + head], m = gm_f[g * heads + head];
+  float D = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = s0; k < s1; ++k) {
+    const int src = col[k];
+    const float z = st[(size_t)src * H2 + head] + tj;
+    const float x = on ? __expf((z > 0.f ? z : slope * z) - m) : 0.f;   // exp(e - max(e)) (:86)
+    D += x;
+    const float xm = edge_mask ? x * edge_mask[(size_t)k * heads + head] : x;   // dropout of the coefficient (:97)
+    acc += xm * *reinterpret_cast<const f32x4*>(wh + (size_t)src * HF + (on ? lane * 4 : 0));
+  }
+  const float inv = 1.f / (D + 1e-10f);                    // (:96)
+  f32x4 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float hp = acc[q] * inv;
+    v[q] = hp > 0.f ? hp : (__expf(hp) - 1.f);             // ELU (:118)
+  }
+  if (concat) {
+    if (row && on) {
+      if (out_mask) v *= *reinterpret_cast<const f32x4*>(out_mask + (size_t)j * HF + lane * 4);   // (:160)
+      *reinterpret_cast<f32x4*>(out + (size_t)j * HF + lane * 4) = v;                               // cat over heads (:155)
+    }
+    return;
+  }
+  if (on) *reinterpret_cast<f32x4*>(&stage[wv][lane * 4]) = v;
+  __syncthreads();
+  if (row && lane < qh) {                                   // mean over heads (:158), fixed order
+    f32x4 sum = *reinterpret_cast<const f32x4*>(&stage[wv][lane * 4]);
+    for (int h = 1; h < heads; ++h) sum += *reinterpret_cast<const f32x4*>(&stage[wv][h * Fh + lane * 4]);
+    sum *= 1.f / (float)heads;
+    if (out_mask) sum *= *reinterpret_cast<const f32x4*>(out_mask + (size_t)j * Fh + lane * 4);      // (:160)
+    *reinterpret_cast<f32x4*>(out + (size_t)j * Fh + lane * 4) = sum;
+  }
+}
+
+// ---- dropout masks from a counter-based generator of the library's own (Philox-4x32-10): value i of stream `stream` under `seed` is a
+// function of (seed, stream, i) alone -- reproducible, order-free, no state.  mask = u >= p ? 1 / (1 - p) : 0, nn.Dropout's rule.
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], const unsigned k0, const unsigned k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (unsigned)p1, c[3] = (unsigned)p0, c[0] = n0, c[2] = n2;
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(unsigned long long seed, unsigned long long stream, int64_t n, float p,
+                                                           float* __restrict__ out) {
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;   // four values per counter
+  if (i4 * 4 >= n) return;
+  unsigned c[4] = {(unsigned)i4, (unsigned)((unsigned long long)i4 >> 32), (unsigned)stream, (unsigned)(stream >> 32)};
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+  const float keep = 1.f / (1.f - p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (i4 * 4 + e < n) out[i4 * 4 + e] = ((float)(c[e] >> 8) * (1.f / 16777216.f) >= p) ? keep : 0.f;
 }
 
 // ---- the max term: gm[g][h] = sum of the rows' shares (fixed order), added to the arg-max edge(s) of the graph -----------------

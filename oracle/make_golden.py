@@ -7,7 +7,7 @@ weights / inputs of oracle/mgunet_oracle.py, checks that the oracle restatement 
 stores the reference's outputs as small fixtures.  Fixtures hold data only (inputs that are
 not formula-derivable, expected outputs, sample indices) -- never reference source text.
 
-Usage:  python oracle/make_golden.py [--only tiny,gat,gatgrad,graph,mincut,region,dethead,losses,scriptlosses,c1,c2,c4,c5]
+Usage:  python oracle/make_golden.py [--only tiny,gat,gatgrad,graph,mincut,region,dethead,losses,scriptlosses,c1,c2,c4,c5,bf16ref,gatdrop]
 """
 import argparse
 import os
@@ -785,13 +785,117 @@ def gen_c5():
     save("c5.npz", **out)
 
 
+
+GATDROP_CASES = {   # tag: (cfg (in, hidden, out, heads), layers, N, graph, x scale, weight scale, p)
+    "edge10": ((8, 16, 16, 4), 1, 10, "edge10", 1.0, 1.0, 0.1),            # the module's own 10-node example, default dropout 0.1
+    "patch":  ((32, 128, 64, 4), 1, 36, "grid6", 1.0, 1.0, 0.1),           # the patch GAT (train_end_to_end.py:144-152), 6 x 6 patches
+    "seg":    ((64, 64, 2, 2), 1, 36, "grid6", 0.5, 1.0, 0.1),             # the segment predictor (:46-54): 64 -> K = 2, 2 heads
+    "l2h1":   ((8, 16, 8, 1), 2, 10, "edge_iso", 1.0, 1.0, 0.3),           # two layers (concat, then mean), isolated node, p = 0.3
+}
+
+
+class _MaskDropout(torch.nn.Module):
+    """Stands in for an nn.Dropout of the reference: the same multiplication, with the mask given instead of drawn."""
+
+    def __init__(self, mask):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, t):
+        return t * self.mask
+
+
+def gen_gatdrop():
+    """The reference GATNetwork in TRAIN mode (graph_attention.py:97, :160) with its nn.Dropout modules replaced by explicit masks --
+    the reference's own forward code, only the random draw made reproducible: every head's `dropout` multiplies the attention
+    coefficients by that head's (E, 1) mask, every layer's `dropout` the layer output by its (N, F) mask.  Records outputs and the
+    gradients torch autograd gives (loss = sum(out * R))."""
+    print("[gatdrop] reference GATNetwork.train() with explicit dropout masks: outputs + gradients")
+    out = {}
+    for tag, (cfg, layers, N, graph, xs, ws, pdrop) in GATDROP_CASES.items():
+        if graph == "edge10":
+            ei = EDGE10
+        elif graph == "edge_iso":
+            ei = np.concatenate([EDGE10, np.array([[10, 10], [0, 3]], dtype=np.int64)], axis=1)
+            N = 11
+        else:
+            side = int(graph[4:])
+            ei = O.patch_graph_edges(side * 16, side * 16, 16)
+        ei = torch.from_numpy(np.ascontiguousarray(ei))
+        E = ei.shape[1]
+        X = torch.from_numpy(O.formula_normal(f"gatdrop/{tag}/x", (N, cfg[0]), seed=5)) * xs
+        R = torch.from_numpy(O.formula_normal(f"gatdrop/{tag}/r", (N, cfg[2]), seed=6))
+        p = O.make_gat_params(cfg[0], cfg[1], cfg[2], cfg[3], layers, seed=5, scale=ws)
+        g = RefGAT(cfg[0], cfg[1], cfg[2], cfg[3], num_gat_layers=layers, dropout_rate=pdrop).train()
+        g.load_state_dict(p)
+        masks = []
+        for l, layer in enumerate(g.gat_layers):
+            width = layer.head_out_features * (cfg[3] if layer.concat else 1)
+            em = O.dropout_mask_from_uniform(torch.from_numpy(O.formula_uniform(f"gatdrop/{tag}/e{l}", (cfg[3], E), 0.0, 1.0, 7).astype(np.float32)), pdrop)
+            om = O.dropout_mask_from_uniform(torch.from_numpy(O.formula_uniform(f"gatdrop/{tag}/o{l}", (N, width), 0.0, 1.0, 8).astype(np.float32)), pdrop)
+            masks.append((em, om))
+            for k, head in enumerate(layer.heads):
+                head.dropout = _MaskDropout(em[k].reshape(-1, 1))      # graph_attention.py:97
+            layer.dropout = _MaskDropout(om)                          # :160
+            out[f"{tag}_emask{l}"], out[f"{tag}_omask{l}"] = em.numpy(), om.numpy()
+        Xr = X.clone().requires_grad_(True)
+        y = g(Xr, ei)
+        (y * R).sum().backward()
+        q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        Xo = X.clone().requires_grad_(True)
+        yo = O.gat_network_forward(q, Xo, ei, cfg[3], layers, masks=masks)
+        (yo * R).sum().backward()
+        check(tag + ".out", yo.detach(), y.detach(), tol=2e-6 * max(1.0, float(y.abs().max())))
+        check(tag + ".dX", Xo.grad, Xr.grad, tol=2e-6 * max(1.0, float(Xr.grad.abs().max())))
+        out[tag + "_out"], out[tag + "_dX"] = y.detach().numpy(), Xr.grad.numpy()
+        for k, v in g.named_parameters():
+            check(f"{tag}.d{k}", q[k].grad, v.grad, tol=2e-6 * max(1.0, float(v.grad.abs().max())))
+            out[f"{tag}_d_{k}"] = v.grad.numpy()
+        kept = float(sum(float((m[0] > 0).float().mean()) for m in masks) / len(masks))
+        print(f"   {tag}: N {N}, E {E}, p {pdrop}, kept {kept*100:.1f} % of the coefficients, max|out| {float(y.abs().max()):.3f}")
+    save("gat_dropout.npz", **out)
+
+
+def gen_bf16ref():
+    """The REFERENCE U-Net run in bfloat16 on the CPU (module.to(torch.bfloat16), bfloat16 input: every parameter, activation and
+    the oneDNN accumulate-then-round path in bf16) against its own fp32 run at the same formula weights: the deviation a bf16
+    implementation of this network has BY ITSELF.  tests/test_gpu_bf16.py holds the HIP bf16-storage mode to
+    1.25 x these statistics (its storage is coarser in one respect only: none -- weights and activations are bf16 there too, the
+    accumulation is fp32 in both), so the bf16 tolerance is pinned by the reference, not argued."""
+    print("[bf16ref] reference UNet in bfloat16 vs its own fp32 run")
+    out = {}
+    cases = [("b", (3, 3, 8, 2), (2, 3, 37, 45), "tiny/b/x", 11, 11), ("c", (3, 2, 8, 3), (2, 3, 64, 48), "tiny/c/x", 11, 11),
+             ("c2_0", (3, 2, 32, 4), (1, 3, 512, 512), "c2/x/0", 1, 0)]
+    for tag, cfg, shape, xname, xseed, pseed in cases:
+        p = O.make_unet_params(*cfg, seed=pseed)
+        x = torch.from_numpy(O.formula_normal(xname, shape, seed=xseed))
+        with torch.no_grad():
+            lf = ref_unet(cfg, p)(x)[0]
+            m16 = ref_unet(cfg, p).to(torch.bfloat16)
+            lb = m16(x.to(torch.bfloat16))[0].float()
+        d = (lb - lf).abs()
+        scale = float(lf.abs().max())
+        agree = float((lb.argmax(1) == lf.argmax(1)).float().mean())
+        flat = d.reshape(-1)
+        p999 = float(torch.quantile(flat[:: max(1, flat.numel() // 2_000_000)], 0.999))
+        stats = np.array([float(d.max()), float(d.mean()), p999, agree, scale], dtype=np.float64)
+        print(f"   {tag}: max-abs {stats[0]:.4e} ({stats[0]/scale*100:.2f} % of max|logit| {scale:.3f}), mean-abs {stats[1]:.3e} "
+              f"({stats[1]/scale*100:.3f} %), p99.9 {p999:.3e}, argmax agreement {agree*100:.2f} %")
+        out[f"{tag}_stats"] = stats                      # [max-abs, mean-abs, 99.9th percentile, argmax agreement, max|fp32 logit|]
+        idx = sample_idx(f"bf16ref/{tag}/idx", lf.numel(), 2048)
+        out[f"{tag}_idx"] = idx
+        out[f"{tag}_fp32"] = lf.reshape(-1)[idx].numpy()
+        out[f"{tag}_bf16"] = lb.reshape(-1)[idx].numpy()
+    save("bf16_reference.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="tiny,gat,gatgrad,graph,mincut,mincutgrad,region,dethead,losses,scriptlosses,c1,c2,c4,c5")
+    ap.add_argument("--only", default="tiny,gat,gatgrad,graph,mincut,mincutgrad,region,dethead,losses,scriptlosses,c1,c2,c4,c5,bf16ref,gatdrop")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
-    fns = {"tiny": gen_tiny, "gat": gen_gat, "gatgrad": gen_gatgrad, "graph": gen_graph, "mincut": gen_mincut, "mincutgrad": gen_mincutgrad, "region": gen_region, "dethead": gen_dethead, "losses": gen_losses, "scriptlosses": gen_scriptlosses, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5}
+    fns = {"tiny": gen_tiny, "gat": gen_gat, "gatgrad": gen_gatgrad, "graph": gen_graph, "mincut": gen_mincut, "mincutgrad": gen_mincutgrad, "region": gen_region, "dethead": gen_dethead, "losses": gen_losses, "scriptlosses": gen_scriptlosses, "c1": gen_c1, "c2": gen_c2, "c4": gen_c4, "c5": gen_c5, "bf16ref": gen_bf16ref, "gatdrop": gen_gatdrop}
     for k in a.only.split(","):
         t0 = time.time()
         fns[k]()

@@ -359,8 +359,9 @@ def make_gat_params(node_feature_dim, hidden_dim, output_dim, num_heads, num_gat
     return params
 
 
-def gat_head_forward(X, edge_index, W, a, alpha=0.2):
-    """GraphAttentionLayer.forward in eval mode, graph_attention.py:40-118, literally."""
+def gat_head_forward(X, edge_index, W, a, alpha=0.2, edge_mask=None):
+    """GraphAttentionLayer.forward, graph_attention.py:40-118, literally.  edge_mask (E, 1): the train-mode dropout of the attention
+    coefficients (:97) as an explicit mask, values 0 or 1 / (1 - p) in the COO edge order (None = eval mode: identity)."""
     N = X.shape[0]
     h = X @ W.t()  # :53
     hs, ht = h[edge_index[0]], h[edge_index[1]]  # :57-58
@@ -370,20 +371,33 @@ def gat_head_forward(X, edge_index, W, a, alpha=0.2):
     exp_e = torch.exp(e - torch.max(e))  # :86 GLOBAL max
     den = torch.zeros(N, 1, dtype=X.dtype).scatter_add_(0, edge_index[1].unsqueeze(1), exp_e)  # :90-91
     att = exp_e / (den[edge_index[1]] + 1e-10)  # :94-96
+    if edge_mask is not None:
+        att = att * edge_mask.to(att.dtype)  # :97
     hp = torch.zeros_like(h)
     hp.scatter_add_(0, edge_index[1].unsqueeze(1).repeat(1, h.shape[1]), att * hs)  # :104-112
     return F.elu(hp)  # :118
 
 
-def gat_network_forward(p, X, edge_index, num_heads, num_gat_layers=1, alpha=0.2):
-    """GATNetwork.forward (eval: dropout is identity), graph_attention.py:150-160, 188-192."""
+def gat_network_forward(p, X, edge_index, num_heads, num_gat_layers=1, alpha=0.2, masks=None):
+    """GATNetwork.forward, graph_attention.py:150-160, 188-192.  masks (train mode): per layer a pair (edge_masks (H, E) -- head k's
+    dropout mask of its attention coefficients, :97 -- , out_mask (N, F_out) -- the layer's output dropout, :160), values 0 or
+    1 / (1 - p); None = eval mode (dropout is the identity)."""
     h = X
     for l in range(num_gat_layers):
+        em, om = masks[l] if masks is not None else (None, None)
         outs = [gat_head_forward(h, edge_index, p[f"gat_layers.{l}.heads.{k}.W.weight"],
-                                 p[f"gat_layers.{l}.heads.{k}.a.weight"], alpha) for k in range(num_heads)]
+                                 p[f"gat_layers.{l}.heads.{k}.a.weight"], alpha,
+                                 None if em is None else em[k].reshape(-1, 1)) for k in range(num_heads)]
         concat = (num_gat_layers > 1) and (l < num_gat_layers - 1)
         h = torch.cat(outs, dim=1) if concat else torch.mean(torch.stack(outs, 0), 0)  # :153-158
+        if om is not None:
+            h = h * om.to(h.dtype)  # :160
     return h
+
+
+def dropout_mask_from_uniform(u, p):
+    """nn.Dropout's mask from uniform numbers: keep where u >= p, scaled by 1 / (1 - p)."""
+    return (u >= p).to(torch.float32) / (1.0 - p)
 
 
 # --------------------------------------------------------------------------------------

@@ -1,7 +1,8 @@
-"""BASELINE configs[2] precision mode: bf16 storage + fp32 accumulate (inference).  The reference has no
-bf16 path of its own for this comparison (its GAT is fp32-only), so the yardstick is the fp32
-golden data with a bf16 tolerance: SURVEY 8d reports that the reference's OWN bf16 CPU run deviates 1.4 % of
-max|logit| from its fp32 run with 99.57 % argmax agreement.
+"""BASELINE configs[2] precision mode: bf16 storage + fp32 accumulate (inference).  The yardstick is PINNED by the reference
+since round 4: tests/golden/bf16_reference.npz holds the reference U-Net's own bfloat16 CPU run at the formula weights (2.6 - 2.9 %
+of max|logit| max-abs / 0.2 - 0.32 % mean-abs away from its fp32 run, 99.35 % argmax agreement on the 512^2 image), and
+test_bf16_deviation_pinned_by_the_references_own_bf16_run holds the HIP mode to 1.25 x that.  (The reference's GAT is fp32-only,
+SURVEY App. A: the graph branch stays fp32 on the bf16 features.)  The older, tighter budget below is kept as well.
 
 Two yardsticks, two tolerances:
   * against the fp32 results (what storing 23 activations per pixel in bf16 costs): every stored activation carries a
@@ -109,6 +110,38 @@ def test_bf16_kernels_vs_storage_emulation(cuda, tag, cfg, shape, first_fp32):
     print(f"[bf16 {tag}] worst segment {worst_all*100:.3f} % of its max; whole network vs whole emulation: max-abs "
           f"{float(e.max()/elg.abs().max())*100:.2f} %, mean-abs {float(e.mean()/elg.abs().max())*100:.3f} % of max|logit|")
     assert float(e.max()) <= 2.5e-2 * float(elg.abs().max())
+
+
+@pytest.mark.parametrize("tag,cfg,shape,xname,xseed,pseed", [
+    ("b", (3, 3, 8, 2), (2, 3, 37, 45), "tiny/b/x", 11, 11), ("c", (3, 2, 8, 3), (2, 3, 64, 48), "tiny/c/x", 11, 11),
+    ("c2_0", (3, 2, 32, 4), (1, 3, 512, 512), "c2/x/0", 1, 0)])
+def test_bf16_deviation_pinned_by_the_references_own_bf16_run(cuda, golden, tag, cfg, shape, xname, xseed, pseed):
+    """The bf16 tolerance pinned by the REFERENCE: tests/golden/bf16_reference.npz (oracle/make_golden.py gen_bf16ref) holds what the
+    reference's own U-Net gives in bfloat16 on the CPU at these weights and inputs -- its deviation from its own fp32 run (2.6 - 2.9 %
+    of max|logit| max-abs, 0.2 - 0.32 % mean-abs, 99.35 - 100 % argmax agreement) and sampled logits of both runs.  The HIP bf16-storage
+    mode (bf16 weights and activations, fp32 accumulation) must deviate from the reference's fp32 logits by at most 1.25 x what the
+    reference's bf16 run does: full-tensor statistics against the fp32 HIP path (itself within 1e-5 of the reference) and the sampled
+    logits against the reference's own fp32 samples."""
+    g = golden["bf16_reference"]
+    ref_max, ref_mean, ref_p999, ref_agree, scale = [float(v) for v in g[f"{tag}_stats"]]
+    x = torch.from_numpy(O.formula_normal(xname, shape, seed=xseed)).to(cuda)
+    lb = build(cfg, pseed, cuda, torch.bfloat16)(x)[0]
+    lf = build(cfg, pseed, cuda, torch.float32)(x)[0]
+    idx = torch.from_numpy(g[f"{tag}_idx"]).to(cuda)
+    fp32_s = torch.from_numpy(g[f"{tag}_fp32"]).to(cuda)
+    assert float((lf.contiguous().reshape(-1)[idx] - fp32_s).abs().max()) <= 1e-4 * scale      # same network, same inputs as the fixture
+    d = (lb - lf).abs()
+    agree = float((lb.argmax(1) == lf.argmax(1)).float().mean())
+    flat = d.reshape(-1)
+    p999 = float(torch.quantile(flat[:: max(1, flat.numel() // 2_000_000)].float(), 0.999))
+    print(f"[bf16 vs reference-bf16 {tag}] HIP max-abs {float(d.max()):.4e} / mean {float(d.mean()):.3e} / p99.9 {p999:.3e} / agree {agree*100:.2f} %   "
+          f"reference bf16: {ref_max:.4e} / {ref_mean:.3e} / {ref_p999:.3e} / {ref_agree*100:.2f} %")
+    assert float(d.max()) <= 1.25 * ref_max and float(d.mean()) <= 1.25 * ref_mean and p999 <= 1.25 * ref_p999
+    assert agree >= ref_agree - 0.005
+    # the sampled logits: HIP bf16 against the reference's fp32 samples, next to the reference's bf16 samples against the same
+    hip_s = (lb.contiguous().reshape(-1)[idx] - fp32_s).abs()
+    ref_s = (torch.from_numpy(g[f"{tag}_bf16"]).to(cuda) - fp32_s).abs()
+    assert float(hip_s.max()) <= 1.25 * max(float(ref_s.max()), ref_p999) and float(hip_s.mean()) <= 1.25 * float(ref_s.mean())
 
 
 def test_bf16_full_batch64_properties(cuda):

@@ -407,3 +407,24 @@ def test_mincut_gradients_vs_reference_fixture(golden, tag):
     for k in q:
         ref = g[f"{tag}_d_{k}"]
         assert np.abs(q[k].grad.numpy() - ref).max() <= 5e-6 * max(1.0, np.abs(ref).max()), k
+
+
+@pytest.mark.parametrize("tag,cfg,shape,xname,xseed,pseed", [("b", (3, 3, 8, 2), (2, 3, 37, 45), "tiny/b/x", 11, 11),
+                                                             ("c", (3, 2, 8, 3), (2, 3, 64, 48), "tiny/c/x", 11, 11)])
+def test_bf16_storage_emulation_within_the_references_own_bf16_deviation(golden, tag, cfg, shape, xname, xseed, pseed):
+    """The oracle's bf16-storage restatement (the kernel-level yardstick of tests/test_gpu_bf16.py) against the fixture of the
+    REFERENCE U-Net run in bfloat16 on the CPU (tests/golden/bf16_reference.npz, oracle/make_golden.py gen_bf16ref): its deviation
+    from the fp32 forward stays within 1.25 x what the reference's own bf16 run shows, and the fixture's fp32 samples are the
+    oracle's fp32 logits."""
+    g = golden["bf16_reference"]
+    ref_max, ref_mean, _, ref_agree, scale = [float(v) for v in g[f"{tag}_stats"]]
+    p = O.make_unet_params(*cfg, seed=pseed)
+    x = torch.from_numpy(O.formula_normal(xname, shape, seed=xseed))
+    with torch.no_grad():
+        lf = O.unet_forward(p, x, cfg[3])[0]
+        lb = O.unet_forward_bf16_storage(p, x, depth=cfg[3], first_fp32=False)[0]
+    idx = torch.from_numpy(g[f"{tag}_idx"])
+    assert float((lf.reshape(-1)[idx] - torch.from_numpy(g[f"{tag}_fp32"])).abs().max()) <= 1e-5 * scale
+    d = (lb - lf).abs()
+    assert float(d.max()) <= 1.25 * ref_max and float(d.mean()) <= 1.25 * ref_mean
+    assert float((lb.argmax(1) == lf.argmax(1)).float().mean()) >= ref_agree - 0.01
