@@ -209,7 +209,7 @@ int mgu_unet_request_patch_mean(mgu_ctx* ctx, int patch, void* out_dev);
 
 /* ---- patch graph: replaces preprocessing/graph_construction/patch_graph_construction.py:49-102 -- */
 /* ---- GAT training (the reference puts the graph branch's parameters in the optimizer, scripts/train_end_to_end.py:219-226, and
- * differentiates through GraphAttentionLayer.forward with loss.backward(), :478; dropout must be off: p = 0 or eval mode) ----------
+ * differentiates through GraphAttentionLayer.forward with loss.backward(), :478; eval-mode dropout here, train-mode below) ----------
  * DEVICE: transpose of a CSR-by-target: rowptr_src (N+1) / eid_src (E) list, per SOURCE node and in target-CSR order, the positions
  * of its out-edges in col[]; tgt_of_edge (E) is the target row of every edge.  Stable radix sort: every sum of the backward has a
  * fixed order.  Static per graph: build once, reuse for every step. */
@@ -223,6 +223,23 @@ int mgu_gat_layer_backward(mgu_ctx* ctx, const void* X_dev, int N, int Fin, cons
                            const int32_t* rowptr_src_dev, const int32_t* eid_src_dev, const int32_t* tgt_of_edge_dev,
                            const int32_t* graph_ptr_dev, int num_graphs, const void* W_dev, const void* a_dev, int heads, int Fout_head,
                            int concat, float alpha, const void* dout_dev, void* dX_dev, void* dW_dev, void* da_dev, void* hip_stream);
+/* ---- GAT in TRAIN mode with dropout (model/gat/graph_attention.py:97: nn.Dropout on every head's attention coefficients; :160:
+ * nn.Dropout on the layer output; default p = 0.1, configs/model.yaml:18).  The random draw is an explicit MASK (0 or 1 / (1 - p)):
+ *   edge_mask (E, heads) fp32 in the CSR-by-target edge order of col[] (head h's mask of edge k at [k * heads + h]); NULL = none
+ *   out_mask  (N, heads*Fout_head if concat else Fout_head) fp32; NULL = none
+ * so that the same draw can be fed to the reference (a patched nn.Dropout: tests/golden/gat_dropout.npz).  mgu_dropout_mask fills a
+ * mask from the library's own counter-based generator (Philox-4x32-10: element i of stream `stream` under `seed` depends on
+ * (seed, stream, i) only).  Forward: one GEMM [Wh | s | t], the per-graph max, then one wavefront per target row; the backward is
+ * mgu_gat_layer_backward with the masks applied where the forward applies them.  heads*Fout_head <= 256. */
+int mgu_dropout_mask(mgu_ctx* ctx, unsigned long long seed, unsigned long long stream, int64_t n, float p, void* mask_dev, void* hip_stream);
+int mgu_gat_layer_forward_train(mgu_ctx* ctx, const void* X_dev, int N, int Fin, const int32_t* rowptr_dev, const int32_t* col_dev, int64_t E,
+                                const int32_t* graph_ptr_dev, int num_graphs, const void* W_dev, const void* a_dev, int heads, int Fout_head,
+                                int concat, float alpha, const void* edge_mask_dev, const void* out_mask_dev, void* out_dev, void* hip_stream);
+int mgu_gat_layer_backward_train(mgu_ctx* ctx, const void* X_dev, int N, int Fin, const int32_t* rowptr_dev, const int32_t* col_dev, int64_t E,
+                                 const int32_t* rowptr_src_dev, const int32_t* eid_src_dev, const int32_t* tgt_of_edge_dev,
+                                 const int32_t* graph_ptr_dev, int num_graphs, const void* W_dev, const void* a_dev, int heads, int Fout_head,
+                                 int concat, float alpha, const void* edge_mask_dev, const void* out_mask_dev, const void* dout_dev,
+                                 void* dX_dev, void* dW_dev, void* da_dev, void* hip_stream);
 
 /* HOST routine (index maps are tiny and static per image size).  Emits the COO edge_index in the
  * reference's exact order (:77-92) into coo[0..E) (sources) and coo[E..2E) (targets), and the

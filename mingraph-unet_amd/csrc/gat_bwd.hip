@@ -376,10 +376,11 @@ int mgu_csr_transpose_device(mgu_ctx* c, const int32_t* rowptr_dev, const int32_
   return MGU_OK;
 }
 
-int mgu_gat_layer_backward(mgu_ctx* c, const void* X_dev, int N, int Fin, const int32_t* rowptr_dev, const int32_t* col_dev, int64_t E,
-                           const int32_t* rowptr_src_dev, const int32_t* eid_src_dev, const int32_t* tgt_of_edge_dev,
-                           const int32_t* graph_ptr_dev, int num_graphs, const void* W_dev, const void* a_dev, int heads, int Fout_head,
-                           int concat, float alpha, const void* dout_dev, void* dX_dev, void* dW_dev, void* da_dev, void* hip_stream) {
+static int gat_backward_impl(mgu_ctx* c, const void* X_dev, int N, int Fin, const int32_t* rowptr_dev, const int32_t* col_dev, int64_t E,
+                             const int32_t* rowptr_src_dev, const int32_t* eid_src_dev, const int32_t* tgt_of_edge_dev,
+                             const int32_t* graph_ptr_dev, int num_graphs, const void* W_dev, const void* a_dev, int heads, int Fout_head,
+                             int concat, float alpha, const float* edge_mask_dev, const float* out_mask_dev, const void* dout_dev, void* dX_dev,
+                             void* dW_dev, void* da_dev, void* hip_stream) {
   if (!c) return MGU_ERR_INVALID;
   const int Fh = Fout_head, HF = heads * Fh;
   if (!X_dev || !rowptr_dev || !W_dev || !a_dev || !dout_dev || !dW_dev || !da_dev || N < 1 || Fin < 4 || (Fin & 3) || heads < 1 || Fh < 4 ||
@@ -420,7 +421,7 @@ int mgu_gat_layer_backward(mgu_ctx* c, const void* X_dev, int N, int Fin, const 
   hipLaunchKernelGGL(gatb_gmax_decode_kernel, dim3((num_graphs * heads + 63) / 64), dim3(64), 0, s, gmax, num_graphs * heads, gen, gm_f);
   // ---- attention backward ----
   hipLaunchKernelGGL(gatb_target_kernel, dim3((N + 3) / 4), dim3(256), 0, s, wh, st, rowptr_dev, col_dev, node_graph, gm_f,
-                     (const float*)dout_dev, N, heads, Fh, concat, alpha, ghp, al, gz, gt, gmr);
+                     (const float*)dout_dev, N, heads, Fh, concat, alpha, ghp, al, gz, gt, gmr, edge_mask_dev, out_mask_dev);
   if (E > 0) {
     int* err_dev = nullptr;
     if ((rc = err_word_dev(c, &err_dev))) return rc;
@@ -440,6 +441,74 @@ int mgu_gat_layer_backward(mgu_ctx* c, const void* X_dev, int N, int Fin, const 
   // ---- the linear layer: gW = gWh^T X, gX = gWh W (a 1x1 convolution over an N x 1 image) ----
   if ((rc = mgu_conv2d_wgrad_nhwc(c, X_dev, Fin, gwh, 1, 1, N, Fin, HF, 1, dW_dev, hip_stream))) return rc;
   if (dX_dev && (rc = mgu_conv2d_dgrad_nhwc(c, gwh, W_dev, 1, 1, N, Fin, HF, 1, dX_dev, Fin, hip_stream))) return rc;
+  return MGU_OK;
+}
+
+int mgu_gat_layer_backward(mgu_ctx* c, const void* X_dev, int N, int Fin, const int32_t* rowptr_dev, const int32_t* col_dev, int64_t E,
+                           const int32_t* rowptr_src_dev, const int32_t* eid_src_dev, const int32_t* tgt_of_edge_dev,
+                           const int32_t* graph_ptr_dev, int num_graphs, const void* W_dev, const void* a_dev, int heads, int Fout_head,
+                           int concat, float alpha, const void* dout_dev, void* dX_dev, void* dW_dev, void* da_dev, void* hip_stream) {
+  return gat_backward_impl(c, X_dev, N, Fin, rowptr_dev, col_dev, E, rowptr_src_dev, eid_src_dev, tgt_of_edge_dev, graph_ptr_dev, num_graphs, W_dev,
+                           a_dev, heads, Fout_head, concat, alpha, nullptr, nullptr, dout_dev, dX_dev, dW_dev, da_dev, hip_stream);
+}
+
+int mgu_gat_layer_backward_train(mgu_ctx* c, const void* X_dev, int N, int Fin, const int32_t* rowptr_dev, const int32_t* col_dev, int64_t E,
+                                 const int32_t* rowptr_src_dev, const int32_t* eid_src_dev, const int32_t* tgt_of_edge_dev,
+                                 const int32_t* graph_ptr_dev, int num_graphs, const void* W_dev, const void* a_dev, int heads, int Fout_head,
+                                 int concat, float alpha, const void* edge_mask_dev, const void* out_mask_dev, const void* dout_dev,
+                                 void* dX_dev, void* dW_dev, void* da_dev, void* hip_stream) {
+  return gat_backward_impl(c, X_dev, N, Fin, rowptr_dev, col_dev, E, rowptr_src_dev, eid_src_dev, tgt_of_edge_dev, graph_ptr_dev, num_graphs, W_dev,
+                           a_dev, heads, Fout_head, concat, alpha, (const float*)edge_mask_dev, (const float*)out_mask_dev, dout_dev, dX_dev, dW_dev,
+                           da_dev, hip_stream);
+}
+
+int mgu_gat_layer_forward_train(mgu_ctx* c, const void* X_dev, int N, int Fin, const int32_t* rowptr_dev, const int32_t* col_dev, int64_t E,
+                                const int32_t* graph_ptr_dev, int num_graphs, const void* W_dev, const void* a_dev, int heads, int Fout_head,
+                                int concat, float alpha, const void* edge_mask_dev, const void* out_mask_dev, void* out_dev, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  const int Fh = Fout_head, HF = heads * Fh;
+  if (!X_dev || !rowptr_dev || !W_dev || !a_dev || !out_dev || N < 1 || Fin < 4 || (Fin & 3) || heads < 1 || Fh < 4 || (Fh & 3) || E < 0 ||
+      (E > 0 && !col_dev))
+    return fail(c, MGU_ERR_INVALID, "bad gat_layer_forward_train args (Fin, Fout_head multiples of 4)");
+  if (HF > 256) return fail(c, MGU_ERR_INVALID, "gat_layer_forward_train supports heads * Fout_head <= 256 (got %d x %d)", heads, Fh);
+  if ((int64_t)N * HF >= (1ll << 31)) return fail(c, MGU_ERR_INVALID, "N * heads * Fout_head must be < 2^31");
+  if (num_graphs < 1 || !graph_ptr_dev) num_graphs = 1, graph_ptr_dev = nullptr;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+  };
+  const size_t o_wh = take((size_t)N * HF * 4), o_st = take((size_t)N * 2 * heads * 4), o_ng = take((size_t)N * 4),
+               o_gm = take((size_t)num_graphs * heads * 4);
+  int rc = ensure(c, &c->gbws, &c->gbws_bytes, off);
+  if (rc) return rc;
+  char* g = (char*)c->gbws;
+  float *wh = (float*)(g + o_wh), *st = (float*)(g + o_st), *gm_f = (float*)(g + o_gm);
+  int32_t* node_graph = num_graphs > 1 ? (int32_t*)(g + o_ng) : nullptr;
+  // Wh, s, t from one GEMM and the per-graph max, exactly as mgu_gat_layer_backward recomputes them
+  if ((rc = gat_linear_st(c, (const float*)X_dev, N, Fin, (const float*)W_dev, (const float*)a_dev, heads, Fh, wh, st, s))) return rc;
+  unsigned long long* gmax;
+  unsigned gen;
+  if ((rc = gmax_buffer(c, num_graphs * heads, &gmax, &gen))) return rc;
+  if (node_graph) HIPCHK(c, launch_gat_node_graph(graph_ptr_dev, num_graphs, 0, N, node_graph, s));
+  if (E > 0) HIPCHK(c, launch_gat_edge_max(st, rowptr_dev, col_dev, node_graph, N, heads, alpha, gmax, c->gmax_cap, gen, s));
+  hipLaunchKernelGGL(gatb_gmax_decode_kernel, dim3((num_graphs * heads + 63) / 64), dim3(64), 0, s, gmax, num_graphs * heads, gen, gm_f);
+  hipLaunchKernelGGL(gatf_train_kernel, dim3((N + 3) / 4), dim3(256), 0, s, wh, st, rowptr_dev, col_dev, node_graph, gm_f, N, heads, Fh, concat,
+                     alpha, (const float*)edge_mask_dev, (const float*)out_mask_dev, (float*)out_dev);
+  HIPCHK(c, hipGetLastError());
+  return MGU_OK;
+}
+
+int mgu_dropout_mask(mgu_ctx* c, unsigned long long seed, unsigned long long stream, int64_t n, float p, void* mask_dev, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (n < 0 || !(p >= 0.f && p < 1.f) || (n > 0 && !mask_dev)) return fail(c, MGU_ERR_INVALID, "bad dropout_mask args (0 <= p < 1)");
+  if (n == 0) return MGU_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)hip_stream, seed, stream, n, p, (float*)mask_dev);
+  HIPCHK(c, hipGetLastError());
   return MGU_OK;
 }
 

@@ -3,7 +3,7 @@ model/ API over libmgunet.so).  Importing works without a GPU; running anything 
 from .config import build_from_config, get_config_recursively, load_config  # noqa: F401
 from .detection import DetectionHead  # noqa: F401
 from .engine import E2ETrainer, FlatAdam, MinGraphUNet, MinGraphUNetE2E, StepLR, Trainer, adam_state_dict, allreduce_mean_, argmax_classes, gat_forward_csr, segment_batch, shard_batch  # noqa: F401
-from .gat import GATNetwork, GraphAttentionLayer, MultiHeadGATLayer  # noqa: F401
+from .gat import GATNetwork, GraphAttentionLayer, MultiHeadGATLayer, seed_dropout  # noqa: F401
 from .losses import EllipticalShapeLoss, FeatureConsistencyLoss, TVLoss, dice_loss  # noqa: F401
 from .preprocess import EdgeDetector, HistogramEqualizer, ImagePreprocessor, patch_features_u8, postprocess_segmentation  # noqa: F401
 from .mincut import MinCutRefinement, PatchSegmentPredictor  # noqa: F401

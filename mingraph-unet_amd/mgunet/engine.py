@@ -97,7 +97,8 @@ def gat_forward_csr(gat: GATNetwork, X, rowptr, col, graph_ptr):
     G = graph_ptr.numel() - 1 if graph_ptr is not None else 1
     for layer in gat.gat_layers:
         if layer.training and layer.dropout_rate > 0:
-            raise RuntimeError("GAT HIP path implements eval mode: call .eval() (see mgunet.gat)")
+            raise RuntimeError("gat_forward_csr is the inference schedule on a prebuilt CSR: call .eval(), or run the layer through "
+                               "GATNetwork.forward(X, edge_index) for train-mode dropout (see mgunet.gat)")
         heads = list(layer.heads)
         Fh, H = heads[0].out_features, len(heads)
         W, a = stacked_head_weights(heads, _csr_cache(layer))

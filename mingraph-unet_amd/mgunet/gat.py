@@ -4,8 +4,11 @@ Same classes, constructor signatures and state_dict() keys (`gat_layers.{l}.head
 `...a.weight`).  forward(node_features, edge_index) takes the reference's COO int64 (2,E) edge_index;
 the CSR-by-target the HIP kernels consume is derived once per edge_index tensor and cached.
 All heads of a layer run in ONE kernel sequence (the reference loops over heads in Python,
-graph_attention.py:151).  Eval-mode semantics (dropout = identity); train mode is accepted only with
-dropout_rate == 0, because the reference's train-mode output depends on torch's dropout RNG stream.
+graph_attention.py:151).  Train mode with dropout_rate > 0 (the reference's default 0.1: nn.Dropout on every head's
+attention coefficients, :97, and on the layer output, :160) draws its masks on the device from the library's own
+counter-based generator (mgu_dropout_mask; `mgunet.gat.seed_dropout(seed)` restarts the stream) -- or takes them from
+`layer.dropout_masks = (edge_masks (H, E) in COO order, out_mask (N, F_out))`, the hook through which a test feeds the
+same draw to the reference (tests/golden/gat_dropout.npz) -- and runs mgu_gat_layer_forward_train / _backward_train.
 The layers are differentiable: when a parameter or the node features require grad, the call becomes a
 torch.autograd.Function whose backward is mgu_gat_layer_backward (dX, dW, da per head), so the graph
 branch trains under loss.backward() as in scripts/train_end_to_end.py:219-226, :478.
@@ -61,7 +64,7 @@ class GraphAttentionLayer(nn.Module):
 
     def forward(self, node_features, edge_index, graph_ptr=None):
         return _gat_layer_forward([self], node_features, edge_index, True, self.alpha, self.training,
-                                  self.dropout_rate, graph_ptr, _csr_cache(self))
+                                  self.dropout_rate, graph_ptr, _csr_cache(self), owner=self, out_dropout=False)
 
 
 def _csr_cache(mod):
@@ -133,11 +136,25 @@ def prepared_head_weights(heads, cache, ctx, dev, has_edges: bool):
     return ent.handle
 
 
-def _gat_layer_forward(heads, X, edge_index, concat, alpha, training, dropout_rate, graph_ptr, cache):
-    if training and dropout_rate > 0:
-        raise RuntimeError("train-mode GAT applies torch-RNG dropout to attention coefficients "
-                           "(graph_attention.py:97,160); the HIP path implements eval mode -- call .eval() "
-                           "or construct with dropout_rate=0")
+_DROPOUT = {"seed": 0x6D67756E6574, "stream": 0}   # the library's dropout generator: one stream id per mask drawn
+
+
+def seed_dropout(seed: int) -> None:
+    """Restart the device-side dropout generator (train-mode GAT masks): the same seed gives the same masks call for call."""
+    _DROPOUT["seed"], _DROPOUT["stream"] = int(seed) & (2 ** 64 - 1), 0
+
+
+def _draw_mask(ctx, dev, shape, p: float) -> torch.Tensor:
+    """nn.Dropout's mask (0 or 1 / (1 - p)) from Philox-4x32-10 on the device: element i of stream s under the seed."""
+    m = torch.empty(shape, device=dev, dtype=torch.float32)
+    _DROPOUT["stream"] += 1
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().mgu_dropout_mask(ctx.handle, _DROPOUT["seed"], _DROPOUT["stream"], m.numel(), float(p), m.data_ptr(),
+                                               _lib.current_stream_ptr(dev)), ctx.handle)
+    return m
+
+
+def _gat_layer_forward(heads, X, edge_index, concat, alpha, training, dropout_rate, graph_ptr, cache, owner=None, out_dropout=True):
     if not X.is_cuda:
         raise RuntimeError("mgunet GAT runs only on a HIP device (MI355X); there is deliberately no CPU fallback")
     if X.dtype != torch.float32:
@@ -149,6 +166,11 @@ def _gat_layer_forward(heads, X, edge_index, concat, alpha, training, dropout_ra
                            f"{heads[0].W.weight.shape[1]}x{heads[0].out_features})")
     meta = _LayerCall(heads, edge_index, concat, alpha, graph_ptr, cache)
     params = [t for h in heads for t in (h.W.weight, h.a.weight)]
+    if training and dropout_rate > 0:
+        meta.dropout_rate = float(dropout_rate)
+        meta.injected = getattr(owner, "dropout_masks", None) if owner is not None else None
+        meta.out_dropout = out_dropout   # a lone GraphAttentionLayer drops coefficients only (:97); :160 belongs to the multi-head layer
+        return _GatLayerTrainFn.apply(X, meta, *params)
     if torch.is_grad_enabled() and (X.requires_grad or any(t.requires_grad for t in params)):
         # a node of the autograd graph whose backward is mgu_gat_layer_backward (gat_bwd.hip): loss.backward() reaches the GAT
         # parameters as it does in the reference's loop (scripts/train_end_to_end.py:219-226, :478)
@@ -161,6 +183,7 @@ class _LayerCall:
 
     def __init__(self, heads, edge_index, concat, alpha, graph_ptr, cache):
         self.heads, self.edge_index, self.concat, self.alpha, self.graph_ptr, self.cache = heads, edge_index, concat, alpha, graph_ptr, cache
+        self.dropout_rate, self.injected, self.out_dropout = 0.0, None, True   # train mode (see _GatLayerTrainFn)
 
 
 def _gat_layer_run(X, m):
@@ -256,6 +279,108 @@ class _GatLayerFn(torch.autograd.Function):
         return (dX[:, :Fin].contiguous() if need_x else None, None, *grads)
 
 
+def _csr_with_perm(m, N, dev):
+    """(rowptr, col, perm): the cached CSR by target and, for injected masks, the stable COO -> CSR edge permutation."""
+    cache, edge_index = m.cache, m.edge_index
+    key = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, N, str(edge_index.device))
+    ent = cache.get("csr")
+    if ent is None or ent[0] != key:
+        rowptr, col = coo_to_csr_device(edge_index.to(dev), N)
+        ent = cache["csr"] = (key, rowptr, col, edge_index)
+        cache.pop("csr_t", None)
+        cache.pop("perm", None)
+    perm = None
+    if m.injected is not None:
+        pe = cache.get("perm")
+        if pe is None or pe[0] != key:
+            pe = cache["perm"] = (key, torch.sort(edge_index.to(dev)[1], stable=True).indices)   # the order mgu_coo_to_csr_device produces
+        perm = pe[1]
+    return ent[1], ent[2], perm
+
+
+class _GatLayerTrainFn(torch.autograd.Function):
+    """One multi-head layer in TRAIN mode with dropout (graph_attention.py:97, :160): mgu_gat_layer_forward_train with explicit masks
+    (drawn by mgu_dropout_mask, or injected through `layer.dropout_masks`), backward mgu_gat_layer_backward_train with the same masks."""
+
+    @staticmethod
+    def forward(ctx_, X, m, *params):
+        heads = m.heads
+        dev = X.device
+        N, Fin = X.shape
+        H = len(heads)
+        Fh_true = heads[0].out_features
+        Fh = (Fh_true + 3) // 4 * 4
+        W, a = stacked_head_weights(heads, m.cache)
+        Xc = X.detach().contiguous()
+        if Fin % 4:
+            Xc = F.pad(Xc, (0, 4 - Fin % 4))
+        rowptr, col, perm = _csr_with_perm(m, N, dev)
+        E = col.numel()
+        G, gp = 1, None
+        if m.graph_ptr is not None:
+            gp = m.graph_ptr.to(device=dev, dtype=torch.int32).contiguous()
+            G = gp.numel() - 1
+        c = _context(dev)
+        Fo_true = H * Fh_true if m.concat else Fh_true
+        if m.injected is not None:   # (H, E) in COO order, (N, F_out) or None: the hook a test feeds the reference's draw through
+            em_coo, om_true = m.injected
+            if tuple(em_coo.shape) != (H, E) or (om_true is not None and tuple(om_true.shape) != (N, Fo_true)):
+                raise ValueError(f"dropout_masks must be ((heads, E) = {(H, E)}, (N, F_out) = {(N, Fo_true)} or None)")
+            edge_mask = em_coo.to(device=dev, dtype=torch.float32)[:, perm].t().contiguous()
+            om_true = om_true.to(device=dev, dtype=torch.float32) if om_true is not None else None
+        else:
+            edge_mask = _draw_mask(c, dev, (max(E, 1), H), m.dropout_rate)
+            om_true = _draw_mask(c, dev, (N, Fo_true), m.dropout_rate) if m.out_dropout else None
+        if om_true is None:
+            out_mask = None
+        elif Fh != Fh_true:   # heads run zero-padded to 16-byte lanes: the pad features are ELU(0) = 0 whatever their mask
+            out_mask = F.pad(om_true.view(N, -1, Fh_true), (0, Fh - Fh_true), value=1.0).reshape(N, -1).contiguous()
+        else:
+            out_mask = om_true.contiguous()
+        out = torch.empty((N, H * Fh if m.concat else Fh), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().mgu_gat_layer_forward_train(c.handle, Xc.data_ptr(), N, Xc.shape[1], rowptr.data_ptr(), col.data_ptr() if E else None, E,
+                                                        gp.data_ptr() if gp is not None else None, G, W.data_ptr(), a.data_ptr(), H, Fh,
+                                                        1 if m.concat else 0, float(m.alpha), edge_mask.data_ptr(),
+                                                        out_mask.data_ptr() if out_mask is not None else None, out.data_ptr(),
+                                                        _lib.current_stream_ptr(dev))
+        _lib.check(rc, c.handle)
+        ctx_.meta = m
+        ctx_.saved = (Xc, W, a, rowptr, col, gp, G, Fh, Fh_true, Fin, edge_mask, out_mask)
+        if Fh != Fh_true:
+            out = out.view(N, -1, Fh)[:, :, :Fh_true].reshape(N, -1).contiguous()
+        return out
+
+    @staticmethod
+    def backward(ctx_, gout):
+        m = ctx_.meta
+        Xc, W, a, rowptr, col, gp, G, Fh, Fh_true, Fin, edge_mask, out_mask = ctx_.saved
+        heads = m.heads
+        H, N, dev = len(heads), Xc.shape[0], Xc.device
+        g = gout.detach().float()
+        if Fh != Fh_true:
+            g = F.pad(g.view(N, -1, Fh_true), (0, Fh - Fh_true)).reshape(N, -1)
+        g = g.contiguous()
+        c = _context(dev)
+        rps, eid, tgt = _transposed_csr(m.cache, rowptr, col, N, dev, c)
+        need_x = ctx_.needs_input_grad[0]
+        dX = torch.empty_like(Xc) if need_x else None
+        dW, da = torch.empty_like(W), torch.empty_like(a)
+        E = col.numel()
+        with torch.cuda.device(dev):
+            rc = _lib.lib().mgu_gat_layer_backward_train(c.handle, Xc.data_ptr(), N, Xc.shape[1], rowptr.data_ptr(), col.data_ptr() if E else None, E,
+                                                         rps.data_ptr(), eid.data_ptr(), tgt.data_ptr(), gp.data_ptr() if gp is not None else None, G,
+                                                         W.data_ptr(), a.data_ptr(), H, Fh, 1 if m.concat else 0, float(m.alpha),
+                                                         edge_mask.data_ptr(), out_mask.data_ptr() if out_mask is not None else None, g.data_ptr(),
+                                                         dX.data_ptr() if need_x else None, dW.data_ptr(), da.data_ptr(), _lib.current_stream_ptr(dev))
+        _lib.check(rc, c.handle)
+        grads = []
+        for h in range(H):
+            grads.append(dW[h * Fh:h * Fh + Fh_true, :Fin].contiguous())
+            grads.append(torch.cat([da[h:h + 1, :Fh_true], da[h:h + 1, Fh:Fh + Fh_true]], 1).contiguous())
+        return (dX[:, :Fin].contiguous() if need_x else None, None, *grads)
+
+
 class MultiHeadGATLayer(nn.Module):
     """graph_attention.py:120-160: all heads in one launch sequence; concat (:155) or mean (:158)."""
 
@@ -274,7 +399,7 @@ class MultiHeadGATLayer(nn.Module):
 
     def forward(self, node_features, edge_index, graph_ptr=None):
         return _gat_layer_forward(list(self.heads), node_features, edge_index, self.concat, self.alpha,
-                                  self.training, self.dropout_rate, graph_ptr, _csr_cache(self))
+                                  self.training, self.dropout_rate, graph_ptr, _csr_cache(self), owner=self)
 
 
 class GATNetwork(nn.Module):

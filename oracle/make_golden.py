@@ -847,7 +847,7 @@ def gen_gatdrop():
         (yo * R).sum().backward()
         check(tag + ".out", yo.detach(), y.detach(), tol=2e-6 * max(1.0, float(y.abs().max())))
         check(tag + ".dX", Xo.grad, Xr.grad, tol=2e-6 * max(1.0, float(Xr.grad.abs().max())))
-        out[tag + "_out"], out[tag + "_dX"] = y.detach().numpy(), Xr.grad.numpy()
+        out[tag + "_out"], out[tag + "_dX"], out[tag + "_ei"] = y.detach().numpy(), Xr.grad.numpy(), ei.numpy()
         for k, v in g.named_parameters():
             check(f"{tag}.d{k}", q[k].grad, v.grad, tol=2e-6 * max(1.0, float(v.grad.abs().max())))
             out[f"{tag}_d_{k}"] = v.grad.numpy()
