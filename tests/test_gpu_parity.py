@@ -193,8 +193,11 @@ def test_gat_non_multiple_of_4_input_width_and_errors(cuda):
     assert maxdiff(y, ref.numpy()) <= TOL
     with pytest.raises(IndexError):
         net(X.to(cuda), torch.tensor([[0], [30]], device=cuda))
-    with pytest.raises(RuntimeError, match="eval"):
-        net.train()(X.to(cuda), ei.to(cuda))
+    # train mode (dropout 0.1 by default, graph_attention.py:97, :160) runs since round 4: its own masks, a different result, and
+    # eval mode is unchanged afterwards (parity of the train mode itself: tests/test_gpu_gat_train.py)
+    yt = net.train()(X.to(cuda), ei.to(cuda)).detach()
+    assert bool(torch.isfinite(yt).all()) and not torch.equal(yt, y)
+    assert torch.equal(net.eval()(X.to(cuda), ei.to(cuda)), y)
 
 
 def test_patch_mean_kernel(cuda, golden):
