@@ -107,13 +107,20 @@ hipError_t launch_first_conv(int dtype, const void* in, const float* wf, const f
 size_t wino_u_floats(int Cout, int Cp);
 hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int Cp, int dgrad, int prec, hipStream_t s);
 // several Winograd weight sets in one launch (wino_f32.hip): w (Cout, Cin, 3, 3) [dgrad: roles swapped, see pack_wino_w_kernel]
+// kind 0: a Winograd set.  The small per-layer forms ride in the same launch (pack_small.h): kind 1 = first-conv weights (w, U = wf,
+// Cout, Cin); 2 = three-piece ConvTranspose fragments (w, U = Wx, Cin, Cout, dgrad = forward / data gradient); 3 = bias tile (w = bias,
+// U = shift, Cout = C, Cin = reps); 4 = direct data-gradient panel (w, U = wp, Cout, Cin, Cp = Cop, Np = Kp, dgrad = KS)
+enum { PACK_WINO = 0, PACK_FIRST_W = 1, PACK_CONVT_X3 = 2, PACK_BIAS_TILE = 3, PACK_DGRAD_W = 4 };
 struct WinoPackItem {
   const float* w;
   float* U;
   int Cout, Cin, Cp, Np, dgrad;
-  unsigned blk0;   // Np, blk0: filled by the launcher
+  unsigned blk0;   // Np (kind 0), blk0: filled by the launcher
+  int kind;
+  int reserved;    // no padding bytes: repack_weights compares the tables with memcmp to skip the upload
 };
-constexpr int WINO_PACK_MAX = 40;
+static_assert(sizeof(WinoPackItem) == 48, "WinoPackItem must have no padding");
+constexpr int WINO_PACK_MAX = 64;
 struct WinoPackBatch {
   int n, prec;
   unsigned total_blocks;
@@ -176,6 +183,9 @@ hipError_t launch_bn_bwd_reduce(const float* dy, int lddy, const float* fwd_scal
 hipError_t launch_bn_bwd_apply(const float* dy, int lddy, const float* fwd_scale, const float* fwd_shift, const float* z, const float* mean,
                                const float* invstd, const float* gamma, const double* sums, int64_t M, int C, float* dz,
                                double* work, float* dbias, hipStream_t s);
+hipError_t launch_bn_bwd_apply_deferred(const float* dy, int lddy, const float* fsc, const float* fsh, const float* z, const float* mean,
+                                        const float* invstd, const float* gamma, const double* sums, int64_t M, int C, float* dz,
+                                        double* work, int* rows, hipStream_t s);
 hipError_t launch_colsum(const float* z, int ldz, int64_t M, int C, double* work, float* out, hipStream_t s);
 hipError_t launch_maxpool2_bwd_add(const float* y, int ldy, const float* dpool, float* dskip, int ldd, int B, int H, int W,
                                    int C, hipStream_t s);
@@ -185,7 +195,7 @@ hipError_t launch_ce(const float* logits, const int64_t* labels, int64_t M, int 
 hipError_t launch_pack_dgrad_w(const float* w, float* wp, int Cout, int Cin, int Cop, int KS, int Kp, hipStream_t s);
 hipError_t launch_pack_convt_dgrad_w(const float* w, float* wp, int Cin, int Cout, int Kp, hipStream_t s);
 hipError_t launch_unpack_conv_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cout, int Cin, int Cp, int KS,
-                                   int Kp, hipStream_t s);
+                                   int Kp, hipStream_t s, double* fold_slots = nullptr, int fold_rows = 0, int fold_n = 0, float* fold_out = nullptr);
 hipError_t launch_unpack_convt_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cin, int Cout, int Kp, hipStream_t s);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                        float wd, int step, float grad_scale, hipStream_t s);

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "pack_small.h"
 
 namespace mgu {
 
@@ -48,26 +49,9 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const 
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// Wx[n / 128][k / 16][(n / 32) & 3][piece][lane = 32 * ((k / 8) & 1) + (n & 31)][k & 7]   (uint16 bf16 bit patterns)
-// n = (dy * 2 + dx) * Cout + co: the column order of the pixel-shuffle store.  w is nn.ConvTranspose2d's (Cin, Cout, 2, 2).
+// weights in fragment order: pack_convt_x3_body (pack_small.h)
 __global__ void pack_convt_x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ Wx, int Cin, int Cout) {
-  const int N = 4 * Cout;
-  const int64_t total = (int64_t)Cin * N;
-  const int ksteps = Cin >> 4;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(idx % Cin), n = (int)(idx / Cin);
-    const int q = n / Cout, co = n - q * Cout;
-    const float x = w[(((int64_t)k * Cout + co) * 2 + (q >> 1)) * 2 + (q & 1)];
-    const unsigned b0 = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(b0);            // exact
-    const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(b1);           // exact; 8 significant bits are left
-    const int lane = ((k >> 3) & 1) * 32 + (n & 31);
-    uint16_t* dst = Wx + (((((int64_t)(n >> 7) * ksteps + (k >> 4)) * 4 + ((n >> 5) & 3)) * 3) * 64 + lane) * 8 + (k & 7);
-    dst[0] = (uint16_t)(b0 >> 16);
-    dst[512] = (uint16_t)(b1 >> 16);
-    dst[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
-  }
+  pack_convt_x3_body(w, Wx, Cin, Cout, 0, blockIdx.x, gridDim.x);
 }
 
 // LDS hand-off barrier without the workgroup fence of __syncthreads(), which makes hipcc wait vmcnt(0): the prefetched loads of the next
@@ -304,23 +288,7 @@ namespace {
 // Weights of the data gradient in the same fragment layout: k = q * Cout + co (q = qy*2 + qx), n = ci.  Columns past Cin inside the last
 // 128-column block are never read (a 64-column workgroup tile reads its own half).
 __global__ void pack_convt_x3_dgrad_kernel(const float* __restrict__ w, uint16_t* __restrict__ Wx, int Cin, int Cout) {
-  const int K = 4 * Cout;
-  const int64_t total = (int64_t)Cin * K;
-  const int ksteps = K >> 4;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(idx % K), n = (int)(idx / K);
-    const int q = k / Cout, co = k - q * Cout;
-    const float x = w[(((int64_t)n * Cout + co) * 2 + (q >> 1)) * 2 + (q & 1)];
-    const unsigned b0 = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(b0);
-    const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(b1);
-    const int lane = ((k >> 3) & 1) * 32 + (n & 31);
-    uint16_t* dst = Wx + (((((int64_t)(n >> 7) * ksteps + (k >> 4)) * 4 + ((n >> 5) & 3)) * 3) * 64 + lane) * 8 + (k & 7);
-    dst[0] = (uint16_t)(b0 >> 16);
-    dst[512] = (uint16_t)(b1 >> 16);
-    dst[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
-  }
+  pack_convt_x3_body(w, Wx, Cin, Cout, 1, blockIdx.x, gridDim.x);
 }
 
 }  // namespace

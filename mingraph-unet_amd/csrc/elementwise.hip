@@ -1,6 +1,7 @@
 // HBM-bound helper kernels around the implicit-GEMM: layout packing, 2x2 max-pool, patch mean,
 // weight repacking, BatchNorm folding, class argmax.  All NHWC, 16-byte lanes where channels allow.
 #include "common.h"
+#include "pack_small.h"
 
 namespace mgu {
 
@@ -277,10 +278,7 @@ hipError_t launch_bn_fold(const float* bias, const float* gamma, const float* be
   return hipGetLastError();
 }
 
-__global__ void bias_tile_kernel(const float* bias, float* shift, int C, int reps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < C * reps) shift[i] = bias[i % C];
-}
+__global__ void bias_tile_kernel(const float* bias, float* shift, int C, int reps) { bias_tile_body(bias, shift, C, reps, blockIdx.x, gridDim.x); }
 
 hipError_t launch_bias_tile(const float* bias, float* shift, int C, int reps, hipStream_t s) {
   hipLaunchKernelGGL(bias_tile_kernel, dim3((C * reps + 255) / 256), dim3(256), 0, s, bias, shift, C, reps);
@@ -436,10 +434,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(const T* __restrict_
 
 // wf[tap][c][co] = w[co][c][tap] (OIHW), zero for c >= Cin
 __global__ void pack_first_w_kernel(const float* __restrict__ w, float* __restrict__ wf, int Cout, int Cin) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 9 * 4 * Cout) return;
-  const int co = i % Cout, c = (i / Cout) % 4, tap = i / (4 * Cout);
-  wf[i] = c < Cin ? w[((int64_t)co * Cin + c) * 9 + tap] : 0.f;
+  pack_first_w_body(w, wf, Cout, Cin, blockIdx.x, gridDim.x);
 }
 
 hipError_t launch_pack_first_w(const float* w, float* wf, int Cout, int Cin, hipStream_t s) {

@@ -186,7 +186,8 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     // fragment per operand straight from global memory -- was measured SLOWER than the LDS-tiled generic kernel, 0.178 vs 0.163 ms per
     // step: 32-byte row segments per K slice; not kept.)
     L.ctx3 = dtype == MGU_DTYPE_F32 && L.convt && L.Cin % 32 == 0 && L.Cout % 32 == 0 && c->tn.wino_prec != 0 && c->tn.convt_frag;
-    if (L.ctx3) total += convt_x3_floats(L.Cin, L.Cout);
+    if (L.ctx3) total += convt_x3_floats(L.Cin, L.Cout) + convt_x3_dgrad_floats(L.Cin, L.Cout);
+    if (dtype == MGU_DTYPE_F32 && !L.convt && L.bn.empty()) total += (size_t)rup(L.Cin, 128) * rup(L.KS * L.KS * rup(L.Cout, 4), 32);   // final conv: data-gradient panel
     L.first = !L.convt && L.KS == 3 && first_conv_applicable(dtype, L.Cin, L.Cp, L.Cout, 8, 0);
     if (L.first) total += 9 * 4 * (size_t)L.Cout;
   }
@@ -235,6 +236,9 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     L.wug = nullptr, L.wug_valid = false;
     if (L.wino && rup(L.Cout, 4) % 16 == 0) L.wug = p, p += wino_u_floats(L.Cin, rup(L.Cout, 4));
     if (L.ctx3) L.wu = p, p += convt_x3_floats(L.Cin, L.Cout);
+    L.wxg = nullptr, L.wxg_valid = false;
+    if (L.ctx3) L.wxg = p, p += convt_x3_dgrad_floats(L.Cin, L.Cout);
+    if (c->dtype == MGU_DTYPE_F32 && !L.convt && L.bn.empty()) L.wxg = p, p += (size_t)rup(L.Cin, 128) * rup(L.KS * L.KS * rup(L.Cout, 4), 32);
     L.wf = nullptr;
     if (L.first) L.wf = p, p += 9 * 4 * (size_t)L.Cout;
     if (!L.bn.empty()) {
@@ -347,30 +351,43 @@ int mgu_unet_reserve(mgu_ctx* c, int B, int H, int W, int training) {
 // optimizer step through the flat buffer).  All Winograd sets -- and, once the context has trained, the data-gradient sets --
 // go out in one launch; the eval BatchNorm fold stays lazy.
 int mgud::repack_weights(mgu_ctx* c, hipStream_t s) {
-  std::vector<WinoPackItem> items;
+  std::vector<WinoPackItem> items;   // every form goes out in the one pack_wino_w_multi_kernel launch (kinds: common.h)
   for (auto& L : c->layers) {
     const float *w = L.w_src, *b = L.b_src;
+    L.wxg_valid = false;
     if (L.convt) {
-      HIPCHK(c, launch_pack_convt_w(w, L.wp, c->dtype, L.Cin, L.Cout, L.Kp, s));
-      if (L.ctx3) HIPCHK(c, launch_pack_convt_x3(w, L.wu, L.Cin, L.Cout, s));
-      HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 4, s));  // scale unused (nullptr at launch)
+      // the generic panel is read by the fallback kernels only: built on first use when the layer runs on its three-piece fragments
+      L.wp_dirty = L.ctx3;
+      if (!L.ctx3) HIPCHK(c, launch_pack_convt_w(w, L.wp, c->dtype, L.Cin, L.Cout, L.Kp, s));
+      if (L.ctx3) items.push_back(WinoPackItem{w, L.wu, L.Cout, L.Cin, 0, 0, 0, 0, PACK_CONVT_X3});
+      items.push_back(WinoPackItem{b, L.shift, L.Cout, 4, 0, 0, 0, 0, PACK_BIAS_TILE});   // scale unused (nullptr at launch)
+      if (L.wxg && c->want_train && c->tn.convt_dgrad_x3 && (L.Cin & 63) == 0 && (L.Cout & 31) == 0) {
+        items.push_back(WinoPackItem{w, L.wxg, L.Cout, L.Cin, 0, 0, 1, 0, PACK_CONVT_X3});
+        L.wxg_valid = true;
+      }
     } else {
-      // a layer that runs as Winograd / first-conv reads wu / wf; its direct panel is packed lazily, only if a launch
-      // ever falls back to the implicit-GEMM kernel (run_layer)
+      // a layer that runs as Winograd / first-conv / 1x1 head kernel reads wu / wf / w_src; its direct panel is packed lazily, only
+      // if a launch ever falls back to the implicit-GEMM kernel (run_layer)
       L.wp_dirty = true;
-      if (L.wu) items.push_back(WinoPackItem{w, L.wu, L.Cout, L.Cin, L.Cp, 0, 0, 0});
+      if (L.wu) items.push_back(WinoPackItem{w, L.wu, L.Cout, L.Cin, L.Cp, 0, 0, 0, PACK_WINO});
       L.wug_valid = false;
       if (L.wug && c->want_train && c->tn.wino_dgrad && c->tn.use_wino) {
-        items.push_back(WinoPackItem{w, L.wug, L.Cin, L.Cout, rup(L.Cout, 4), 0, 1, 0});
+        items.push_back(WinoPackItem{w, L.wug, L.Cin, L.Cout, rup(L.Cout, 4), 0, 1, 0, PACK_WINO});
         L.wug_valid = true;
       }
-      if (!L.wu && !L.first) {
+      const bool head_kernel = L.bn.empty() && c->ncls <= 4;   // conv1x1_head_kernel reads the reference's (ncls, C) weight itself
+      if (!L.wu && !L.first && !head_kernel) {
         HIPCHK(c, launch_pack_conv_w(w, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
         L.wp_dirty = false;
       }
-      if (L.wf) HIPCHK(c, launch_pack_first_w(w, L.wf, L.Cout, L.Cin, s));
+      if (L.wf) items.push_back(WinoPackItem{w, L.wf, L.Cout, L.Cin, 0, 0, 0, 0, PACK_FIRST_W});
       if (!L.bn.empty()) c->fold_dirty = true;   // eval scale/shift are folded lazily by the next eval forward (training never reads them)
-      else HIPCHK(c, launch_bias_tile(b, L.shift, L.Cout, 1, s));
+      else items.push_back(WinoPackItem{b, L.shift, L.Cout, 1, 0, 0, 0, 0, PACK_BIAS_TILE});
+      if (L.bn.empty() && L.wxg && c->want_train) {   // final conv: panel of its data gradient (mgu_unet_backward)
+        const int Cop = rup(L.Cout, 4);
+        items.push_back(WinoPackItem{w, L.wxg, L.Cout, L.Cin, Cop, rup(L.KS * L.KS * Cop, 32), L.KS, 0, PACK_DGRAD_W});
+        L.wxg_valid = true;
+      }
     }
   }
   // batches of <= WINO_PACK_MAX items; the tables are uploaded only when they differ from what the device already holds (a
@@ -450,9 +467,13 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
     d.pool = (float*)pool, d.ldpool = ldpool;
     if (pool_fused) *pool_fused = true;
   }
-  if (L.wp_dirty && !(c->dtype == MGU_DTYPE_F32 && wino_applicable(d))) {   // falling back to the direct kernel: build its panel now
-    HIPCHK(c, launch_pack_conv_w(L.w_src, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
-    L.wp_dirty = false;
+  if (L.wp_dirty) {   // falling back to the direct kernel: build its panel now
+    const bool direct = L.convt ? !(c->dtype == MGU_DTYPE_F32 && convt_x3_applicable(d)) : !(c->dtype == MGU_DTYPE_F32 && wino_applicable(d));
+    if (direct) {
+      if (L.convt) HIPCHK(c, launch_pack_convt_w(L.w_src, L.wp, c->dtype, L.Cin, L.Cout, L.Kp, s));
+      else HIPCHK(c, launch_pack_conv_w(L.w_src, L.wp, c->dtype, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, s));
+      L.wp_dirty = false;
+    }
   }
   // profiling record: algorithmic 2*MAC of the operator and what the matrix pipe really issues (Winograd F(2x2,3x3): 16 products
   // per 2x2 tile and channel pair; the three-piece operand split issues six bf16 products per fp32 product)

@@ -120,6 +120,8 @@ struct Bwd {
   size_t dgp_floats = 0;
   size_t dwp_floats;
   double *sums, *red;
+  int pend_rows = 0;   // rows of `red` holding the column sums of the last bn_relu_bwd (= the conv bias gradient), folded by the layer's
+                       // gradient unpack launch (conv_wgrad)
 };
 
 // weight gradient of a conv layer into flat[off_w]: Z = dz (dense, pitch Cout), A = gather of the layer's input
@@ -144,7 +146,10 @@ int conv_wgrad(Bwd& w, const Layer& L, const float* dz) {
                  alg, ww ? alg * 16.0 / 36.0 * (x3 ? 6.0 : 1.0) : alg, wgrad_thin_applicable(d) ? -1 : x3 ? 1 : 0);
     HIPCHK(c, launch_wgrad_f32(d, w.s));
   }
-  HIPCHK(c, launch_unpack_conv_grad(w.dwp, d.groups, (size_t)d.N * d.Kp, w.flat + L.off_w, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, w.s));
+  // ... and, in the same launch, the fold of the bias gradient's column sums that bn_relu_bwd left in the reduction slots
+  HIPCHK(c, launch_unpack_conv_grad(w.dwp, d.groups, (size_t)d.N * d.Kp, w.flat + L.off_w, L.Cout, L.Cin, L.Cp, L.KS, L.Kp, w.s, w.red,
+                                    w.pend_rows, L.Cout, w.flat + L.off_b));
+  w.pend_rows = 0;
   return MGU_OK;
 }
 
@@ -197,9 +202,10 @@ int bn_relu_bwd(Bwd& w, const Layer& L, const float* dy, int lddy, float* dz) {
   const int C = L.Cout;
   HIPCHK(c, launch_bn_bwd_reduce(dy, lddy, L.tscale, L.tshift, L.t_z, C, L.mean, L.invstd, M, C, w.red, w.sums,
                                  w.flat + L.off_beta, w.flat + L.off_gamma, w.s));
-  // dz and, fused, the conv bias gradient = column sum of dz (analytically ~0 under BatchNorm)
-  HIPCHK(c, launch_bn_bwd_apply(dy, lddy, L.tscale, L.tshift, L.t_z, L.mean, L.invstd, L.gamma, w.sums, M, C, dz, w.red,
-                                w.flat + L.off_b, w.s));
+  // dz and, fused, the column sums of dz (the conv bias gradient, analytically ~0 under BatchNorm): they stay in the reduction slots
+  // until conv_wgrad of the SAME layer -- always the next user of the slots -- folds them inside its unpack launch
+  HIPCHK(c, launch_bn_bwd_apply_deferred(dy, lddy, L.tscale, L.tshift, L.t_z, L.mean, L.invstd, L.gamma, w.sums, M, C, dz, w.red,
+                                         &w.pend_rows, w.s));
   return MGU_OK;
 }
 
@@ -390,11 +396,13 @@ static int backward_body(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_de
     HIPCHK(c, launch_wgrad_f32(g, s));
     HIPCHK(c, launch_unpack_conv_grad(w.dwp, g.groups, (size_t)g.N * g.Kp, w.flat + F.off_w, c->ncls, C0, C0, 1, F.Kp, s));
     const int Kpd = rup(ldd, 32);
-    HIPCHK(c, launch_pack_dgrad_w(F.w_src, w.dgp, c->ncls, C0, ldd, 1, Kpd, s));
+    // the panel of the data gradient: normally already packed with every other weight form by the last refresh (repack_weights)
+    const float* dpanel = F.wxg_valid ? F.wxg : w.dgp;
+    if (!F.wxg_valid) HIPCHK(c, launch_pack_dgrad_w(F.w_src, w.dgp, c->ncls, C0, ldd, 1, Kpd, s));
     IgemmDesc q;
     memset(&q, 0, sizeof q);
     q.tn = &c->tn;
-    q.in = dlog, q.w = w.dgp, q.out = tc, q.M = (int)M0, q.H = H, q.W = W, q.Cp = ldd, q.ldin = ldd, q.KS = 1, q.K = ldd,
+    q.in = dlog, q.w = dpanel, q.out = tc, q.M = (int)M0, q.H = H, q.W = W, q.Cp = ldd, q.ldin = ldd, q.KS = 1, q.K = ldd,
     q.Kp = Kpd, q.N = C0, q.ldout = C0;
     HIPCHK(c, launch_igemm_f32(q, s));
   }
@@ -430,9 +438,9 @@ static int backward_body(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_de
     q.in = dcat + C, q.w = w.dgp, q.out = tc, q.M = U.t_B * U.t_H * U.t_W, q.H = U.t_H, q.W = U.t_W, q.Cp = C, q.ldin = 2 * C;
     q.KS = 2, q.K = Kt, q.Kp = Kpt, q.N = U.Cin, q.ldout = U.Cin, q.Hout = hs[i], q.Wout = ws[i];
     // three-piece kernel of the forward layer in its gather mode (convt_x3.hip) where the shapes allow, else the generic tile kernel
-    q.wu = w.dgp;
-    if (c->tn.convt_dgrad_x3 && convt_x3_dgrad_applicable(q) && convt_x3_dgrad_floats(U.Cin, C) <= w.dgp_floats) {
-      HIPCHK(c, launch_pack_convt_x3_dgrad(U.w_src, w.dgp, U.Cin, C, s));
+    q.wu = U.wxg_valid ? U.wxg : w.dgp;
+    if (c->tn.convt_dgrad_x3 && convt_x3_dgrad_applicable(q) && (U.wxg_valid || convt_x3_dgrad_floats(U.Cin, C) <= w.dgp_floats)) {
+      if (!U.wxg_valid) HIPCHK(c, launch_pack_convt_x3_dgrad(U.w_src, w.dgp, U.Cin, C, s));   // else: packed by the last weight refresh
     } else {
       q.wu = nullptr;
       HIPCHK(c, launch_pack_convt_dgrad_w(U.w_src, w.dgp, U.Cin, C, Kpt, s));
@@ -467,6 +475,11 @@ static int backward_body(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_de
 
 static int backward_impl(mgu_ctx* c, const void* dlogits_dev, void* flat_grad_dev, void* hip_stream, int exchange) {
   const int rc = backward_body(c, dlogits_dev, flat_grad_dev, hip_stream, exchange);
+  if (rc != MGU_OK && c && c->redws) {
+    // an error return between a deferred column-sum pass and its fold would leave rows of the (otherwise self-cleaning) reduction
+    // slots non-zero for every later reduction: clear them
+    (void)hipMemsetAsync(c->redws, 0, c->redws_bytes, (hipStream_t)hip_stream);
+  }
   if (rc != MGU_OK && exchange && c && c->comm) {
     // an error return after some buckets were issued: the caller's stream must still be ordered behind the communicator
     // stream (the buckets read and write flat_grad_dev), or the caller could free / reuse the buffer under a running collective

@@ -3,6 +3,7 @@
 // softmax cross-entropy forward+backward, weight-panel packing for dgrad, gradient unpacking, Adam.
 // All tensors NHWC fp32 with an explicit pixel pitch (ld) so channel slices of the concat buffers work.
 #include "common.h"
+#include "pack_small.h"
 
 namespace mgu {
 
@@ -157,7 +158,7 @@ size_t chan_reduce_work_bytes(int Cmax) {
 static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const float* dy, int lddy, const float* fsc, const float* fsh,
                                      const float* mean, const float* invstd, const float* gamma, const double* sums,
                                      float* dz, int64_t M, int C, double* work, double* outd, float* outf0, int n0,
-                                     float* outf1, hipStream_t s) {
+                                     float* outf1, hipStream_t s, int* defer_rows = nullptr) {
   if ((C & 3) || C < 4 || C > 1024 || (ldz & 3) || M < 1) return hipErrorInvalidValue;
   int64_t blocks = (M + 63) / 64;   // `work` is zero on entry and on exit (slot_reduce_kernel cleans up)
   if (blocks > CHAN_REDUCE_ROWS) blocks = CHAN_REDUCE_ROWS;   // one row of the table per workgroup
@@ -173,6 +174,10 @@ static hipError_t launch_chan_reduce(int mode, const float* z, int ldz, const fl
   else MGU_CR(3);
 #undef MGU_CR
   const int n = (mode == 0 || mode == 1) ? 2 * C : C;
+  if (defer_rows) {   // the caller folds (and clears) the rows later, in a launch it makes anyway, before `work` is used again
+    *defer_rows = (int)blocks;
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(slot_reduce_kernel, dim3((n + 31) / 32), dim3(1024), 0, s, work, (int)blocks, n, 2 * C, outd, outf0, n0, outf1);
   return hipGetLastError();
 }
@@ -193,6 +198,13 @@ hipError_t launch_bn_bwd_apply(const float* dy, int lddy, const float* fsc, cons
                                const float* invstd, const float* gamma, const double* sums, int64_t M, int C, float* dz,
                                double* work, float* dbias, hipStream_t s) {
   return launch_chan_reduce(3, z, C, dy, lddy, fsc, fsh, mean, invstd, gamma, sums, dz, M, C, work, nullptr, dbias, C, nullptr, s);
+}
+// the same without the fold of the column sums: rows [0, *rows) of `work` (pitch 2C) hold them until launch_unpack_conv_grad(..., fold)
+// folds them into the bias gradient -- one launch less per layer of the backward pass
+hipError_t launch_bn_bwd_apply_deferred(const float* dy, int lddy, const float* fsc, const float* fsh, const float* z, const float* mean,
+                                        const float* invstd, const float* gamma, const double* sums, int64_t M, int C, float* dz,
+                                        double* work, int* rows, hipStream_t s) {
+  return launch_chan_reduce(3, z, C, dy, lddy, fsc, fsh, mean, invstd, gamma, sums, dz, M, C, work, nullptr, nullptr, C, nullptr, s, rows);
 }
 hipError_t launch_colsum(const float* z, int ldz, int64_t M, int C, double* work, float* out, hipStream_t s) {
   return launch_chan_reduce(2, z, ldz, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, work, nullptr,
@@ -480,14 +492,7 @@ hipError_t launch_ce(const float* logits, const int64_t* labels, int64_t M, int 
 // panel [Cin][Kp], k = tap'*Cop + co  (Cop = Cout rounded up to 4, zero padded)
 __global__ void pack_dgrad_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int Cop, int KS,
                                     int Kp) {
-  const int64_t total = (int64_t)Cin * Kp;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(i / Kp), k = (int)(i - (int64_t)ci * Kp);
-    const int tap = k / Cop, co = k - tap * Cop;
-    float v = 0.f;
-    if (tap < KS * KS && co < Cout) v = w[((int64_t)co * Cin + ci) * KS * KS + (KS * KS - 1 - tap)];
-    wp[i] = v;
-  }
+  pack_dgrad_w_body(w, wp, Cout, Cin, Cop, KS, Kp, blockIdx.x, gridDim.x);
 }
 hipError_t launch_pack_dgrad_w(const float* w, float* wp, int Cout, int Cin, int Cop, int KS, int Kp, hipStream_t s) {
   hipLaunchKernelGGL(pack_dgrad_w_kernel, dim3(nblk((int64_t)Cin * Kp, 256)), dim3(256), 0, s, w, wp, Cout, Cin, Cop, KS, Kp);
@@ -515,13 +520,49 @@ hipError_t launch_pack_convt_dgrad_w(const float* w, float* wp, int Cin, int Cou
 // version moved 128 bytes per instruction and ran at 2.7 TB/s), the 32 slice sums meet in LDS, and the OIHW destination of those
 // 32 x TAPS values is ONE contiguous run written in order (a thread per panel element wrote 4 bytes at a 36-byte stride: 56 us for
 // the 512 x 512 layer, whose reads take 10).
+// Workgroups past `ublocks` (fold.slots != nullptr) fold the deferred column sums of the layer's BatchNorm backward instead
+// (launch_bn_bwd_apply_deferred): 32 columns per workgroup, row lane rl adds rows rl, rl + 8, ... and clears them, the eight partial
+// sums meet in LDS in a fixed order.
+struct SlotFold {
+  double* slots;   // nullptr: nothing to fold
+  int nrows, n, pitch;
+  float* out;
+};
 template <int TAPS>
 __global__ __launch_bounds__(256) void unpack_conv_grad_kernel(const float* __restrict__ dwp, int groups, size_t panel_stride,
-                                                               float* __restrict__ g, int Cout, int Cin, int Cp, int Kp) {
-  __shared__ float part[32][TAPS][33];
+                                                               float* __restrict__ g, int Cout, int Cin, int Cp, int Kp, int ublocks,
+                                                               SlotFold fold) {
+  __shared__ __attribute__((aligned(16))) float part[32][TAPS][33];
+  if ((int)blockIdx.x >= ublocks) {   // block-uniform
+    double* fpart = reinterpret_cast<double*>(&part[0][0][0]);   // [8][33] doubles = 2112 bytes (part has >= 4224)
+    const int e = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int j = ((int)blockIdx.x - ublocks) * 32 + e;
+    double sacc = 0.0;
+    if (j < fold.n) {
+      double* col = fold.slots + j;
+      for (int k0 = rl; k0 < fold.nrows; k0 += 64) {   // eight independent loads in flight
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = k0 + 8 * u < fold.nrows ? col[(size_t)(k0 + 8 * u) * fold.pitch] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sacc += v[u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + 8 * u < fold.nrows) col[(size_t)(k0 + 8 * u) * fold.pitch] = 0.0;
+      }
+    }
+    fpart[rl * 33 + e] = sacc;
+    __syncthreads();
+    if (rl == 0 && j < fold.n) {
+#pragma unroll
+      for (int k = 1; k < 8; ++k) sacc += fpart[k * 33 + e];
+      fold.out[j] = (float)sacc;
+    }
+    return;
+  }
   const int cq = threadIdx.x & 7, sl = threadIdx.x >> 3;
   const int nchunk = (Cp + 31) / 32;
-  for (int item = blockIdx.x; item < Cout * nchunk; item += gridDim.x) {
+  for (int item = blockIdx.x; item < Cout * nchunk; item += ublocks) {
     const int co = item / nchunk, ci0 = (item - co * nchunk) * 32;
     const bool ok = ci0 + cq * 4 < Cp;   // Cp is a multiple of 4: a quad is whole or absent
     const float* p = dwp + (int64_t)co * Kp + (ok ? ci0 + cq * 4 : 0);
@@ -549,14 +590,20 @@ __global__ __launch_bounds__(256) void unpack_conv_grad_kernel(const float* __re
     __syncthreads();
   }
 }
+// fold_rows > 0: also folds rows [0, fold_rows) of the reduction slots (pitch 2 fold_n) into fold_out[0 .. fold_n) and clears them
 hipError_t launch_unpack_conv_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cout, int Cin, int Cp, int KS,
-                                   int Kp, hipStream_t s) {
+                                   int Kp, hipStream_t s, double* fold_slots, int fold_rows, int fold_n, float* fold_out) {
   int64_t blocks = (int64_t)Cout * ((Cp + 31) / 32);
   if (blocks > 65535) blocks = 65535;
+  SlotFold f{nullptr, 0, 0, 0, nullptr};
+  int fblocks = 0;
+  if (fold_slots && fold_rows > 0 && fold_n > 0) f = SlotFold{fold_slots, fold_rows, fold_n, 2 * fold_n, fold_out}, fblocks = (fold_n + 31) / 32;
   if (KS == 3)
-    hipLaunchKernelGGL(unpack_conv_grad_kernel<9>, dim3((unsigned)blocks), dim3(256), 0, s, dwp, groups, panel_stride, g, Cout, Cin, Cp, Kp);
+    hipLaunchKernelGGL(unpack_conv_grad_kernel<9>, dim3((unsigned)blocks + fblocks), dim3(256), 0, s, dwp, groups, panel_stride, g, Cout, Cin, Cp, Kp,
+                       (int)blocks, f);
   else
-    hipLaunchKernelGGL(unpack_conv_grad_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, dwp, groups, panel_stride, g, Cout, Cin, Cp, Kp);
+    hipLaunchKernelGGL(unpack_conv_grad_kernel<1>, dim3((unsigned)blocks + fblocks), dim3(256), 0, s, dwp, groups, panel_stride, g, Cout, Cin, Cp, Kp,
+                       (int)blocks, f);
   return hipGetLastError();
 }
 // convT: partial panels [groups][Cin][Kp], k = q*Cout + co  ->  (Cin, Cout, 2, 2), the panels added in a fixed order.

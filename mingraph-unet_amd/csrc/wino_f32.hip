@@ -25,6 +25,7 @@
 //   * inverse transform: each wave folds its own row (M[i][.] A) in registers, the four row waves meet through a
 //     small LDS exchange, and lanes store one channel each (32 lanes = one 128-byte line of a pixel).
 #include "common.h"
+#include "pack_small.h"
 #include "x3.h"
 #include <algorithm>
 #include <cstdlib>
@@ -228,8 +229,15 @@ __global__ void pack_wino_w_multi_kernel(const WinoPackBatch* __restrict__ bp) {
   int i = 0;
   while (i + 1 < b.n && blockIdx.x >= b.it[i + 1].blk0) ++i;   // <= 40 items: a linear scan of the block prefix
   const WinoPackItem& t = b.it[i];
-  const unsigned vgrid = (i + 1 < b.n ? b.it[i + 1].blk0 : b.total_blocks) - t.blk0;
-  pack_wino_w_body(t.w, t.U, t.Cout, t.Cin, t.Cp, t.Np, t.dgrad, b.prec, blockIdx.x - t.blk0, vgrid);
+  const unsigned vgrid = (i + 1 < b.n ? b.it[i + 1].blk0 : b.total_blocks) - t.blk0, vblock = blockIdx.x - t.blk0;
+  switch (t.kind) {   // block-uniform
+    case PACK_WINO: pack_wino_w_body(t.w, t.U, t.Cout, t.Cin, t.Cp, t.Np, t.dgrad, b.prec, vblock, vgrid); break;
+    case PACK_FIRST_W: pack_first_w_body(t.w, t.U, t.Cout, t.Cin, vblock, vgrid); break;
+    case PACK_CONVT_X3: pack_convt_x3_body(t.w, reinterpret_cast<uint16_t*>(t.U), t.Cin, t.Cout, t.dgrad, vblock, vgrid); break;
+    case PACK_BIAS_TILE: bias_tile_body(t.w, t.U, t.Cout, t.Cin, vblock, vgrid); break;
+    case PACK_DGRAD_W: pack_dgrad_w_body(t.w, t.U, t.Cout, t.Cin, t.Cp, t.dgrad, t.Np, vblock, vgrid); break;
+    default: break;
+  }
 }
 
 // n tiles padded to pairs; 6 bytes per value in the three-piece layout (sized for either)
@@ -240,10 +248,24 @@ bool wino_pack_batch_prepare(WinoPackBatch& b) {
   unsigned blk = 0;
   for (int i = 0; i < b.n; ++i) {
     WinoPackItem& t = b.it[i];
-    if (t.Cp & (b.prec ? 15 : 7)) return false;
-    t.Np = (t.Cout + 63) / 64 * 64;
     t.blk0 = blk;
-    blk += (unsigned)std::min<int64_t>(2048, ((int64_t)t.Np * t.Cp / (b.prec ? 8 : 1) + 255) / 256);
+    int64_t work;   // threads' worth of elements
+    switch (t.kind) {
+      case PACK_WINO:
+        if (t.Cp & (b.prec ? 15 : 7)) return false;
+        t.Np = (t.Cout + 63) / 64 * 64;
+        work = (int64_t)t.Np * t.Cp / (b.prec ? 8 : 1);
+        break;
+      case PACK_FIRST_W: work = 9 * 4 * (int64_t)t.Cout; break;
+      case PACK_CONVT_X3:
+        if ((t.Cin & 31) || (t.Cout & 31)) return false;
+        work = (int64_t)t.Cin * t.Cout * 4;
+        break;
+      case PACK_BIAS_TILE: work = (int64_t)t.Cout * t.Cin; break;
+      case PACK_DGRAD_W: work = (int64_t)t.Cin * t.Np; break;
+      default: return false;
+    }
+    blk += (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (work + 255) / 256));
   }
   b.total_blocks = blk;
   return true;
