@@ -20,6 +20,7 @@
 //     channel pitch/offset so encoder outputs and the pixel-shuffled ConvTranspose outputs land
 //     directly in the two halves of the decoder's concat buffer (torch.cat never materialises).
 #include "common.h"
+#include "x3.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -436,36 +437,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
 
   const int nchunks = d.Cp / CK;
   const int nitems = npatch * nchunks;
-  const int nsteps = nitems * SPI;
   setup_load(p_begin);
   load_halo(0);
   load_b(0, 0);
   store_halo();
   store_b(0);
-  load_b(0, 1);              // nsteps >= 3
-  int c = 0, tap = 0, pi = 0;   // chunk / step-in-item / patch of the step being computed
-  int c2 = 0, t2 = 2;           // chunk / step-in-item of step st + 2 (weights depend on (chunk, step) only)
+  load_b(0, 1);              // SPI >= 3
+  int c = 0, pi = 0;         // chunk / patch of the item being computed
+  int par = 0;               // weight buffer of the step being computed
+  [[maybe_unused]] int st = 0;
 #if defined(MGU_DIAG) && MGU_DIAG == 23
   const bool diag_on = blockIdx.x == 40 && blockIdx.y == 0 && d.H == MGU_DIAG_H && d.Cp == MGU_DIAG_CP && d.N == MGU_DIAG_N && sizeof(T) == 2;
 #endif
-  for (int st = 0; st < nsteps; ++st) {
-    HALO_T(0);
-    __syncthreads();  // Bs[st&1] (and a fresh halo when tap == 0) visible; Bs[(st+1)&1] no longer read
-    HALO_T(1);
-    if (st + 1 < nsteps) store_b((st + 1) & 1);
-    if (st + 2 < nsteps) load_b(c2, t2);
-    if (++t2 == SPI) {
-      t2 = 0;
-      if (++c2 == nchunks) c2 = 0;
-    }
-    if (tap == 0) {   // prefetch the halo of the next item
-      if (c + 1 < nchunks) {
-        load_halo(c + 1);
-      } else if (pi + 1 < npatch) {
-        setup_load(p_begin + pi + 1);
-        load_halo(0);
-      }
-    }
+  // The SPI steps of an item are unrolled (the tap is a compile-time constant) and EVERY step issues the same loads whatever the
+  // position in the walk (past the end: clamped re-reads that nobody uses): with a runtime tap and conditional loads hipcc merged the
+  // pending-load states of the paths into `s_waitcnt vmcnt(0)` at every step, and -- vmcnt retiring in order -- each weight tile's wait
+  // was a wait for the HBM halo loads issued one step earlier (a timing build without them: -13 % on the bf16 forward).  Order
+  // inside a step: MFMAs, then the next step's weight tile goes to LDS (requested one step ago), then the tile after it is
+  // requested, then (step 0) the halo of the next item: the halo loads are behind the weight loads in the queue, so the first wait
+  // that covers them is the one at the bottom of step 2.
+  for (int item = 0; item < nitems; ++item) {
+    const int cnext = c + 1 == nchunks ? 0 : c + 1;   // chunk of the next item
+    x3_static_for<0, SPI>([&](auto tap_c) {
+      constexpr int tap = decltype(tap_c)::value;
+      HALO_T(0);
+      __syncthreads();  // Bs[par] (and a fresh halo when tap == 0) visible; Bs[par ^ 1] no longer read
+      HALO_T(1);
     // operand fetches are software-pipelined one (tap, kk) group ahead of the MFMAs that consume them, so the
     // ~100-cycle ds_read latency hides under the previous group's MFMAs instead of being exposed 4x per tap
     {
@@ -477,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
         const int tp = tap * TPS + tt;            // 3x3 tap index
         const int r = tp / 3, s = tp - 3 * r;
         const T* Ap = Hs + (r * HWID + s) * LDS_LD + kk * 2 * VEC;
-        const T* Bp = Bs + ((st & 1) * TPS + tt) * BN * LDS_LD + boff + kk * 2 * VEC;
+        const T* Bp = Bs + (par * TPS + tt) * BN * LDS_LD + boff + kk * 2 * VEC;
 #pragma unroll
         for (int mi = 0; mi < WMT; ++mi) a[slot][mi] = *reinterpret_cast<const f32x4*>(Ap + aoff[mi]);
 #pragma unroll
@@ -493,9 +490,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
           for (int ni = 0; ni < WNT; ++ni) acc[mi][ni] = mma_chunk<T>(a[gidx & 1][mi], b[gidx & 1][ni], acc[mi][ni]);
       }
     }
-    HALO_T(2);   // MFMAs of the step issued
-    if (++tap == SPI) {
-      tap = 0;
+      HALO_T(2);   // MFMAs of the step issued
+      store_b(par ^ 1);                         // the next step's weight tile (its buffer is free since the barrier above)
+      if constexpr (tap + 2 < SPI) load_b(c, tap + 2);   // the tile of the step after it: (chunk, step) two steps ahead
+      else load_b(cnext, tap + 2 - SPI);
+      if constexpr (tap == 0) {                 // halo of the next item: next chunk, or chunk 0 of the next patch (last item: a re-read)
+        if (cnext == 0 && pi + 1 < npatch) setup_load(p_begin + pi + 1);
+        load_halo(cnext);
+      }
+      par ^= 1;
+      ++st;
+      HALO_T(3);
+    });
+    {
       const bool patch_done = (c + 1 == nchunks);
       const bool more = patch_done ? (pi + 1 < npatch) : true;
       if (more) {

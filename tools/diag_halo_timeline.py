@@ -41,3 +41,14 @@ print(f"  barrier -> MFMAs issued  {(t[:, :, 2] - t[:, :, 1]).mean():7.0f}  per 
 print(f"  tail of the step    mean {(t[:, :, 3] - t[:, :, 2]).mean():7.0f}")
 long = np.argsort(-per[0])[:8]
 print("  longest steps (wave 0):", [(int(i), int(per[0, i])) for i in sorted(long)])
+# per tap of an item (9 steps per 64-channel chunk): where the waits land
+nt = 9
+m = (n // nt) * nt
+if m >= 2 * nt:
+    tt = t[:, nt:m, :].reshape(4, -1, nt, 4)   # skip the first item (cold)
+    bw = (tt[..., 1] - tt[..., 0]).mean(axis=(0, 1))
+    mf = (tt[..., 2] - tt[..., 1]).mean(axis=(0, 1))
+    tl = (tt[..., 3] - tt[..., 2]).mean(axis=(0, 1))
+    print("  per tap: barrier wait   ", np.round(bw).astype(int).tolist())
+    print("           barrier->MFMAs ", np.round(mf).astype(int).tolist())
+    print("           tail           ", np.round(tl).astype(int).tolist())
