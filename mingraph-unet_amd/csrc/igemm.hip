@@ -365,8 +365,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
   const unsigned img_bytes = (unsigned)((size_t)d.H * d.W * d.ldin * sizeof(T));
   // x fastest by default; y fastest (MGU_WINO_YFAST=1, as in wino3x3_cp_kernel) measured neutral (+-0.5 %) in the bf16 mode
   auto setup_patch = [&](int p, int& img, int& y0, int& x0) {
-    const int ty = yfast ? p % tiles_y : (p / tiles_x) % tiles_y;
-    const int tx = yfast ? (p / tiles_y) % tiles_x : p % tiles_x;
+    const int ty = (yfast & 1) ? p % tiles_y : (p / tiles_x) % tiles_y;
+    const int tx = (yfast & 1) ? (p / tiles_y) % tiles_x : p % tiles_x;
     img = p / (tiles_x * tiles_y);
     y0 = ty * TH;
     x0 = tx * TW;
@@ -468,7 +468,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
     {
       constexpr int NKK = NP / 2;               // 32-byte k groups per chunk
       constexpr int NG = TPS * NKK;
-      f32x4 a[2][WMT], b[2][WNT];
+      // every operand of the step requested up front when the step is four k groups (one tap of a 64-channel chunk; 64 fragment
+      // registers), else a ring of two: alone on its SIMD a wave took 930 cycles for the 512 of a step's 16 MFMAs with a one-group lead
+      // (timeline of a one-workgroup-per-CU run) -- an LDS round trip per group
+      constexpr int DEPTH = NG >= 3 ? 3 : 2;
+      f32x4 a[DEPTH][WMT], b[DEPTH][WNT];
       auto fetch = [&](int gidx, int slot) {
         const int tt = gidx / NKK, kk = gidx % NKK;
         const int tp = tap * TPS + tt;            // 3x3 tap index
@@ -480,14 +484,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
 #pragma unroll
         for (int ni = 0; ni < WNT; ++ni) b[slot][ni] = *reinterpret_cast<const f32x4*>(Bp + ni * 32 * LDS_LD);
       };
-      fetch(0, 0);
+#pragma unroll
+      for (int gidx = 0; gidx < DEPTH - 1; ++gidx) fetch(gidx, gidx);
+      __builtin_amdgcn_sched_barrier(0);   // (hipcc sinks the reads back in front of their MFMAs otherwise: fewer live registers)
 #pragma unroll
       for (int gidx = 0; gidx < NG; ++gidx) {
-        if (gidx + 1 < NG) fetch(gidx + 1, (gidx + 1) & 1);
+        if (gidx + DEPTH - 1 < NG) {
+          fetch(gidx + DEPTH - 1, (gidx + DEPTH - 1) % DEPTH);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int mi = 0; mi < WMT; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < WNT; ++ni) acc[mi][ni] = mma_chunk<T>(a[gidx & 1][mi], b[gidx & 1][ni], acc[mi][ni]);
+          for (int ni = 0; ni < WNT; ++ni) acc[mi][ni] = mma_chunk<T>(a[gidx % DEPTH][mi], b[gidx % DEPTH][ni], acc[mi][ni]);
       }
     }
       HALO_T(2);   // MFMAs of the step issued
@@ -499,8 +508,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
         load_halo(cnext);
       }
       par ^= 1;
-      ++st;
       HALO_T(3);
+      ++st;
     });
     {
       const bool patch_done = (c + 1 == nchunks);
@@ -600,7 +609,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
         ++c;
       }
     }
-    HALO_T(3);
   }
 }
 
@@ -616,7 +624,10 @@ static hipError_t launch_halo(const IgemmDesc& d, hipStream_t s) {
   if (ppb < 1) ppb = 1;
   if (ppb > tun(d).halo_max_ppb) ppb = std::max(1, tun(d).halo_max_ppb);
   dim3 grid((total + ppb - 1) / ppb, ntn);
-  const size_t lds = (size_t)(HP + 2 * TPS * BN) * (NP * 16 + 16);
+  size_t lds = (size_t)(HP + 2 * TPS * BN) * (NP * 16 + 16);
+#if defined(MGU_DIAG) && MGU_DIAG == 23
+  if (getenv("MGU_DIAG_OCC1")) lds = std::max<size_t>(lds, 100 * 1024);   // timing experiment: one workgroup per CU
+#endif
   static bool attr_done[64] = {};
   hipError_t ae = ensure_dyn_lds(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, NP, TH, WAVES_M, WAVES_N, WMT, WNT, TPS>), lds, attr_done);
   if (ae != hipSuccess) return ae;
