@@ -364,16 +364,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
   auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in_t), 0, 0x7ffffff0, 0x00020000);
   const unsigned img_bytes = (unsigned)((size_t)d.H * d.W * d.ldin * sizeof(T));
   // x fastest by default; y fastest (MGU_WINO_YFAST=1, as in wino3x3_cp_kernel) measured neutral (+-0.5 %) in the bf16 mode
-  auto setup_patch = [&](int p, int& img, int& y0, int& x0) {
-    const int ty = (yfast & 1) ? p % tiles_y : (p / tiles_x) % tiles_y;
-    const int tx = (yfast & 1) ? (p / tiles_y) % tiles_x : p % tiles_x;
-    img = p / (tiles_x * tiles_y);
-    y0 = ty * TH;
-    x0 = tx * TW;
+  struct PatchPos { int img, y0, x0; };
+  auto setup_patch = [&](int p) {   // (by value: out-parameters through the nested closures of the item loop ended up in scratch)
+    const int ty = yfast ? p % tiles_y : (p / tiles_x) % tiles_y;
+    const int tx = yfast ? (p / tiles_y) % tiles_x : p % tiles_x;
+    return PatchPos{p / (tiles_x * tiles_y), ty * TH, tx * TW};
   };
   auto setup_load = [&](int p) {
-    int img, y0, x0;
-    setup_patch(p, img, y0, x0);
+    const PatchPos pp = setup_patch(p);
+    const int img = pp.img, y0 = pp.y0, x0 = pp.x0;
     in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in_t) + (size_t)img * d.H * d.W * d.ldin, 0, img_bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
@@ -388,17 +387,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
 #pragma unroll
   for (int i = 0; i < BR; ++i) wrow[i] = w_t + (size_t)(bn0 + r0 + RPP * i) * d.Kp + kq * VEC;   // panel rows padded to 128
 
-  f32x4 hreg[HR];
+  // DEEPH (the 32-channel-chunk tiles: the full-resolution layers, one or two items per patch): the halo is requested TWO items ahead
+  // into a second register set.  An item of those tiles is three short steps, less than an HBM round trip under load, and the
+  // layers ran at 3.2 TB/s with neither pipe busy (the wino3x3_cp_kernel DEEP case).  The 64-channel tiles have no registers for it.
+  constexpr bool DEEPH = NP == 4 && HR <= 6;
+  constexpr int NSETH = DEEPH ? 2 : 1;
+  f32x4 hreg[NSETH][HR];
   f32x4 breg[TPS][BR];
-  auto load_halo = [&](int c) {
+  auto load_halo = [&](int c, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
 #pragma unroll
     for (int i = 0; i < HR; ++i)
-      hreg[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, hoff[i], c * CK * (int)sizeof(T), 0));
+      hreg[set][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, hoff[i], c * CK * (int)sizeof(T), 0));
   };
-  auto store_halo = [&]() {
+  auto store_halo = [&](auto set_c) {
+    constexpr int set = decltype(set_c)::value;
 #pragma unroll
     for (int i = 0; i < HR; ++i)
-      if (r0 + RPP * i < HP) *reinterpret_cast<f32x4*>(Hs + (r0 + RPP * i) * LDS_LD + kq * VEC) = hreg[i];
+      if (r0 + RPP * i < HP) *reinterpret_cast<f32x4*>(Hs + (r0 + RPP * i) * LDS_LD + kq * VEC) = hreg[set][i];
   };
   auto load_b = [&](int c, int stp) {   // the TPS weight tiles of step `stp` of chunk c
 #pragma unroll
@@ -437,12 +443,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
 
   const int nchunks = d.Cp / CK;
   const int nitems = npatch * nchunks;
-  setup_load(p_begin);
-  load_halo(0);
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, DEEPH ? 1 : 0>;
+  // loader position: (patch, chunk) of the next item whose halo is requested; past the last item the last one is requested again
+  int li = 0;
+  auto load_next_halo = [&](auto set_c) {
+    const int lic = min(li, nitems - 1);
+    const int lp = lic / nchunks, lc = lic - lp * nchunks;
+    if (lc == 0 && li < nitems) setup_load(p_begin + lp);   // a new patch (address arithmetic only; a clamped repeat keeps hoff)
+    load_halo(lc, set_c);
+    ++li;
+  };
+  load_next_halo(Set0{});
   load_b(0, 0);
-  store_halo();
+  store_halo(Set0{});
   store_b(0);
   load_b(0, 1);              // SPI >= 3
+  if constexpr (DEEPH) load_next_halo(Set1{});   // item 1 -> set 1
   int c = 0, pi = 0;         // chunk / patch of the item being computed
   int par = 0;               // weight buffer of the step being computed
   [[maybe_unused]] int st = 0;
@@ -454,9 +471,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
   // pending-load states of the paths into `s_waitcnt vmcnt(0)` at every step, and -- vmcnt retiring in order -- each weight tile's wait
   // was a wait for the HBM halo loads issued one step earlier (a timing build without them: -13 % on the bf16 forward).  Order
   // inside a step: MFMAs, then the next step's weight tile goes to LDS (requested one step ago), then the tile after it is
-  // requested, then (step 0) the halo of the next item: the halo loads are behind the weight loads in the queue, so the first wait
-  // that covers them is the one at the bottom of step 2.
-  for (int item = 0; item < nitems; ++item) {
+  // requested, then (step 0) the halo of the next item (DEEPH: of the item after it, into the set of this item's parity): the halo
+  // loads are behind the weight loads in the queue, so the first wait that covers them is the one at the bottom of step 2.
+  auto do_item = [&](auto par_c) {
+    using SetLoad = std::integral_constant<int, DEEPH ? decltype(par_c)::value : 0>;        // receives item + 2 (item + 1)
+    using SetStore = std::integral_constant<int, DEEPH ? (decltype(par_c)::value ^ 1) : 0>;  // holds item + 1
     const int cnext = c + 1 == nchunks ? 0 : c + 1;   // chunk of the next item
     x3_static_for<0, SPI>([&](auto tap_c) {
       constexpr int tap = decltype(tap_c)::value;
@@ -468,10 +487,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
     {
       constexpr int NKK = NP / 2;               // 32-byte k groups per chunk
       constexpr int NG = TPS * NKK;
-      // every operand of the step requested up front when the step is four k groups (one tap of a 64-channel chunk; 64 fragment
-      // registers), else a ring of two: alone on its SIMD a wave took 930 cycles for the 512 of a step's 16 MFMAs with a one-group lead
-      // (timeline of a one-workgroup-per-CU run) -- an LDS round trip per group
-      constexpr int DEPTH = NG >= 3 ? 3 : 2;
+      // the operands are requested two k groups ahead (a ring of three fragment sets) where the registers allow: alone on its SIMD a
+      // wave took 930 cycles for the 512 of a step's 16 MFMAs with a one-group lead (timeline of a one-workgroup-per-CU run) -- an
+      // LDS round trip per group.  (All four groups up front: 255 registers + spills.)
+      constexpr int DEPTH = (NG >= 3 && HR * NSETH <= 12) ? 3 : 2;   // (the 16 x 16 pixel tiles with 64-channel chunks hold 11 halo registers x 4: no room)
       f32x4 a[DEPTH][WMT], b[DEPTH][WNT];
       auto fetch = [&](int gidx, int slot) {
         const int tt = gidx / NKK, kk = gidx % NKK;
@@ -503,10 +522,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
       store_b(par ^ 1);                         // the next step's weight tile (its buffer is free since the barrier above)
       if constexpr (tap + 2 < SPI) load_b(c, tap + 2);   // the tile of the step after it: (chunk, step) two steps ahead
       else load_b(cnext, tap + 2 - SPI);
-      if constexpr (tap == 0) {                 // halo of the next item: next chunk, or chunk 0 of the next patch (last item: a re-read)
-        if (cnext == 0 && pi + 1 < npatch) setup_load(p_begin + pi + 1);
-        load_halo(cnext);
-      }
+      if constexpr (tap == 0) load_next_halo(SetLoad{});
       par ^= 1;
       HALO_T(3);
       ++st;
@@ -516,12 +532,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
       const bool more = patch_done ? (pi + 1 < npatch) : true;
       if (more) {
         __syncthreads();  // every wave is done with the old halo
-        store_halo();     // visible after the barrier at the top of the next step
+        store_halo(SetStore{});     // visible after the barrier at the top of the next step
       }
       if (patch_done) {
         // ---- epilogue of patch pi (its stores overlap the next patch's halo, already in LDS/flight) ----
-        int img, y0, x0;
-        setup_patch(p_begin + pi, img, y0, x0);
+        const PatchPos pp = setup_patch(p_begin + pi);
+        const int img = pp.img, y0 = pp.y0, x0 = pp.x0;
         // uniform 64-bit image base + 32-bit element index; per element only one add (row/col constants fold
         // into scalar multiples of W*ldout and ldout), bounds tests only on patches that cross the image edge
         T* const img_out = reinterpret_cast<T*>(d.out) + (size_t)img * d.H * d.W * d.ldout + d.coff;
@@ -603,11 +619,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
         if (interior) store_patch(std::false_type{});
         else store_patch(std::true_type{});
 #endif
-        c = 0;
-        ++pi;
-      } else {
-        ++c;
       }
+      // (plain arithmetic: `if (done) { c = 0; ++pi; } else ++c;` became an increment through a selected ADDRESS, with c and pi in scratch)
+      pi += patch_done ? 1 : 0;
+      c = patch_done ? 0 : c + 1;
+    }
+  };
+  for (int item = 0; item < nitems; item += NSETH) {
+    do_item(Set0{});
+    if constexpr (DEEPH) {
+      if (item + 1 < nitems) do_item(Set1{});
     }
   }
 }

@@ -42,7 +42,7 @@ print(f"  tail of the step    mean {(t[:, :, 3] - t[:, :, 2]).mean():7.0f}")
 long = np.argsort(-per[0])[:8]
 print("  longest steps (wave 0):", [(int(i), int(per[0, i])) for i in sorted(long)])
 # per tap of an item (9 steps per 64-channel chunk): where the waits land
-nt = 9
+nt = int(os.environ.get('NT', '9'))   # steps per item: 9 (one tap per step) or 3 (the N <= 32 tile: three taps per step)
 m = (n // nt) * nt
 if m >= 2 * nt:
     tt = t[:, nt:m, :].reshape(4, -1, nt, 4)   # skip the first item (cold)
