@@ -18,6 +18,7 @@ namespace mgu {
 // Kernel-selection switches of ONE context (mgu_ctx::tn, filled from the MGU_* environment in mgu_create).  They ride in
 // the launch descriptors, so two contexts of a process never see each other's settings.
 struct Tuning {
+  bool first_mfma = true;   // MGU_NO_FIRST_MFMA=1: the first convolution on the VALU kernel (conv3x3_first_kernel) instead of the matrix cores (A/B)
   bool use_halo = true;     // MGU_NO_HALO=1: generic gather kernel instead of the LDS-halo conv kernel (A/B)
   bool halo_tps3 = true;    // MGU_HALO_TPS1=1: one tap per barrier on the N <= 32 halo tile too (A/B)
   int halo_max_ppb = 16;    // MGU_HALO_PPB=n: patches a halo workgroup walks (1 = no persistence)
@@ -100,6 +101,15 @@ hipError_t launch_convt_x3_dgrad(const IgemmDesc& d, hipStream_t s);
   // the kernel family launch_igemm_* will pick (profiling records)  // in / w / out point to bf16, sizes in elements
 // elementwise.hip: first convolution (<= 4 input channels on the packed NHWC4 input), VALU + scalar-cache weights
 hipError_t launch_pack_first_w(const float* w, float* wf, int Cout, int Cin, hipStream_t s);
+// first_mfma.hip: the same layer on the bf16 matrix cores (Cin <= 3, Cout == 32)
+size_t first_mfma_floats();
+bool first_mfma_applicable(int dtype, int Cin, int Cp, int Cout, int ldout, int coff, int64_t H, int64_t W);
+hipError_t launch_pack_first_mfma(const float* w, float* wfm, int Cout, int Cin, hipStream_t s);
+hipError_t launch_first_mfma(int dtype, const void* in, const float* wfm, const float* scale, const float* shift, void* out, int B, int H,
+                             int W, int ldout, int coff, int relu, hipStream_t s);
+hipError_t launch_first_mfma_direct(int dtype, const float* x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, int cin, const float* wfm,
+                                    const float* scale, const float* shift, void* out, int B, int H, int W, int ldout, int coff, int relu,
+                                    hipStream_t s);
 bool first_conv_applicable(int dtype, int Cin, int Cp, int Cout, int ldout, int coff);
 hipError_t launch_first_conv(int dtype, const void* in, const float* wf, const float* scale, const float* shift, void* out, int B, int H, int W,
                              int Cin, int Cout, int ldout, int coff, int relu, hipStream_t s);
@@ -110,7 +120,7 @@ hipError_t launch_pack_wino_w(const float* w, float* U, int Cout, int Cin, int C
 // kind 0: a Winograd set.  The small per-layer forms ride in the same launch (pack_small.h): kind 1 = first-conv weights (w, U = wf,
 // Cout, Cin); 2 = three-piece ConvTranspose fragments (w, U = Wx, Cin, Cout, dgrad = forward / data gradient); 3 = bias tile (w = bias,
 // U = shift, Cout = C, Cin = reps); 4 = direct data-gradient panel (w, U = wp, Cout, Cin, Cp = Cop, Np = Kp, dgrad = KS)
-enum { PACK_WINO = 0, PACK_FIRST_W = 1, PACK_CONVT_X3 = 2, PACK_BIAS_TILE = 3, PACK_DGRAD_W = 4 };
+enum { PACK_WINO = 0, PACK_FIRST_W = 1, PACK_CONVT_X3 = 2, PACK_BIAS_TILE = 3, PACK_DGRAD_W = 4, PACK_FIRST_MFMA = 5 };   // 5: (w, U = wfm, Cout, Cin)
 struct WinoPackItem {
   const float* w;
   float* U;

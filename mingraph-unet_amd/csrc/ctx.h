@@ -28,6 +28,7 @@ struct Layer {
   float* wug = nullptr;          // Winograd weights of the layer's DATA-GRADIENT convolution (training; same launch as wu)
   mutable bool wug_valid = false;   // wug holds the current weights
   float* wf = nullptr;   // first conv (Cp == 4): [9][4][Cout] weights for conv3x3_first_kernel
+  float* wfm = nullptr;  // the same layer's three-piece fragment weights for conv3x3_first_mfma_kernel (Cin <= 3, Cout == 32)
   float* wxg = nullptr;  // data-gradient weights kept across the step (training; packed with everything else by the weight refresh):
                          // three-piece fragments of a ConvTranspose (convt_x3.hip) or the direct panel of the final 1x1 conv
   mutable bool wxg_valid = false;

@@ -65,6 +65,7 @@ int mgu_create(int device_id, mgu_ctx** out) {
   auto flag = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
   auto num = [](const char* name, int dflt) { const char* v = getenv(name); return v && v[0] ? atoi(v) : dflt; };
   Tuning& t = c->tn;
+  t.first_mfma = !flag("MGU_NO_FIRST_MFMA");
   t.use_halo = !flag("MGU_NO_HALO");
   t.halo_tps3 = !flag("MGU_HALO_TPS1");
   t.halo_max_ppb = std::max(1, num("MGU_HALO_PPB", t.halo_max_ppb));
@@ -189,7 +190,7 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     if (L.ctx3) total += convt_x3_floats(L.Cin, L.Cout) + convt_x3_dgrad_floats(L.Cin, L.Cout);
     if (dtype == MGU_DTYPE_F32 && !L.convt && L.bn.empty()) total += (size_t)rup(L.Cin, 128) * rup(L.KS * L.KS * rup(L.Cout, 4), 32);   // final conv: data-gradient panel
     L.first = !L.convt && L.KS == 3 && first_conv_applicable(dtype, L.Cin, L.Cp, L.Cout, 8, 0);
-    if (L.first) total += 9 * 4 * (size_t)L.Cout;
+    if (L.first) total += 9 * 4 * (size_t)L.Cout + first_mfma_floats();
   }
   // flat parameter order = the reference's named_parameters(): per ConvBlock conv1.{w,b}, conv2.{w,b},
   // bn1.{w,b}, bn2.{w,b} (unet_encoder.py:7-13); decoder block: upsample.{w,b} then its conv_block; final.
@@ -241,6 +242,8 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     if (c->dtype == MGU_DTYPE_F32 && !L.convt && L.bn.empty()) L.wxg = p, p += (size_t)rup(L.Cin, 128) * rup(L.KS * L.KS * rup(L.Cout, 4), 32);
     L.wf = nullptr;
     if (L.first) L.wf = p, p += 9 * 4 * (size_t)L.Cout;
+    L.wfm = nullptr;
+    if (L.first) L.wfm = p, p += first_mfma_floats();
     if (!L.bn.empty()) {
       L.mean = p, p += L.Np;
       L.invstd = p, p += L.Np;
@@ -381,6 +384,7 @@ int mgud::repack_weights(mgu_ctx* c, hipStream_t s) {
         L.wp_dirty = false;
       }
       if (L.wf) items.push_back(WinoPackItem{w, L.wf, L.Cout, L.Cin, 0, 0, 0, 0, PACK_FIRST_W});
+      if (L.wfm && L.Cout == 32 && L.Cin <= 3) items.push_back(WinoPackItem{w, L.wfm, L.Cout, L.Cin, 0, 0, 0, 0, PACK_FIRST_MFMA});
       if (!L.bn.empty()) c->fold_dirty = true;   // eval scale/shift are folded lazily by the next eval forward (training never reads them)
       else items.push_back(WinoPackItem{b, L.shift, L.Cout, 1, 0, 0, 0, 0, PACK_BIAS_TILE});
       if (L.bn.empty() && L.wxg && c->want_train) {   // final conv: panel of its data gradient (mgu_unet_backward)
@@ -448,6 +452,12 @@ int mgud::run_layer(mgu_ctx* c, const Layer& L, const void* in_v, int ldin, int 
   d.Wout = Wout;
   if (pool_fused) *pool_fused = false;
   if (stat_fused) *stat_fused = false;
+  if (L.wfm && c->tn.first_mfma && ldin == L.Cp && first_mfma_applicable(c->dtype, L.Cin, L.Cp, L.Cout, ldout, coff, H, W)) {
+    const double alg = 2.0 * d.M * 9.0 * L.Cin * L.Cout;
+    ProfScope ps(c, s, "conv3x3_first_mfma_kernel", alg, 2.0 * d.M * 32.0 * 32.0 * (c->dtype == MGU_DTYPE_F32 ? 6.0 : 3.0), 1);
+    HIPCHK(c, launch_first_mfma(c->dtype, in_v, L.wfm, scale, shift, out_v, B, H, W, ldout, coff, relu, s));
+    return MGU_OK;
+  }
   if (L.wf && ldin == L.Cp && first_conv_applicable(c->dtype, L.Cin, L.Cp, L.Cout, ldout, coff) &&
       (int64_t)B * H * W * std::max(ldout, 8) < (1ll << 31)) {
     ProfScope ps(c, s, "conv3x3_first_kernel", 2.0 * d.M * 9.0 * L.Cin * L.Cout, 0, -1);
@@ -551,14 +561,25 @@ int mgu_unet_forward(mgu_ctx* c, const void* x_dev, int B, int H, int W, int64_t
     if (2 * hs[i + 1] != hs[i] || 2 * wsz[i + 1] != wsz[i])
       HIPCHK(c, hipMemsetAsync(cat_dev[i], 0, (size_t)B * hs[i] * wsz[i] * 2 * ((size_t)c->feat << i) * es, s));
 
-  HIPCHK(c, launch_pack_input((const float*)x_dev, xin, c->dtype, B, c->in_ch, c->Cp0, H, W, xs_n, xs_c, xs_h, xs_w, s));
+  // the first convolution on the matrix cores reads the caller's image itself (first_mfma.hip): no packed copy of the input
+  const Layer& L0 = c->layers[0];
+  const bool first_direct = L0.wfm && c->tn.first_mfma && first_mfma_applicable(c->dtype, L0.Cin, L0.Cp, L0.Cout, c->feat, 0, H, W) &&
+                            (int64_t)B * H * W < (1ll << 31);
+  if (!first_direct) HIPCHK(c, launch_pack_input((const float*)x_dev, xin, c->dtype, B, c->in_ch, c->Cp0, H, W, xs_n, xs_c, xs_h, xs_w, s));
 
   int li = 0;
   const void* cur = xin;
   int cur_ld = c->Cp0;
   for (int i = 0; i < depth; ++i) {  // encoder, unet_encoder.py:67-70
     const int C = c->feat << i;
-    if ((rc = run_conv(c, c->layers[li++], cur, cur_ld, B, hs[i], wsz[i], tmp, C, 0, 1, 0, 0, s))) return rc;
+    if (i == 0 && first_direct) {
+      if (c->fold_dirty) return fail(c, MGU_ERR_STATE, "internal: eval scale/shift not folded");
+      const double alg = 2.0 * B * H * W * 9.0 * L0.Cin * L0.Cout;
+      ProfScope ps(c, s, "conv3x3_first_mfma_kernel", alg, 2.0 * B * H * W * 32.0 * 32.0 * (c->dtype == MGU_DTYPE_F32 ? 6.0 : 3.0), 1);
+      HIPCHK(c, launch_first_mfma_direct(c->dtype, (const float*)x_dev, xs_n, xs_c, xs_h, xs_w, c->in_ch, L0.wfm, L0.bn.empty() ? nullptr : L0.scale,
+                                         L0.shift, tmp, B, H, W, C, 0, 1, s));
+      ++li;
+    } else if ((rc = run_conv(c, c->layers[li++], cur, cur_ld, B, hs[i], wsz[i], tmp, C, 0, 1, 0, 0, s))) return rc;
     void* pooled = ws + plan.pooled[i];
     bool fused = false;   // MaxPool2d(2) (unet_encoder.py:48) rides in the conv2 epilogue on the Winograd path
     if ((rc = run_conv(c, c->layers[li++], tmp, C, B, hs[i], wsz[i], cat_dev[i], 2 * C, 0, 1, 0, 0, s, pooled, C, &fused))) return rc;

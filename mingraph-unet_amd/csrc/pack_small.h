@@ -49,6 +49,28 @@ __device__ __forceinline__ void pack_convt_x3_body(const float* __restrict__ w, 
   }
 }
 
+// Three-piece weights of conv3x3_first_mfma_kernel (first_mfma.hip) in fragment order: [k step s][piece][lane][8] bf16 bit patterns;
+// lane = 32 h + cout, element e of k step s = slot j = 8 s + e of half h = (tap 5 h + j / 3, channel j % 3); slots without a value
+// (j = 15, taps > 8, channels >= Cin) are zero.  w is OIHW (32, Cin, 3, 3).
+__device__ __forceinline__ void pack_first_mfma_body(const float* __restrict__ w, uint16_t* __restrict__ wfm, int Cout, int Cin, unsigned vblock,
+                                                     unsigned vgrid) {
+  for (int i = (int)(vblock * blockDim.x + threadIdx.x); i < 2 * 64 * 8; i += (int)(vgrid * blockDim.x)) {
+    const int e = i & 7, lane = (i >> 3) & 63, s = i >> 9;
+    const int co = lane & 31, h = lane >> 5, j = 8 * s + e;
+    const int tap = 5 * h + j / 3, ch = j % 3;
+    float x = 0.f;
+    if (j < 15 && tap < 9 && ch < Cin && co < Cout) x = w[((int64_t)co * Cin + ch) * 9 + tap];
+    const unsigned b0 = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(b0);            // exact
+    const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(b1);           // exact; 8 significant bits are left
+    uint16_t* dst = wfm + ((size_t)(s * 3) * 64 + lane) * 8 + e;
+    dst[0] = (uint16_t)(b0 >> 16);
+    dst[512] = (uint16_t)(b1 >> 16);
+    dst[1024] = (uint16_t)(__float_as_uint(r2) >> 16);
+  }
+}
+
 // data-gradient panel of a conv3x3 / 1x1 (train_kernels.hip): din = conv(dz, W') with W'[ci][(2-r,2-s), co] = W[co][ci][r][s]:
 // panel [Cin][Kp], k = tap' * Cop + co  (Cop = Cout rounded up to 4, zero padded)
 __device__ __forceinline__ void pack_dgrad_w_body(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int Cop, int KS, int Kp,

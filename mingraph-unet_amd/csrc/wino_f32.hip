@@ -236,6 +236,7 @@ __global__ void pack_wino_w_multi_kernel(const WinoPackBatch* __restrict__ bp) {
     case PACK_CONVT_X3: pack_convt_x3_body(t.w, reinterpret_cast<uint16_t*>(t.U), t.Cin, t.Cout, t.dgrad, vblock, vgrid); break;
     case PACK_BIAS_TILE: bias_tile_body(t.w, t.U, t.Cout, t.Cin, vblock, vgrid); break;
     case PACK_DGRAD_W: pack_dgrad_w_body(t.w, t.U, t.Cout, t.Cin, t.Cp, t.dgrad, t.Np, vblock, vgrid); break;
+    case PACK_FIRST_MFMA: pack_first_mfma_body(t.w, reinterpret_cast<uint16_t*>(t.U), t.Cout, t.Cin, vblock, vgrid); break;
     default: break;
   }
 }
@@ -263,6 +264,7 @@ bool wino_pack_batch_prepare(WinoPackBatch& b) {
         break;
       case PACK_BIAS_TILE: work = (int64_t)t.Cout * t.Cin; break;
       case PACK_DGRAD_W: work = (int64_t)t.Cin * t.Np; break;
+      case PACK_FIRST_MFMA: work = 2 * 64 * 8; break;
       default: return false;
     }
     blk += (unsigned)std::max<int64_t>(1, std::min<int64_t>(2048, (work + 255) / 256));
