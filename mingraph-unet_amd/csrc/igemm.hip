@@ -319,6 +319,12 @@ __device__ __forceinline__ float max_1op(const float lo, const float x) {
   return r;
 }
 
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x70 | 0xF00);
+}
+
 template <typename T, int NP, int TH, int WAVES_M, int WAVES_N, int WMT, int WNT, int TPS>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y,
                                                            const int total_patches, const int patches_per_block, const int yfast) {
@@ -341,7 +347,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
   constexpr int BR = (BN + RPP - 1) / RPP;
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   T* Hs = reinterpret_cast<T*>(smem_raw);   // [HP][LDS_LD]
-  T* Bs = Hs + HP * LDS_LD;                 // [2][TPS][BN][LDS_LD]
+  T* Bs = Hs + HP * LDS_LD;                 // [2][TPS][BN][LDS_LD]   (GLDS: [2][TPS][BN] rows of 128 bytes, XOR-swizzled, no pad)
+  // GLDS (64-channel-chunk tiles): the weight tile of a later step goes global -> LDS by LDS-DMA
+  // (global_load_lds_dwordx4: no registers, no ds_write pass, no wait in front of a hand-off).  An instruction writes 1 KB = eight
+  // 128-byte rows in lane order, so the rows cannot be padded: 16-byte piece q of row r sits at position q ^ ((r >> 1) & 7) (the
+  // SOURCE address is per lane, the image is linear) and the fragment reads of 16 consecutive rows fall on 16 distinct bank groups.
+#if defined(MGU_HALO_NO_GLDS)   // (A/B build: weight tiles through registers, as the 32-channel-chunk tiles do)
+  constexpr bool GLDS = false;
+#else
+  constexpr bool GLDS = NP == 8 && BN % 32 == 0;
+#endif
+  constexpr int BROW = GLDS ? CK : LDS_LD;   // weight-row pitch in LDS (elements)
+  // GLDS: three weight buffers (the tile of step s + 2 requested at the top of step s) where two workgroups of the CU still fit
+  constexpr int NBUF = (GLDS && (HP * LDS_LD + 3 * TPS * BN * CK) * (int)sizeof(T) <= 80 * 1024) ? 3 : 2;
+  constexpr int NGL = TPS * (BN / 32);       // (GLDS) DMA instructions per wave and step
   const T* const in_t = reinterpret_cast<const T*>(d.in);
   const T* const w_t = reinterpret_cast<const T*>(d.w);
 
@@ -414,6 +433,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
       for (int i = 0; i < BR; ++i) breg[tt][i] = *reinterpret_cast<const f32x4*>(wrow[i] + k0);
     }
   };
+  // GLDS: the TPS weight tiles of step `stp` of chunk c straight into buffer `buf`: per tap BN / 8 instructions of 1 KB, BN / 32 per wave
+  auto glds_b = [&](int c, int stp, int buf) {
+    if constexpr (GLDS) {
+      const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+      for (int tt = 0; tt < TPS; ++tt) {
+        const int k0 = (stp * TPS + tt) * d.Cp + c * CK;
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j) {
+          const int ii = wave_u * (BN / 32) + j;                 // instruction = rows 8 ii .. 8 ii + 7 of the tile
+          const int row = 8 * ii + (lane >> 3);
+          const int logical = (lane & 7) ^ ((row >> 1) & 7);     // the piece that belongs at this lane's LDS position
+          const T* src = w_t + (size_t)(bn0 + row) * d.Kp + k0 + logical * VEC;
+          T* dst = Bs + ((size_t)(buf * TPS + tt) * BN + 8 * ii) * BROW;   // wave-uniform
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of hipcc has no target feature for this builtin and silently drops the kernel's stub)
+          __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+#else
+          (void)src, (void)dst;
+#endif
+        }
+      }
+    }
+  };
   auto store_b = [&](int buf) {
 #pragma unroll
     for (int tt = 0; tt < TPS; ++tt)
@@ -439,7 +481,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
     const int pp = (wm * WMT + mi) * 32 + lr;
     aoff[mi] = ((pp >> 4) * HWID + (pp & 15)) * LDS_LD + lh * VEC;
   }
-  const int boff = (wn * WNT * 32 + lr) * LDS_LD + lh * VEC;
+  const int boff = GLDS ? (wn * WNT * 32 + lr) * BROW : (wn * WNT * 32 + lr) * LDS_LD + lh * VEC;
+  const int bswz = ((wn * WNT * 32 + lr) >> 1) & 7;   // (GLDS) this lane's row swizzle: the same for its WNT rows (32 apart)
 
   const int nchunks = d.Cp / CK;
   const int nitems = npatch * nchunks;
@@ -454,11 +497,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
     load_halo(lc, set_c);
     ++li;
   };
+  // workgroup barrier.  GLDS: the raw form -- __syncthreads() drains vmcnt while an LDS-DMA is in flight (its fence), i.e. the weight
+  // tile requested at the top of the step would be waited for at once; the waits for the DMA are counted by hand below
+  auto wg_barrier = [&]() {
+    if constexpr (GLDS) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
+  };
+  constexpr int NST = WMT * WNT * 16 < 63 ? WMT * WNT * 16 : 63;   // output stores of an interior patch per lane (vmcnt counts to 63)
+  int w0 = 0;                // (GLDS) stores issued behind the weight DMA of the NEXT item's first step: NST after an interior patch
   load_next_halo(Set0{});
-  load_b(0, 0);
-  store_halo(Set0{});
-  store_b(0);
-  load_b(0, 1);              // SPI >= 3
+  if constexpr (GLDS) {
+    glds_b(0, 0, 0);
+    if constexpr (NBUF == 3) glds_b(0, 1, 1);
+    store_halo(Set0{});
+    wait_vmcnt<0>();
+  } else {
+    load_b(0, 0);
+    store_halo(Set0{});
+    store_b(0);
+    load_b(0, 1);              // SPI >= 3
+  }
   if constexpr (DEEPH) load_next_halo(Set1{});   // item 1 -> set 1
   int c = 0, pi = 0;         // chunk / patch of the item being computed
   int par = 0;               // weight buffer of the step being computed
@@ -480,8 +542,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
     x3_static_for<0, SPI>([&](auto tap_c) {
       constexpr int tap = decltype(tap_c)::value;
       HALO_T(0);
-      __syncthreads();  // Bs[par] (and a fresh halo when tap == 0) visible; Bs[par ^ 1] no longer read
+      if constexpr (GLDS) {
+        // this step's weight tile has landed: everything of this wave older than the operations issued BEHIND its DMA is complete.
+        // NBUF == 2: the DMA was issued at the top of the previous step; behind it: the halo loads of step 0 (tap 1), the previous
+        // patch's stores (tap 0).  NBUF == 3: issued two steps ago; behind it additionally the DMA of the step in between (NGL) and the
+        // halo loads when one of the two steps was step 0.  Counts are lower bounds of what is really in flight (vmcnt counts to 63).
+        constexpr int HRL = HR < 63 ? HR : 63;
+        if constexpr (NBUF == 2) {
+          if constexpr (tap == 1) wait_vmcnt<HRL>();
+          else if constexpr (tap == 0) {
+            if (w0) wait_vmcnt<NST>();
+            else wait_vmcnt<0>();
+          } else wait_vmcnt<0>();
+        } else {
+          constexpr int both = NGL + HRL < 63 ? NGL + HRL : 63;
+          if constexpr (tap == 1 || tap == 2) wait_vmcnt<both>();
+          else wait_vmcnt<NGL>();   // (behind a patch's epilogue this also waits for its stores: once per patch)
+        }
+      }
+      wg_barrier();  // Bs[par] (and a fresh halo when tap == 0) visible; the buffer of the previous step no longer read
       HALO_T(1);
+      if constexpr (GLDS) {   // the tile of step s + NBUF - 1 into the buffer the previous step read
+        constexpr int ahead = NBUF - 1;
+        const int tgt = NBUF == 2 ? (par ^ 1) : (par == 0 ? 2 : par - 1);
+        if constexpr (tap + ahead < SPI) glds_b(c, tap + ahead, tgt);
+        else glds_b(cnext, tap + ahead - SPI, tgt);
+        if constexpr (tap == 0) load_next_halo(SetLoad{});   // behind the DMA in the queue
+      }
     // operand fetches are software-pipelined one (tap, kk) group ahead of the MFMAs that consume them, so the
     // ~100-cycle ds_read latency hides under the previous group's MFMAs instead of being exposed 4x per tap
     {
@@ -490,18 +577,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
       // the operands are requested two k groups ahead (a ring of three fragment sets) where the registers allow: alone on its SIMD a
       // wave took 930 cycles for the 512 of a step's 16 MFMAs with a one-group lead (timeline of a one-workgroup-per-CU run) -- an
       // LDS round trip per group.  (All four groups up front: 255 registers + spills.)
-      constexpr int DEPTH = (NG >= 3 && HR * NSETH <= 12) ? 3 : 2;   // (the 16 x 16 pixel tiles with 64-channel chunks hold 11 halo registers x 4: no room)
+      constexpr int DEPTH = (GLDS && NG == 4 && HR <= 6) ? 4 : (NG >= 3 && HR * NSETH <= 12) ? 3 : 2;   // (the 16 x 16 pixel tiles with 64-channel chunks hold 11 halo registers x 4: no room)
       f32x4 a[DEPTH][WMT], b[DEPTH][WNT];
       auto fetch = [&](int gidx, int slot) {
         const int tt = gidx / NKK, kk = gidx % NKK;
         const int tp = tap * TPS + tt;            // 3x3 tap index
         const int r = tp / 3, s = tp - 3 * r;
         const T* Ap = Hs + (r * HWID + s) * LDS_LD + kk * 2 * VEC;
-        const T* Bp = Bs + (par * TPS + tt) * BN * LDS_LD + boff + kk * 2 * VEC;
+        const T* Bp = GLDS ? Bs + (par * TPS + tt) * BN * BROW + boff + (((2 * kk + lh) ^ bswz) * VEC)
+                           : Bs + (par * TPS + tt) * BN * LDS_LD + boff + kk * 2 * VEC;
 #pragma unroll
         for (int mi = 0; mi < WMT; ++mi) a[slot][mi] = *reinterpret_cast<const f32x4*>(Ap + aoff[mi]);
 #pragma unroll
-        for (int ni = 0; ni < WNT; ++ni) b[slot][ni] = *reinterpret_cast<const f32x4*>(Bp + ni * 32 * LDS_LD);
+        for (int ni = 0; ni < WNT; ++ni) b[slot][ni] = *reinterpret_cast<const f32x4*>(Bp + ni * 32 * BROW);
       };
 #pragma unroll
       for (int gidx = 0; gidx < DEPTH - 1; ++gidx) fetch(gidx, gidx);
@@ -519,11 +607,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
       }
     }
       HALO_T(2);   // MFMAs of the step issued
-      store_b(par ^ 1);                         // the next step's weight tile (its buffer is free since the barrier above)
-      if constexpr (tap + 2 < SPI) load_b(c, tap + 2);   // the tile of the step after it: (chunk, step) two steps ahead
-      else load_b(cnext, tap + 2 - SPI);
-      if constexpr (tap == 0) load_next_halo(SetLoad{});
-      par ^= 1;
+      if constexpr (!GLDS) {
+        store_b(par ^ 1);                         // the next step's weight tile (its buffer is free since the barrier above)
+        if constexpr (tap + 2 < SPI) load_b(c, tap + 2);   // the tile of the step after it: (chunk, step) two steps ahead
+        else load_b(cnext, tap + 2 - SPI);
+        if constexpr (tap == 0) load_next_halo(SetLoad{});
+      }
+      if constexpr (NBUF == 2) par ^= 1;
+      else par = par == 2 ? 0 : par + 1;
       HALO_T(3);
       ++st;
     });
@@ -531,9 +622,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
       const bool patch_done = (c + 1 == nchunks);
       const bool more = patch_done ? (pi + 1 < npatch) : true;
       if (more) {
-        __syncthreads();  // every wave is done with the old halo
+        wg_barrier();  // every wave is done with the old halo
         store_halo(SetStore{});     // visible after the barrier at the top of the next step
       }
+      w0 = 0;
       if (patch_done) {
         // ---- epilogue of patch pi (its stores overlap the next patch's halo, already in LDS/flight) ----
         const PatchPos pp = setup_patch(p_begin + pi);
@@ -618,6 +710,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
 #else
         if (interior) store_patch(std::false_type{});
         else store_patch(std::true_type{});
+        w0 = interior ? 1 : 0;
 #endif
       }
       // (plain arithmetic: `if (done) { c = 0; ++pi; } else ++c;` became an increment through a selected ADDRESS, with c and pi in scratch)
@@ -646,6 +739,10 @@ static hipError_t launch_halo(const IgemmDesc& d, hipStream_t s) {
   if (ppb > tun(d).halo_max_ppb) ppb = std::max(1, tun(d).halo_max_ppb);
   dim3 grid((total + ppb - 1) / ppb, ntn);
   size_t lds = (size_t)(HP + 2 * TPS * BN) * (NP * 16 + 16);
+#if !defined(MGU_HALO_NO_GLDS)
+  if (NP == 8 && BN % 32 == 0 && (size_t)HP * (NP * 16 + 16) + (size_t)3 * TPS * BN * NP * 16 <= 80 * 1024)
+    lds = (size_t)HP * (NP * 16 + 16) + (size_t)3 * TPS * BN * NP * 16;   // three unpadded weight buffers (the kernel's NBUF)
+#endif
 #if defined(MGU_DIAG) && MGU_DIAG == 23
   if (getenv("MGU_DIAG_OCC1")) lds = std::max<size_t>(lds, 100 * 1024);   // timing experiment: one workgroup per CU
 #endif
