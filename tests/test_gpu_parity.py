@@ -82,6 +82,28 @@ def test_unet_accepts_channels_last_and_strided_input(cuda):
     assert torch.equal(ref, a) and torch.equal(ref, b)
 
 
+@pytest.mark.parametrize("cin", [1, 2, 3])
+def test_first_convolution_on_the_matrix_cores_reads_any_view_of_the_image(cuda, cin, monkeypatch):
+    """The 32-feature U-Net's first convolution runs on conv3x3_first_mfma_kernel, which reads the caller's image through its strides
+    (no packed copy): NCHW, channels_last and a window of a larger tensor give the same bytes, ragged sizes (edge patches) included, and
+    the result equals the VALU kernel behind pack_input_kernel (MGU_NO_FIRST_MFMA=1) and the oracle to the fp32 tolerance."""
+    cfg = (cin, 2, 32, 2)
+    x = torch.from_numpy(O.formula_normal("firstmfma/x", (2, cin, 37, 45), seed=cin)).to(cuda)
+    m = make_unet(cfg, 7, cuda)
+    ref = m(x)[0]
+    a = m(x.contiguous(memory_format=torch.channels_last))[0]
+    big = torch.zeros(2, cin, 41, 50, device=cuda)
+    big[:, :, 3:40, 2:47] = x
+    b = m(big[:, :, 3:40, 2:47])[0]
+    assert torch.equal(ref, a) and torch.equal(ref, b)
+    with torch.no_grad():
+        olg = O.unet_forward(O.make_unet_params(*cfg, seed=7), x.cpu(), cfg[3])[0]
+    assert maxdiff(ref, olg.numpy()) <= 2e-5
+    monkeypatch.setenv("MGU_NO_FIRST_MFMA", "1")   # read by mgu_create: a new model = a new context
+    v = make_unet(cfg, 7, cuda)(x)[0]
+    assert maxdiff(ref, v.cpu().numpy()) <= 2e-5
+
+
 def test_c1_sampled_logits_and_checksums(cuda, golden):
     g = golden["c1"]
     m = make_unet((1, 2, 32, 4), 0, cuda)
