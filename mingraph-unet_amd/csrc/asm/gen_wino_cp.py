@@ -1,0 +1,703 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled gfx950 assembly of the wide component-pair Winograd kernel.
+
+Emits `mgu_wino_cp2_gfx950`: the same algorithm, data layout and arithmetic ORDER as wino3x3_cp_kernel<2, false, false, false>
+(csrc/wino_f32.hip; the 3x3 convolutions of ConvBlock, model/unet/unet_encoder.py:15-25) -- results are bitwise equal to the
+C++ kernel -- with the register map and the instruction order of the chunk loop fixed by hand:
+
+  * 256 VGPRs per wave, no scratch: 128 accumulators | 48 weight pieces | 2 x 12 operand pieces | 32 raw operands |
+    12 halo registers | 9 lane constants | 3 temporaries;
+  * a step issues the eight LDS reads of the NEXT step's raw operands first, then its twelve MFMAs with the transform and the
+    three-way split of those operands spread between them (nothing waits for a read it has just issued); the weight pieces of
+    the next chunk are requested right behind the last MFMA that uses the register they land in;
+  * every s_waitcnt is counted (vmcnt: halo loads, weight pieces and stores retire in order; lgkmcnt: LDS only, no scalar
+    loads inside the loops);
+  * out-of-image halo pixels ride on the buffer descriptor's range check (offset 0x7fff0000): no mask, no select.
+
+Applicability (the launcher checks; everything else stays on the C++ kernel): inference epilogue (no statistics), H % 8 == 0,
+W % 32 == 0, N % 64 == 0, Cp % 32 == 0, channel pitches and offsets % 4 == 0, scale and shift present, x-fastest patch order.
+
+Usage: gen_wino_cp.py OUT.s
+"""
+import sys
+
+# ---------------------------------------------------------------------------------------------------------------------
+# register map
+# ---------------------------------------------------------------------------------------------------------------------
+def vr(b, n=1):
+    return f"v{b}" if n == 1 else f"v[{b}:{b + n - 1}]"
+
+def ACC(jj, nt, mi): return ((jj * 2 + nt) * 2 + mi) * 16
+def BX(jj, nt, p): return 128 + ((jj * 2 + nt) * 3 + p) * 4
+def PC(slot, p): return 176 + (slot * 3 + p) * 4
+def RAW(hf, k): return 200 + (hf * 4 + k) * 4          # k: 0 = a(x), 1 = b(x), 2 = a(y), 3 = b(y)
+def HREG(i): return 232 + i * 4
+VA, VB = 244, 245
+VHST = [246, 247, 248]
+VHOFF = [249, 250, 251]
+VLANE16 = 252
+VTID = 253
+VT0, VT1 = 254, 255
+
+# SGPRs
+S_IN, S_WU, S_OUT, S_SCALE, S_SHIFT, S_POOL = 4, 6, 8, 10, 12, 14
+S_H, S_W, S_LDIN, S_LDOUT, S_LDPOOL, S_NC, S_RELU, S_TX, S_TY, S_TOTAL, S_PPB, S_NGROUPS = 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27
+S_NITEMS, S_PERXCD, S_MGNG, S_MGTX, S_MGTXTY, S_PAD = 28, 29, 30, 31, 32, 33
+S_NBLOCK, S_PBEGIN, S_NPATCH, S_LC, S_LP, S_PI, S_C, S_LC64 = 34, 35, 36, 37, 38, 39, 40, 41
+S_N64X4 = 42        # (nblock * 64) * 4: byte offset of the workgroup's first channel
+S_SUMOFF = 43       # (W * ldout + ldout) * 4
+S_INR = 44          # s[44:47] input descriptor
+S_UR = 48           # s[48:51] weight-piece descriptor
+S_SGN, S_W1, S_MASK, S_PERM, S_NTSTRIDE, S_TXTY, S_IMGB, S_OOB = 52, 53, 54, 55, 56, 57, 58, 59
+S_T = [60, 61, 62, 63, 64, 65, 66, 67]
+S_WI, S_JP = 68, 69
+S_P, S_IMG, S_REM, S_PY, S_PX, S_Y0, S_X0 = 70, 71, 72, 73, 74, 75, 72   # S_X0 shares with S_REM after use? no: keep separate below
+S_X0 = 88
+S_M = 76            # s[76:77]
+S_WO = [[78, 79], [90, 91]]   # weight soffsets [jj][nt] of the chunk being requested
+S_OUTR = 80         # s[80:83]
+S_POOLR = 84        # s[84:87]
+S_OUTIMGB = 89
+S_SCR = 92          # s[92:95] scale descriptor
+S_SHR = 96          # s[96:99] shift descriptor
+S_LD4, S_SW4 = 100, 101
+
+S1F, S2F, S3F = 17 * 20, 20, 17 * 20 + 20     # LDS offsets (floats) of tile columns 1..3
+BUFX = 0x20000                                # byte distance of the two raw buffers (slots 0 and 4 of the LDS map)
+RAWB = 8192 * 4                               # bytes of an LDS slot
+ZBIAS = 57472
+
+out = []
+def E(s=""): out.append("\t" + s if s and not s.endswith(":") else s)
+def L(s): out.append(s + ":")
+_lbl = [0]
+def newlabel(p="L"):
+    _lbl[0] += 1
+    return f".{p}_{_lbl[0]}"
+
+
+def divmod_magic(n, d, mg, q, r, t0, t1):
+    """q = n / d, r = n % d  (scalar; mg = floor(2^32 / d), n * d < 2^32)"""
+    E(f"s_mul_hi_u32 s{q}, s{n}, s{mg}")
+    E(f"s_mul_i32 s{t0}, s{q}, s{d}")
+    E(f"s_sub_u32 s{r}, s{n}, s{t0}")
+    E(f"s_add_u32 s{t0}, s{q}, 1")
+    E(f"s_sub_u32 s{t1}, s{r}, s{d}")
+    E(f"s_cmp_ge_u32 s{r}, s{d}")
+    E(f"s_cselect_b32 s{q}, s{t0}, s{q}")
+    E(f"s_cselect_b32 s{r}, s{t1}, s{r}")
+
+
+def patch_coords(p):
+    """s_p -> S_IMG, S_Y0, S_X0 (x fastest inside an image)"""
+    divmod_magic(p, S_TXTY, S_MGTXTY, S_IMG, S_REM, S_T[6], S_T[7])
+    divmod_magic(S_REM, S_TX, S_MGTX, S_PY, S_PX, S_T[6], S_T[7])
+    E(f"s_lshl_b32 s{S_Y0}, s{S_PY}, 3")
+    E(f"s_lshl_b32 s{S_X0}, s{S_PX}, 5")
+
+
+def setup_load():
+    """setup_load(p_begin + lp): input descriptor of the patch's image and the three halo offsets of the thread."""
+    E(f"s_add_u32 s{S_P}, s{S_PBEGIN}, s{S_LP}")
+    patch_coords(S_P)
+    E(f"s_mul_i32 s{S_T[6]}, s{S_IMG}, s{S_IMGB}")
+    E(f"s_mul_hi_u32 s{S_T[7]}, s{S_IMG}, s{S_IMGB}")
+    E(f"s_add_u32 s{S_INR}, s{S_IN}, s{S_T[6]}")
+    E(f"s_addc_u32 s{S_INR + 1}, s{S_IN + 1}, s{S_T[7]}")
+    E(f"s_and_b32 s{S_INR + 1}, s{S_INR + 1}, 0xffff")
+    E(f"s_sub_u32 s{S_T[6]}, s{S_Y0}, 1")     # y0 - 1
+    E(f"s_sub_u32 s{S_T[7]}, s{S_X0}, 1")     # x0 - 1
+    for i in range(3):
+        d = VHOFF[i]
+        E(f"v_lshrrev_b32_e32 v{VT0}, 2, v{VTID}")
+        if i:
+            E(f"v_add_u32_e32 v{VT0}, {128 * i}, v{VT0}")                    # hp
+        E(f"v_mul_u32_u24_e32 v{VT1}, 0x788, v{VT0}")
+        E(f"v_lshrrev_b32_e32 v{VT1}, 16, v{VT1}")                            # r = hp / 34
+        E(f"v_mul_u32_u24_e32 v{d}, 34, v{VT1}")
+        E(f"v_sub_u32_e32 v{d}, v{VT0}, v{d}")                                # cc
+        E(f"v_cmp_gt_u32_e32 vcc, 0x154, v{VT0}")                             # hp < 340
+        E(f"v_add_u32_e32 v{VT1}, s{S_T[6]}, v{VT1}")                         # y
+        E(f"v_add_u32_e32 v{d}, s{S_T[7]}, v{d}")                             # x
+        E(f"v_cmp_gt_u32_e64 s[{S_M}:{S_M + 1}], s{S_H}, v{VT1}")
+        E(f"s_and_b64 vcc, vcc, s[{S_M}:{S_M + 1}]")
+        E(f"v_cmp_gt_u32_e64 s[{S_M}:{S_M + 1}], s{S_W}, v{d}")
+        E(f"s_and_b64 vcc, vcc, s[{S_M}:{S_M + 1}]")
+        E(f"v_mad_u32_u24 v{VT1}, v{VT1}, s{S_W}, v{d}")                      # y * W + x
+        E(f"v_mul_lo_u32 v{VT1}, v{VT1}, s{S_LDIN}")
+        E(f"v_and_b32_e32 v{VT0}, 3, v{VTID}")                                # kq
+        E(f"v_lshl_add_u32 v{VT1}, v{VT0}, 2, v{VT1}")
+        E(f"v_lshlrev_b32_e32 v{VT1}, 2, v{VT1}")                             # bytes
+        E(f"v_mov_b32_e32 v{d}, s{S_OOB}")
+        E("s_nop 1")
+        E(f"v_cndmask_b32_e32 v{d}, v{d}, v{VT1}, vcc")
+
+
+def halo_loads():
+    for i in range(3):
+        E(f"buffer_load_dwordx4 {vr(HREG(i), 4)}, v{VHOFF[i]}, s[{S_INR}:{S_INR + 3}], s{S_LC64} offen")
+    # lc = lc + 1 == nC ? 0 : lc + 1;  lp += lc == 0
+    E(f"s_add_u32 s{S_LC}, s{S_LC}, 1")
+    E(f"s_cmp_eq_u32 s{S_LC}, s{S_NC}")
+    E(f"s_cselect_b32 s{S_LC}, 0, s{S_LC}")
+    E(f"s_cmp_eq_u32 s{S_LC}, 0")
+    E(f"s_addc_u32 s{S_LP}, s{S_LP}, 0")
+    E(f"s_lshl_b32 s{S_LC64}, s{S_LC}, 6")
+
+
+def halo_stores():
+    for i in range(3):
+        E(f"ds_write_b128 v{VHST[i]}, {vr(HREG(i), 4)}")
+
+
+def raw_reads(jp, jj, mi):
+    """the eight ds_read_b128 of step (jj, mi): returns instruction strings"""
+    cx = (S2F if jp else 0) if jj == 0 else S1F
+    cy = (S1F if jp else S2F) if jj == 0 else (S3F if jp else S2F)
+    r = []
+    for hf in range(2):
+        base = mi * 10880 + hf * 16
+        r.append(f"ds_read_b128 {vr(RAW(hf, 0), 4)}, v{VA} offset:{base + cx * 4}")
+        r.append(f"ds_read_b128 {vr(RAW(hf, 1), 4)}, v{VB} offset:{base + cx * 4}")
+        r.append(f"ds_read_b128 {vr(RAW(hf, 2), 4)}, v{VA} offset:{base + cy * 4}")
+        r.append(f"ds_read_b128 {vr(RAW(hf, 3), 4)}, v{VB} offset:{base + cy * 4}")
+    return r
+
+
+def form_valu(jp, jj, slot, hf):
+    """transform + three-way split of half hf of step (jj, .) into pc[slot]: 34 VALU, chains interleaved"""
+    w = "-1.0" if not (jj == 1 and jp == 0) else "1.0"
+    a, b, c, d = RAW(hf, 0), RAW(hf, 1), RAW(hf, 2), RAW(hf, 3)
+    r = []
+    for e in range(4):
+        r.append(f"v_fma_f32 v{a + e}, s{S_SGN}, v{b + e}, v{a + e}")       # qx = sgn * rb_x + ra_x
+    for e in range(4):
+        r.append(f"v_fma_f32 v{c + e}, s{S_SGN}, v{d + e}, v{c + e}")       # qy
+    for e in range(4):
+        r.append(f"v_fma_f32 v{a + e}, {w}, v{c + e}, v{a + e}")            # v = w * qy + qx
+    # pairs (0,1) -> piece dword hf*2, (2,3) -> hf*2+1;  temporaries: the b registers
+    for piece in range(3):
+        for p in range(2):
+            r.append(f"v_perm_b32 v{PC(slot, piece) + hf * 2 + p}, v{a + 2 * p + 1}, v{a + 2 * p}, s{S_PERM}")
+        if piece < 2:
+            for e in range(4):
+                r.append(f"v_and_b32_e32 v{b + e}, s{S_MASK}, v{a + e}")
+            for e in range(4):
+                r.append(f"v_sub_f32_e32 v{a + e}, v{a + e}, v{b + e}")
+    assert len(r) == 34
+    return r
+
+
+def mfmas(jj, mi, slot):
+    r = []
+    for nt in range(2):
+        acc = vr(ACC(jj, nt, mi), 16)
+        for (pa, pb) in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)):
+            r.append(f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(PC(slot, pa), 4)}, {vr(BX(jj, nt, pb), 4)}, {acc}")
+    return r
+
+
+def weight_load(jj, nt, p):
+    return f"buffer_load_dwordx4 {vr(BX(jj, nt, p), 4)}, v{VLANE16}, s[{S_UR}:{S_UR + 3}], s{S_WO[jj][nt]} offen offset:{p * 1024}"
+
+
+def emit_step(jp, s):
+    jj, mi, slot = s >> 1, s & 1, s & 1
+    ns = (s + 1) & 3
+    njj, nmi = ns >> 1, ns & 1
+    if s == 2:
+        pass
+    if s == 3:
+        # B1: chunk c + 1 is complete in the other buffer; this step's reads are the next chunk's step 0
+        E("s_waitcnt lgkmcnt(0)")
+        E("s_barrier")
+        E(f"v_xor_b32_e32 v{VA}, 0x{BUFX:x}, v{VA}")
+        E(f"v_xor_b32_e32 v{VB}, 0x{BUFX:x}, v{VB}")
+    for r in raw_reads(jp, njj, nmi):
+        E(r)
+    if s in (0, 2):
+        E("s_waitcnt vmcnt(9)")          # this component's weight pieces (requested a chunk ago)
+    mf = mfmas(jj, mi, slot)
+    v0 = form_valu(jp, njj, slot ^ 1, 0)
+    v1 = form_valu(jp, njj, slot ^ 1, 1)
+    wl = {}
+    if mi == 1:   # pieces of the next chunk into the registers this step has finished with
+        wl = {1: [weight_load(jj, 0, 2)], 4: [weight_load(jj, 0, 1)], 5: [weight_load(jj, 0, 0)],
+              7: [weight_load(jj, 1, 2)], 10: [weight_load(jj, 1, 1)], 11: [weight_load(jj, 1, 0)]}
+    def take(lst, n):
+        for _ in range(min(n, len(lst))):
+            E(lst.pop(0))
+    for k in range(12):
+        E(mf[k])
+        for x in wl.get(k, []):
+            E(x)
+        if k == 2:
+            E("s_waitcnt lgkmcnt(4)")
+        if 2 <= k <= 6:
+            take(v0, 7)
+        if k == 6:
+            assert not v0
+            E("s_waitcnt lgkmcnt(0)")
+        if 7 <= k <= 10:
+            take(v1, 9)
+    assert not v1
+
+
+def emit_chunk(jp):
+    """one 16-channel chunk: B0, park chunk c + 1, request chunk c + 2, four steps"""
+    lskip = newlabel("nosetup")
+    E(f"s_cmp_lg_u32 s{S_LC}, 0")
+    E(f"s_cbranch_scc1 {lskip}")
+    E(f"s_cmp_ge_u32 s{S_LP}, s{S_NPATCH}")
+    E(f"s_cbranch_scc1 {lskip}")
+    setup_load()
+    L(lskip)
+    E("s_waitcnt lgkmcnt(0)")
+    E("s_barrier")                        # B0
+    E("s_waitcnt vmcnt(12)")              # the halo registers (two sets of weight pieces are younger)
+    halo_stores()
+    halo_loads()
+    for i in range(3):
+        E(f"v_xor_b32_e32 v{VHST[i]}, 0x{BUFX:x}, v{VHST[i]}")
+    # weight soffsets of chunk cn = c + 1 == nC ? 0 : c + 1
+    E(f"s_add_u32 s{S_T[0]}, s{S_C}, 1")
+    E(f"s_cmp_eq_u32 s{S_T[0]}, s{S_NC}")
+    E(f"s_cselect_b32 s{S_T[0]}, 0, s{S_T[0]}")
+    E(f"s_mul_i32 s{S_WO[0][0]}, s{S_T[0]}, 0xc000")
+    E(f"s_add_u32 s{S_WO[0][1]}, s{S_WO[0][0]}, s{S_NTSTRIDE}")
+    E(f"s_add_u32 s{S_WO[1][0]}, s{S_WO[0][0]}, 0xc00")
+    E(f"s_add_u32 s{S_WO[1][1]}, s{S_WO[0][1]}, 0xc00")
+    for s in range(4):
+        emit_step(jp, s)
+
+
+def emit_epilogue(jp):
+    E0 = 188                              # 44 free registers v188..v231 (second operand slot + raw operands)
+    CQ, VT = VT0, VT1
+    VZ0, VZ1, VOUT, VPOOL = E0 + 0, E0 + 1, E0 + 2, E0 + 3
+    SCW = [E0 + 4, E0 + 5]
+    SHW = [E0 + 6, E0 + 7]
+    TMP = [E0 + 8 + i for i in range(8)]
+    e0, e1, e2, e3 = E0 + 16, E0 + 17, E0 + 18, E0 + 19
+    E("s_nop 7")
+    E("s_nop 7")
+    E("s_nop 7")
+    E(f"s_add_u32 s{S_P}, s{S_PBEGIN}, s{S_PI}")
+    patch_coords(S_P)
+    # output / pooled descriptors of the image
+    E(f"s_mul_i32 s{S_T[6]}, s{S_IMG}, s{S_OUTIMGB}")
+    E(f"s_mul_hi_u32 s{S_T[7]}, s{S_IMG}, s{S_OUTIMGB}")
+    E(f"s_add_u32 s{S_OUTR}, s{S_OUT}, s{S_T[6]}")
+    E(f"s_addc_u32 s{S_OUTR + 1}, s{S_OUT + 1}, s{S_T[7]}")
+    E(f"s_and_b32 s{S_OUTR + 1}, s{S_OUTR + 1}, 0xffff")
+    # pooled image bytes = (H/2) * (W/2) * ldpool * 4
+    E(f"s_lshr_b32 s{S_T[4]}, s{S_H}, 1")
+    E(f"s_lshr_b32 s{S_T[5]}, s{S_W}, 1")
+    E(f"s_mul_i32 s{S_T[4]}, s{S_T[4]}, s{S_T[5]}")
+    E(f"s_mul_i32 s{S_T[4]}, s{S_T[4]}, s{S_LDPOOL}")
+    E(f"s_lshl_b32 s{S_T[4]}, s{S_T[4]}, 2")
+    E(f"s_mov_b32 s{S_POOLR + 2}, s{S_T[4]}")
+    E(f"s_mul_i32 s{S_T[6]}, s{S_IMG}, s{S_T[4]}")
+    E(f"s_mul_hi_u32 s{S_T[7]}, s{S_IMG}, s{S_T[4]}")
+    E(f"s_add_u32 s{S_POOLR}, s{S_POOL}, s{S_T[6]}")
+    E(f"s_addc_u32 s{S_POOLR + 1}, s{S_POOL + 1}, s{S_T[7]}")
+    E(f"s_and_b32 s{S_POOLR + 1}, s{S_POOLR + 1}, 0xffff")
+    # finishing unit of the thread
+    E(f"v_and_b32_e32 v{CQ}, 7, v{VTID}")
+    E(f"v_lshrrev_b32_e32 v{VT}, 3, v{VTID}")
+    E(f"v_and_b32_e32 v{e0}, 32, v{VT}")
+    E(f"v_and_b32_e32 v{e1}, 3, v{VT}")
+    E(f"v_bfe_u32 v{e2}, v{VT}, 3, 2")                       # (T & 31) >> 3
+    E(f"v_lshl_add_u32 v{e1}, v{e2}, 2, v{e1}")
+    E(f"v_lshl_add_u32 v{e0}, v{e1}, 1, v{e0}")
+    E(f"v_bfe_u32 v{e2}, v{VT}, 2, 1")
+    E(f"v_add_u32_e32 v{e0}, v{e0}, v{e2}")                  # Tslot
+    E(f"v_lshlrev_b32_e32 v{e0}, 7, v{e0}")
+    E(f"v_lshl_add_u32 v{VZ0}, v{CQ}, 4, v{e0}")
+    E(f"v_add_u32_e32 v{VZ1}, 0x10000, v{VZ0}")
+    E(f"v_lshrrev_b32_e32 v{e1}, 4, v{VT}")
+    E(f"v_lshl_add_u32 v{e1}, v{e1}, 1, s{S_Y0}")            # oy
+    E(f"v_and_b32_e32 v{e2}, 15, v{VT}")
+    E(f"v_lshl_add_u32 v{e2}, v{e2}, 1, s{S_X0}")            # ox
+    E(f"v_mad_u32_u24 v{e3}, v{e1}, s{S_W}, v{e2}")
+    E(f"v_mul_lo_u32 v{e3}, v{e3}, s{S_LDOUT}")
+    E(f"v_lshl_add_u32 v{e3}, v{CQ}, 2, v{e3}")
+    E(f"v_lshlrev_b32_e32 v{VOUT}, 2, v{e3}")
+    E(f"v_add_u32_e32 v{VOUT}, s{S_N64X4}, v{VOUT}")
+    # pooled pixel
+    E(f"v_lshrrev_b32_e32 v{e1}, 1, v{e1}")
+    E(f"v_lshrrev_b32_e32 v{e2}, 1, v{e2}")
+    E(f"v_mad_u32_u24 v{e3}, v{e1}, s{S_T[5]}, v{e2}")
+    E(f"v_mul_lo_u32 v{e3}, v{e3}, s{S_LDPOOL}")
+    E(f"v_lshl_add_u32 v{e3}, v{CQ}, 2, v{e3}")
+    E(f"v_lshlrev_b32_e32 v{VPOOL}, 2, v{e3}")
+    E(f"v_add_u32_e32 v{VPOOL}, s{S_N64X4}, v{VPOOL}")
+    # per-channel scale / shift of the writer lane (n = nblock * 64 + nt * 32 + (tid & 31))
+    E(f"v_and_b32_e32 v{e0}, 31, v{VTID}")
+    E(f"v_lshlrev_b32_e32 v{e0}, 2, v{e0}")
+    for nt in range(2):
+        E(f"buffer_load_dword v{SCW[nt]}, v{e0}, s[{S_SCR}:{S_SCR + 3}], s{S_N64X4} offen offset:{nt * 128}")
+    lz, ld = newlabel("shz"), newlabel("shd")
+    if jp == 0:
+        E(f"s_cmp_lg_u32 s{S_WI}, 1")
+        E(f"s_cbranch_scc1 {lz}")
+        for nt in range(2):
+            E(f"buffer_load_dword v{SHW[nt]}, v{e0}, s[{S_SHR}:{S_SHR + 3}], s{S_N64X4} offen offset:{nt * 128}")
+        E(f"s_branch {ld}")
+        L(lz)
+    for nt in range(2):
+        E(f"v_mov_b32_e32 v{SHW[nt]}, 0")
+    L(ld)
+    # add-TID bases of this wave's two shares
+    #   q = 0: jp 0 -> region (0,0) = slot 0 (the consumed raw buffer, even chunk count), jp 1 -> region (0,1) = slot 1
+    #   q = 1: slot 2 + jp, biased by ZBIAS
+    E(f"s_lshl_b32 s{S_T[0]}, s{S_WI}, 13")                  # wi * 64 * 32 * 4
+    if jp:
+        E(f"s_add_u32 s{S_T[0]}, s{S_T[0]}, 0x{RAWB:x}")
+    E(f"s_lshl_b32 s{S_T[1]}, s{S_WI}, 13")
+    E(f"s_add_u32 s{S_T[1]}, s{S_T[1]}, 0x{(2 + jp) * RAWB - ZBIAS:x}")
+    E("s_waitcnt lgkmcnt(0)")
+    E("s_barrier")                       # every wave has finished reading the consumed raw buffer
+    E("s_waitcnt vmcnt(0)")
+    for nt in range(2):
+        def share(q, mi, r, t):
+            m0, m1 = ACC(0, nt, mi) + r, ACC(1, nt, mi) + r
+            if jp == 0 and q == 0:
+                E(f"v_add_f32_e32 v{t}, v{m0}, v{m1}")
+                E(f"v_fma_f32 v{t}, v{SCW[nt]}, v{t}, v{SHW[nt]}")
+            elif jp == 0:
+                E(f"v_fma_f32 v{t}, v{m1}, v{SCW[nt]}, v{SHW[nt]}")
+            elif q == 0:
+                E(f"v_fma_f32 v{t}, v{m0}, v{SCW[nt]}, v{SHW[nt]}")
+            else:
+                E(f"v_sub_f32_e64 v{t}, -v{m0}, v{m1}")
+                E(f"v_fma_f32 v{t}, v{SCW[nt]}, v{t}, v{SHW[nt]}")
+        for q in range(2):
+            E(f"s_mov_b32 m0, s{S_T[q]}")
+            E("s_nop 0")
+            g = 0
+            for mi in range(2):
+                for r0 in range(0, 16, 4):
+                    ts = TMP[(g & 1) * 4:(g & 1) * 4 + 4]
+                    g += 1
+                    for k in range(4):
+                        share(q, mi, r0 + k, ts[k])
+                    E("s_nop 0")
+                    for k in range(4):
+                        off = (32 * mi + 2 * (r0 + k)) * 128 + (ZBIAS if q else 0)
+                        E(f"ds_write_addtid_b32 v{ts[k]} offset:{off}")
+        E("s_waitcnt lgkmcnt(0)")
+        E("s_barrier")
+        # finishing pass of unit (T, cq): 16 share reads into the dead accumulators of this n tile
+        zb = [ACC(0, nt, 0), ACC(0, nt, 1), ACC(1, nt, 0), ACC(1, nt, 1)]
+        def Z(q, j, i):
+            k = (q * 2 + j) * 4 + i
+            return zb[k // 4] + (k % 4) * 4
+        for q in range(2):
+            for j in range(2):
+                for i in range(4):
+                    E(f"ds_read_b128 {vr(Z(q, j, i), 4)}, v{VZ1 if q else VZ0} offset:{j * RAWB + i * 8192}")
+        E("s_waitcnt lgkmcnt(0)")
+        for q in range(2):
+            for i in range(4):
+                for e in range(4):
+                    E(f"v_add_f32_e32 v{Z(q, 0, i) + e}, v{Z(q, 0, i) + e}, v{Z(q, 1, i) + e}")     # z_i
+            ya, yb = Z(q, 1, 0), Z(q, 1, 1)
+            for e in range(4):
+                E(f"v_add_f32_e32 v{ya + e}, v{Z(q, 0, 0) + e}, v{Z(q, 0, 1) + e}")
+            for e in range(4):
+                E(f"v_add_f32_e32 v{ya + e}, v{ya + e}, v{Z(q, 0, 2) + e}")                        # (z0 + z1) + z2
+            for e in range(4):
+                E(f"v_sub_f32_e32 v{yb + e}, v{Z(q, 0, 1) + e}, v{Z(q, 0, 2) + e}")
+            for e in range(4):
+                E(f"v_sub_f32_e32 v{yb + e}, v{yb + e}, v{Z(q, 0, 3) + e}")                        # (z1 - z2) - z3
+        lnr = newlabel("norelu")
+        E(f"s_cmp_eq_u32 s{S_RELU}, 0")
+        E(f"s_cbranch_scc1 {lnr}")
+        for q in range(2):
+            for y in (Z(q, 1, 0), Z(q, 1, 1)):
+                for e in range(4):
+                    E(f"v_max_f32_e32 v{y + e}, 0, v{y + e}")
+        L(lnr)
+        ya0, yb0, ya1, yb1 = Z(0, 1, 0), Z(0, 1, 1), Z(1, 1, 0), Z(1, 1, 1)
+        E(f"buffer_store_dwordx4 {vr(ya0, 4)}, v{VOUT}, s[{S_OUTR}:{S_OUTR + 3}], 0 offen offset:{nt * 128} nt")
+        E(f"buffer_store_dwordx4 {vr(ya1, 4)}, v{VOUT}, s[{S_OUTR}:{S_OUTR + 3}], s{S_LD4} offen offset:{nt * 128} nt")
+        E(f"buffer_store_dwordx4 {vr(yb0, 4)}, v{VOUT}, s[{S_OUTR}:{S_OUTR + 3}], s{S_SW4} offen offset:{nt * 128} nt")
+        E(f"buffer_store_dwordx4 {vr(yb1, 4)}, v{VOUT}, s[{S_OUTR}:{S_OUTR + 3}], s{S_SUMOFF} offen offset:{nt * 128} nt")
+        lnp = newlabel("nopool")
+        E(f"s_cmp_eq_u64 s[{S_POOL}:{S_POOL + 1}], 0")
+        E(f"s_cbranch_scc1 {lnp}")
+        pm = Z(0, 0, 0)
+        for e in range(4):
+            E(f"v_max_f32_e32 v{pm + e}, v{ya0 + e}, v{yb0 + e}")
+        for e in range(4):
+            E(f"v_max_f32_e32 v{Z(0, 0, 1) + e}, v{ya1 + e}, v{yb1 + e}")
+        for e in range(4):
+            E(f"v_max_f32_e32 v{pm + e}, v{pm + e}, v{Z(0, 0, 1) + e}")
+        E(f"buffer_store_dwordx4 {vr(pm, 4)}, v{VPOOL}, s[{S_POOLR}:{S_POOLR + 3}], 0 offen offset:{nt * 128}")
+        L(lnp)
+        E("s_waitcnt lgkmcnt(0)")
+        E("s_barrier")                   # the regions are rewritten by the next pass / receive the next raw chunk
+    for r in range(128):
+        E(f"v_mov_b32_e32 v{r}, 0")
+
+
+def emit_patch_loop(jp):
+    lp, lc = newlabel("patch"), newlabel("chunk")
+    L(lp)
+    E(f"s_mov_b32 s{S_C}, 0")
+    L(lc)
+    emit_chunk(jp)
+    E(f"s_add_u32 s{S_C}, s{S_C}, 1")
+    E(f"s_cmp_lt_u32 s{S_C}, s{S_NC}")
+    E(f"s_cbranch_scc1 {lc}")
+    emit_epilogue(jp)
+    E(f"s_add_u32 s{S_PI}, s{S_PI}, 1")
+    E(f"s_cmp_lt_u32 s{S_PI}, s{S_NPATCH}")
+    E(f"s_cbranch_scc1 {lp}")
+    E("s_branch .Lend")
+
+
+def emit_prologue():
+    E("s_load_dwordx16 s[4:19], s[0:1], 0x0")
+    E("s_load_dwordx8 s[20:27], s[0:1], 0x40")
+    E("s_load_dwordx4 s[28:31], s[0:1], 0x60")
+    E("s_load_dwordx2 s[32:33], s[0:1], 0x70")
+    E(f"v_mov_b32_e32 v{VTID}, v0")
+    E("s_waitcnt lgkmcnt(0)")
+    # item = (wg & 7) * per_xcd + (wg >> 3)
+    t = S_T
+    E(f"s_and_b32 s{t[0]}, s2, 7")
+    E(f"s_mul_i32 s{t[0]}, s{t[0]}, s{S_PERXCD}")
+    E(f"s_lshr_b32 s{t[1]}, s2, 3")
+    E(f"s_add_u32 s{t[0]}, s{t[0]}, s{t[1]}")
+    E(f"s_cmp_ge_u32 s{t[0]}, s{S_NITEMS}")
+    E("s_cbranch_scc1 .Lend")
+    divmod_magic(t[0], S_NGROUPS, S_MGNG, S_NBLOCK, t[1], t[2], t[3])
+    E(f"s_mul_i32 s{S_PBEGIN}, s{t[1]}, s{S_PPB}")
+    E(f"s_sub_i32 s{t[2]}, s{S_TOTAL}, s{S_PBEGIN}")
+    E(f"s_min_i32 s{S_NPATCH}, s{S_PPB}, s{t[2]}")
+    E(f"s_cmp_lt_i32 s{S_NPATCH}, 1")
+    E("s_cbranch_scc1 .Lend")
+    # constants
+    E(f"s_mov_b32 s{S_MASK}, 0xffff0000")
+    E(f"s_mov_b32 s{S_PERM}, 0x07060302")
+    E(f"s_mov_b32 s{S_OOB}, 0x7fff0000")
+    E(f"s_mul_i32 s{S_TXTY}, s{S_TX}, s{S_TY}")
+    E(f"s_mul_i32 s{S_IMGB}, s{S_H}, s{S_W}")
+    E(f"s_mul_i32 s{S_OUTIMGB}, s{S_IMGB}, s{S_LDOUT}")
+    E(f"s_lshl_b32 s{S_OUTIMGB}, s{S_OUTIMGB}, 2")
+    E(f"s_mul_i32 s{S_IMGB}, s{S_IMGB}, s{S_LDIN}")
+    E(f"s_lshl_b32 s{S_IMGB}, s{S_IMGB}, 2")
+    E(f"s_mul_i32 s{S_NTSTRIDE}, s{S_NC}, 0xc000")
+    E(f"s_lshl_b32 s{S_N64X4}, s{S_NBLOCK}, 8")
+    E(f"s_lshl_b32 s{S_LD4}, s{S_LDOUT}, 2")
+    E(f"s_mul_i32 s{S_SW4}, s{S_W}, s{S_LD4}")
+    E(f"s_add_u32 s{S_SUMOFF}, s{S_SW4}, s{S_LD4}")
+    # descriptors: input (base per patch), output (base per patch), pooled, scale, shift, weight pieces
+    E(f"s_mov_b32 s{S_INR + 2}, s{S_IMGB}")
+    E(f"s_mov_b32 s{S_INR + 3}, 0x00020000")
+    E(f"s_mov_b32 s{S_OUTR + 2}, s{S_OUTIMGB}")
+    E(f"s_mov_b32 s{S_OUTR + 3}, 0x00020000")
+    E(f"s_mov_b32 s{S_POOLR + 3}, 0x00020000")
+    for (r, p) in ((S_SCR, S_SCALE), (S_SHR, S_SHIFT)):
+        E(f"s_mov_b32 s{r}, s{p}")
+        E(f"s_and_b32 s{r + 1}, s{p + 1}, 0xffff")
+        E(f"s_mov_b32 s{r + 2}, 0x7ffffff0")
+        E(f"s_mov_b32 s{r + 3}, 0x00020000")
+    # wave roles
+    E(f"v_lshrrev_b32_e32 v0, 6, v{VTID}")
+    E("v_readfirstlane_b32 s60, v0")
+    E(f"s_and_b32 s{S_WI}, s60, 3")
+    E(f"s_lshr_b32 s{S_JP}, s60, 2")
+    E(f"s_lshl_b32 s61, s{S_WI}, 1")
+    E("s_lshr_b32 s62, 0x64, s61")
+    E("s_and_b32 s62, s62, 3")                      # ra
+    E("s_lshr_b32 s63, 0xda, s61")
+    E("s_and_b32 s63, s63, 3")                      # rb
+    E(f"s_cmp_eq_u32 s{S_WI}, 1")
+    E(f"s_cselect_b32 s{S_SGN}, 1.0, -1.0")
+    # weight descriptor: base = wu + nblock * 2 * nC * 49152 + (wi * 4 + 2 jp) * 3072
+    E(f"s_lshl_b32 s64, s{S_NTSTRIDE}, 1")                    # u_bytes of the workgroup's two n tiles
+    E(f"s_mul_i32 s65, s{S_NBLOCK}, s64")
+    E(f"s_lshl_b32 s66, s{S_WI}, 2")
+    E(f"s_lshl_b32 s67, s{S_JP}, 1")
+    E("s_add_u32 s66, s66, s67")
+    E("s_mul_i32 s66, s66, 0xc00")
+    E("s_add_u32 s65, s65, s66")
+    E(f"s_add_u32 s{S_UR}, s{S_WU}, s65")
+    E(f"s_addc_u32 s{S_UR + 1}, s{S_WU + 1}, 0")
+    E(f"s_and_b32 s{S_UR + 1}, s{S_UR + 1}, 0xffff")
+    E(f"s_mov_b32 s{S_UR + 2}, s64")
+    E(f"s_mov_b32 s{S_UR + 3}, 0x00020000")
+    # lane constants
+    E(f"v_and_b32_e32 v1, 63, v{VTID}")             # lane
+    E(f"v_lshlrev_b32_e32 v{VLANE16}, 4, v1")
+    E("v_and_b32_e32 v2, 31, v1")                   # lr
+    E("v_lshrrev_b32_e32 v3, 5, v1")                # lh
+    E("v_and_b32_e32 v4, 15, v2")                   # tx
+    E("v_lshrrev_b32_e32 v5, 4, v2")                # ty
+    E("v_lshlrev_b32_e32 v5, 1, v5")                # 2 ty
+    E("v_mul_u32_u24_e32 v4, 0x50, v4")             # tx * 80
+    E("v_lshl_add_u32 v4, v3, 5, v4")               # + lh * 32
+    for (dst, srow) in ((VA, 62), (VB, 63)):
+        E(f"v_add_u32_e32 v6, s{srow}, v5")
+        E("v_mul_u32_u24_e32 v6, 0xaa0, v6")        # (2 ty + r) * 34 * 80
+        E("v_add_u32_e32 v6, v6, v4")
+        E(f"v_add_u32_e32 v{dst}, 0x{BUFX:x}, v6")  # chunk 0 of a patch sits in slot 4
+    for i in range(3):
+        E(f"v_lshrrev_b32_e32 v1, 2, v{VTID}")
+        if i:
+            E(f"v_add_u32_e32 v1, {128 * i}, v1")
+        E("v_mul_u32_u24_e32 v2, 0x788, v1")
+        E("v_lshrrev_b32_e32 v2, 16, v2")           # r
+        E("v_mul_u32_u24_e32 v3, 34, v2")
+        E("v_sub_u32_e32 v3, v1, v3")               # cc
+        E("v_and_b32_e32 v4, 1, v3")
+        E("v_lshl_add_u32 v4, v2, 1, v4")           # r * 2 + (cc & 1)
+        E("v_mul_u32_u24_e32 v4, 17, v4")
+        E("v_lshrrev_b32_e32 v3, 1, v3")
+        E("v_add_u32_e32 v4, v4, v3")
+        E("v_mul_u32_u24_e32 v4, 0x50, v4")
+        E(f"v_and_b32_e32 v5, 3, v{VTID}")
+        E(f"v_lshl_add_u32 v{VHST[i]}, v5, 4, v4")
+    # pipeline lead-in
+    E(f"s_mov_b32 s{S_LC}, 0")
+    E(f"s_mov_b32 s{S_LP}, 0")
+    E(f"s_mov_b32 s{S_PI}, 0")
+    E(f"s_mov_b32 s{S_LC64}, 0")
+    setup_load()
+    halo_loads()                                     # chunk 0
+    for i in range(3):
+        E(f"v_xor_b32_e32 v{VHST[i]}, 0x{BUFX:x}, v{VHST[i]}")
+    E("s_waitcnt vmcnt(0)")
+    halo_stores()                                    # -> slot 4
+    for i in range(3):
+        E(f"v_xor_b32_e32 v{VHST[i]}, 0x{BUFX:x}, v{VHST[i]}")
+    lskip = newlabel("nosetup")
+    E(f"s_cmp_lg_u32 s{S_LC}, 0")
+    E(f"s_cbranch_scc1 {lskip}")
+    E(f"s_cmp_ge_u32 s{S_LP}, s{S_NPATCH}")
+    E(f"s_cbranch_scc1 {lskip}")
+    setup_load()
+    L(lskip)
+    halo_loads()                                     # chunk 1 -> halo registers
+    # weight pieces of chunk 0
+    E(f"s_mov_b32 s{S_WO[0][0]}, 0")
+    E(f"s_mov_b32 s{S_WO[0][1]}, s{S_NTSTRIDE}")
+    E(f"s_mov_b32 s{S_WO[1][0]}, 0xc00")
+    E(f"s_add_u32 s{S_WO[1][1]}, s{S_NTSTRIDE}, 0xc00")
+    for jj in range(2):
+        for nt in range(2):
+            for p in range(3):
+                E(weight_load(jj, nt, p))
+    for r in range(128):
+        E(f"v_mov_b32_e32 v{r}, 0")
+    E("s_waitcnt lgkmcnt(0)")
+    E("s_barrier")
+    E(f"s_cmp_lg_u32 s{S_JP}, 0")
+    E("s_cbranch_scc1 .Ljp1")
+
+
+def emit_first_form(jp):
+    """step 0 of the first chunk (no MFMAs to hide behind)"""
+    for r in raw_reads(jp, 0, 0):
+        E(r)
+    E("s_waitcnt lgkmcnt(0)")
+    for hf in range(2):
+        for x in form_valu(jp, 0, 0, hf):
+            E(x)
+
+
+def main():
+    path = sys.argv[1]
+    name = "mgu_wino_cp2_gfx950"
+    hdr = f"""\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+\t.text
+\t.protected\t{name}
+\t.globl\t{name}
+\t.p2align\t8
+\t.type\t{name},@function
+{name}:"""
+    out.append(hdr)
+    emit_prologue()
+    emit_first_form(0)
+    emit_patch_loop(0)
+    L(".Ljp1")
+    emit_first_form(1)
+    emit_patch_loop(1)
+    L(".Lend")
+    E("s_endpgm")
+    out.append(f"""\t.section\t.rodata,"a",@progbits
+\t.p2align\t6, 0x0
+\t.amdhsa_kernel {name}
+\t\t.amdhsa_group_segment_fixed_size 163840
+\t\t.amdhsa_private_segment_fixed_size 0
+\t\t.amdhsa_kernarg_size 120
+\t\t.amdhsa_user_sgpr_count 2
+\t\t.amdhsa_user_sgpr_dispatch_ptr 0
+\t\t.amdhsa_user_sgpr_queue_ptr 0
+\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
+\t\t.amdhsa_user_sgpr_dispatch_id 0
+\t\t.amdhsa_user_sgpr_kernarg_preload_length 0
+\t\t.amdhsa_user_sgpr_kernarg_preload_offset 0
+\t\t.amdhsa_user_sgpr_private_segment_size 0
+\t\t.amdhsa_uses_dynamic_stack 0
+\t\t.amdhsa_enable_private_segment 0
+\t\t.amdhsa_system_sgpr_workgroup_id_x 1
+\t\t.amdhsa_system_sgpr_workgroup_id_y 0
+\t\t.amdhsa_system_sgpr_workgroup_id_z 0
+\t\t.amdhsa_system_sgpr_workgroup_info 0
+\t\t.amdhsa_system_vgpr_workitem_id 0
+\t\t.amdhsa_next_free_vgpr 256
+\t\t.amdhsa_next_free_sgpr 102
+\t\t.amdhsa_accum_offset 256
+\t\t.amdhsa_reserve_vcc 1
+\t\t.amdhsa_float_round_mode_32 0
+\t\t.amdhsa_float_round_mode_16_64 0
+\t\t.amdhsa_float_denorm_mode_32 3
+\t\t.amdhsa_float_denorm_mode_16_64 3
+\t\t.amdhsa_dx10_clamp 1
+\t\t.amdhsa_ieee_mode 1
+\t\t.amdhsa_fp16_overflow 0
+\t\t.amdhsa_tg_split 0
+\t.end_amdhsa_kernel
+\t.text
+.Lfunc_end0:
+\t.size\t{name}, .Lfunc_end0-{name}
+\t.amdgpu_metadata
+---
+amdhsa.kernels:
+  - .agpr_count:     0
+    .args:
+      - .offset:         0
+        .size:           120
+        .value_kind:     by_value
+    .group_segment_fixed_size: 163840
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: 120
+    .max_flat_workgroup_size: 512
+    .name:           {name}
+    .private_segment_fixed_size: 0
+    .sgpr_count:     108
+    .sgpr_spill_count: 0
+    .symbol:         {name}.kd
+    .uniform_work_group_size: 1
+    .uses_dynamic_stack: false
+    .vgpr_count:     256
+    .vgpr_spill_count: 0
+    .wavefront_size: 64
+amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+amdhsa.version:
+  - 1
+  - 2
+...
+
+\t.end_amdgpu_metadata
+""")
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,7 @@ struct Tuning {
   bool gat_fused = true;    // MGU_NO_GAT_FUSED=1
   bool wino_ures = true;    // MGU_NO_WINO_URES=1: the 32-input-channel narrow layers reload their weight pieces every chunk (A/B)
   bool wino_prio = false;   // MGU_WINO_PRIO=1: s_setprio 1 for waves 4-7 of the component-pair Winograd kernels (A/B)
+  bool wino_asm = false;    // MGU_WINO_ASM=1: the hand-scheduled assembly form of the wide component-pair kernel (wino_asm.hip) where it applies
 };
 const Tuning& default_tuning();
 // The >64 KB dynamic-LDS opt-in is a per-DEVICE function attribute: set it once per (kernel, device).
@@ -140,6 +141,9 @@ bool wino_pack_batch_prepare(WinoPackBatch& b);   // fills Np / blk0 / total_blo
 hipError_t launch_pack_wino_w_multi(const WinoPackBatch* batch_dev, unsigned total_blocks, hipStream_t s);
 bool wino_applicable(const IgemmDesc& d);
 hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s);
+// wino_asm.hip: the assembly form of wino3x3_cp_kernel<2> (bitwise equal results)
+bool wino_asm_applicable(const IgemmDesc& d);
+hipError_t launch_wino_cp_asm(const IgemmDesc& d, hipStream_t s);
 
 // wgrad_f32.hip:  Dw[n][k] += sum_m Z[m][n] * A(m,k)   (A = the forward kernels' im2col gather)
 struct WgradDesc {
