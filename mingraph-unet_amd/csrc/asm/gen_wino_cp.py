@@ -19,7 +19,10 @@ W % 32 == 0, N % 64 == 0, Cp % 32 == 0, channel pitches and offsets % 4 == 0, sc
 
 Usage: gen_wino_cp.py OUT.s
 """
+import os
 import sys
+
+DEBUG = os.environ.get("GEN_WINO_DEBUG", "")
 
 # ---------------------------------------------------------------------------------------------------------------------
 # register map
@@ -375,6 +378,12 @@ def emit_epilogue(jp):
         for q in range(2):
             E(f"s_mov_b32 m0, s{S_T[q]}")
             E("s_nop 0")
+            if "noaddtid" in DEBUG:   # ordinary stores with a VGPR address (debug A/B of the add-TID form)
+                E(f"v_and_b32_e32 v{e0}, 63, v{VTID}")
+                E(f"v_lshlrev_b32_e32 v{e0}, 2, v{e0}")
+                E(f"v_add_u32_e32 v{e0}, s{S_T[q]}, v{e0}")
+                if q:
+                    E(f"v_add_u32_e32 v{e0}, 0x{ZBIAS:x}, v{e0}")
             g = 0
             for mi in range(2):
                 for r0 in range(0, 16, 4):
@@ -385,7 +394,10 @@ def emit_epilogue(jp):
                     E("s_nop 0")
                     for k in range(4):
                         off = (32 * mi + 2 * (r0 + k)) * 128 + (ZBIAS if q else 0)
-                        E(f"ds_write_addtid_b32 v{ts[k]} offset:{off}")
+                        if "noaddtid" in DEBUG:
+                            E(f"ds_write_b32 v{e0}, v{ts[k]} offset:{off - (ZBIAS if q else 0)}")
+                        else:
+                            E(f"ds_write_addtid_b32 v{ts[k]} offset:{off}")
         E("s_waitcnt lgkmcnt(0)")
         E("s_barrier")
         # finishing pass of unit (T, cq): 16 share reads into the dead accumulators of this n tile
@@ -507,7 +519,10 @@ def emit_prologue():
         E(f"s_mov_b32 s{r + 3}, 0x00020000")
     # wave roles
     E(f"v_lshrrev_b32_e32 v0, 6, v{VTID}")
+    E("s_nop 3")                                    # VALU write -> v_readfirstlane of the same register: wait states (measured: without
+    #                                                 them some waves read the OLD v0 = the thread id)
     E("v_readfirstlane_b32 s60, v0")
+    E("s_nop 3")
     E(f"s_and_b32 s{S_WI}, s60, 3")
     E(f"s_lshr_b32 s{S_JP}, s60, 2")
     E(f"s_lshl_b32 s61, s{S_WI}, 1")
@@ -595,8 +610,22 @@ def emit_prologue():
         E(f"v_mov_b32_e32 v{r}, 0")
     E("s_waitcnt lgkmcnt(0)")
     E("s_barrier")
-    E(f"s_cmp_lg_u32 s{S_JP}, 0")
-    E("s_cbranch_scc1 .Ljp1")
+
+
+def emit_dump(first_reg):
+    """debug: thread tid stores 32 consecutive registers at out + tid * 128 bytes and the program ends"""
+    E("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    E("s_nop 7")
+    E("s_nop 7")
+    E(f"s_mov_b32 s{S_OUTR}, s{S_OUT}")
+    E(f"s_and_b32 s{S_OUTR + 1}, s{S_OUT + 1}, 0xffff")
+    E(f"s_mov_b32 s{S_OUTR + 2}, 0x7ffffff0")
+    E(f"s_mov_b32 s{S_OUTR + 3}, 0x00020000")
+    E(f"v_lshlrev_b32_e32 v{VT0}, 7, v{VTID}")
+    for k in range(8):
+        E(f"buffer_store_dwordx4 {vr(first_reg + 4 * k, 4)}, v{VT0}, s[{S_OUTR}:{S_OUTR + 3}], 0 offen offset:{16 * k}")
+    E("s_waitcnt vmcnt(0)")
+    E("s_endpgm")
 
 
 def emit_first_form(jp):
@@ -621,6 +650,14 @@ def main():
 {name}:"""
     out.append(hdr)
     emit_prologue()
+    if DEBUG.startswith("dump_pro:"):      # registers after the lead-in (raw reads of step 0 are issued but not transformed)
+        for r in raw_reads(0, 0, 0):
+            E(r)
+        for i, sr in enumerate((S_SGN, S_WI, S_JP, 60, 61, 62, 63, S_NBLOCK, S_PBEGIN, S_NPATCH, S_LC, S_LP, S_NC, S_UR, S_UR + 1, S_UR + 2)):
+            E(f"v_mov_b32_e32 v{224 + i}, s{sr}")
+        emit_dump(int(DEBUG.split(":")[1]))
+    E(f"s_cmp_lg_u32 s{S_JP}, 0")
+    E("s_cbranch_scc1 .Ljp1")
     emit_first_form(0)
     emit_patch_loop(0)
     L(".Ljp1")
