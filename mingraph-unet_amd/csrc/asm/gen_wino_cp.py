@@ -23,6 +23,15 @@ import os
 import sys
 
 DEBUG = os.environ.get("GEN_WINO_DEBUG", "")
+# Options of the kernel being emitted (main() emits the shipping kernel and, with GEN_WINO_VARIANTS=1, timing-only variants):
+#   no_epilogue   timing only: no inverse transform / stores (accumulators cleared)
+#   no_valu       timing only: no input transform / split in the chunk loop (operand pieces stay constant)
+#   no_mfma       timing only: no MFMAs in the chunk loop
+#   no_barrier    timing only: no s_barrier in the chunk loop
+#   b1_step       step in front of which barrier B1 sits (2 or 3)
+#   valu_from     first MFMA gap of a step that carries transform work
+OPT = {}
+def opt(k, d=None): return OPT.get(k, d)
 
 # ---------------------------------------------------------------------------------------------------------------------
 # register map
@@ -136,8 +145,8 @@ def setup_load():
         E(f"v_cndmask_b32_e32 v{d}, v{d}, v{VT1}, vcc")
 
 
-def halo_loads():
-    for i in range(3):
+def halo_loads(issue=True):
+    for i in range(3 if issue else 0):
         E(f"buffer_load_dwordx4 {vr(HREG(i), 4)}, v{VHOFF[i]}, s[{S_INR}:{S_INR + 3}], s{S_LC64} offen")
     # lc = lc + 1 == nC ? 0 : lc + 1;  lp += lc == 0
     E(f"s_add_u32 s{S_LC}, s{S_LC}, 1")
@@ -204,45 +213,143 @@ def weight_load(jj, nt, p):
     return f"buffer_load_dwordx4 {vr(BX(jj, nt, p), 4)}, v{VLANE16}, s[{S_UR}:{S_UR + 3}], s{S_WO[jj][nt]} offen offset:{p * 1024}"
 
 
+STAMP_PAIRS = [60, 62, 64, 66, 70, 72, 74, 76]
+def stamp(i):
+    """timing-only (steptimes): s_memtime into pair i; placed only where no LDS read is in flight (lgkmcnt returns out of order with SMEM)"""
+    if opt("steptimes"):
+        E(f"s_memtime s[{STAMP_PAIRS[i]}:{STAMP_PAIRS[i] + 1}]")
+        E("s_waitcnt lgkmcnt(0)")
+
+
+def emit_step_spread(jp, s):
+    """Step s with the raw-operand reads spread over the MFMA gaps (at most two ds_read_b128 per gap, none waited for in the
+    step it was issued in): the raw registers are two halves of four 16-byte registers (input channels 0-3 / 4-7 of the lane's
+    eight); half 0 of step s + 2 is requested in gaps 7-8 of step s (its registers are free once the first half of step s + 1's
+    transform has run), half 1 of step s + 1 in gaps 0-1.  Reads of the next chunk begin in gap 7 of step 2: B1 sits in front
+    of step 2 and the read bases flip to the other buffer inside it."""
+    jj, mi, slot = s >> 1, s & 1, s & 1
+    n1, n2 = (s + 1) & 3, (s + 2) & 3
+    stamp((2, 3, 4, 6)[s])                # starts of steps 0, 1; arrival at B1; start of step 3
+    if s == 2:
+        E("s_waitcnt lgkmcnt(0)")
+        if not opt("no_barrier"):
+            E("s_barrier")                # B1: chunk c + 1 is complete in the other buffer
+        stamp(5)
+    if s in (0, 2):
+        E("s_waitcnt vmcnt(9)")           # this component's weight pieces (requested a chunk ago)
+    mf = mfmas(jj, mi, slot)
+    v0 = form_valu(jp, n1 >> 1, slot ^ 1, 0)
+    v1 = form_valu(jp, n1 >> 1, slot ^ 1, 1)
+    if opt("no_valu"):
+        v0, v1 = [], []
+    r1 = raw_reads(jp, n1 >> 1, n1 & 1)[4:8]        # half 1 of the next step
+    r2 = raw_reads(jp, n2 >> 1, n2 & 1)[0:4]        # half 0 of the step after it
+    if opt("no_ldsread"):
+        r1, r2 = [], []
+    wl = {}
+    if mi == 1 and not opt("no_wload"):
+        wl = {1: [weight_load(jj, 0, 2)], 4: [weight_load(jj, 0, 1)], 5: [weight_load(jj, 0, 0)],
+              7: [weight_load(jj, 1, 2)], 10: [weight_load(jj, 1, 1)], 11: [weight_load(jj, 1, 0)]}
+    def take(lst, n):
+        for _ in range(min(n, len(lst))):
+            E(lst.pop(0))
+    extra = {}
+    if s == 0 and opt("stage_in_step0", 1):
+        # Parking chunk c + 1 (halo registers -> the idle buffer) and requesting chunk c + 2 ride in the gaps of step 0 instead of
+        # standing in front of it: the matrix pipe starts right behind B0.  vmcnt(9) above covers the halo registers (they are
+        # older than the weight pieces it waits for).
+        if not opt("no_halo"):
+            for i in range(3):
+                extra.setdefault(i, []).append(f"ds_write_b128 v{VHST[i]}, {vr(HREG(i), 4)}")
+            for i in range(3):
+                extra.setdefault(3 + i, []).append(f"buffer_load_dwordx4 {vr(HREG(i), 4)}, v{VHOFF[i]}, s[{S_INR}:{S_INR + 3}], s{S_LC64} offen")
+        extra.setdefault(6, []).extend([
+            f"s_add_u32 s{S_LC}, s{S_LC}, 1", f"s_cmp_eq_u32 s{S_LC}, s{S_NC}", f"s_cselect_b32 s{S_LC}, 0, s{S_LC}",
+            f"s_cmp_eq_u32 s{S_LC}, 0", f"s_addc_u32 s{S_LP}, s{S_LP}, 0", f"s_lshl_b32 s{S_LC64}, s{S_LC}, 6"])
+        extra.setdefault(3, []).extend([f"v_xor_b32_e32 v{VHST[i]}, 0x{BUFX:x}, v{VHST[i]}" for i in range(3)])
+    a0, a1 = opt("sp_v0", (2, 6)), opt("sp_v1", (7, 10))      # gap ranges of the two transform halves
+    per0 = -(-34 // (a0[1] - a0[0] + 1))
+    per1 = -(-34 // (a1[1] - a1[0] + 1))
+    for k in range(12):
+        if not opt("no_mfma"):
+            E(mf[k])
+        for x in wl.get(k, []):
+            E(x)
+        for x in extra.get(k, []):
+            E(x)
+        if k in (0, 1):
+            take(r1, 2)
+        if k == a0[0]:
+            # half 0 (requested in the previous step); the four reads of half 1 (and step 0's three halo stores) may be in flight
+            E(f"s_waitcnt lgkmcnt({7 if extra and not opt('no_halo') else 4})")
+        if a0[0] <= k <= a0[1]:
+            take(v0, per0)
+        if k == a1[0]:
+            assert not v0
+            E("s_waitcnt lgkmcnt(0)")
+            if s == 2:
+                E(f"v_xor_b32_e32 v{VA}, 0x{BUFX:x}, v{VA}")
+                E(f"v_xor_b32_e32 v{VB}, 0x{BUFX:x}, v{VB}")
+        if k in (a1[0], a1[0] + 1):
+            take(r2, 2)
+        if a1[0] <= k <= a1[1]:
+            take(v1, per1)
+    assert not v1 and not r1 and not r2
+
+
 def emit_step(jp, s):
+    if opt("spread", 1):
+        return emit_step_spread(jp, s)
     jj, mi, slot = s >> 1, s & 1, s & 1
     ns = (s + 1) & 3
     njj, nmi = ns >> 1, ns & 1
     if s == 2:
         pass
-    if s == 3:
-        # B1: chunk c + 1 is complete in the other buffer; this step's reads are the next chunk's step 0
+    stamp(2 + s if s < 3 else 5)         # 2, 3, 4: starts of steps 0..2; 5: arrival at B1
+    if s == opt("b1_step", 3):
+        # B1: chunk c + 1 is complete in the other buffer (step 3's reads are the next chunk's step 0)
         E("s_waitcnt lgkmcnt(0)")
-        E("s_barrier")
+        if not opt("no_barrier"):
+            E("s_barrier")
+        stamp(6)
+    if s == 3:
         E(f"v_xor_b32_e32 v{VA}, 0x{BUFX:x}, v{VA}")
         E(f"v_xor_b32_e32 v{VB}, 0x{BUFX:x}, v{VB}")
-    for r in raw_reads(jp, njj, nmi):
-        E(r)
+    if not opt("no_ldsread"):
+        for r in raw_reads(jp, njj, nmi):
+            E(r)
     if s in (0, 2):
         E("s_waitcnt vmcnt(9)")          # this component's weight pieces (requested a chunk ago)
     mf = mfmas(jj, mi, slot)
     v0 = form_valu(jp, njj, slot ^ 1, 0)
     v1 = form_valu(jp, njj, slot ^ 1, 1)
     wl = {}
-    if mi == 1:   # pieces of the next chunk into the registers this step has finished with
+    if mi == 1 and not opt("no_wload"):   # pieces of the next chunk into the registers this step has finished with
         wl = {1: [weight_load(jj, 0, 2)], 4: [weight_load(jj, 0, 1)], 5: [weight_load(jj, 0, 0)],
               7: [weight_load(jj, 1, 2)], 10: [weight_load(jj, 1, 1)], 11: [weight_load(jj, 1, 0)]}
     def take(lst, n):
         for _ in range(min(n, len(lst))):
             E(lst.pop(0))
+    if opt("no_valu"):
+        v0, v1 = [], []
+    f0 = opt("valu_from", 2)                     # first gap with transform work
+    n0 = 5 if f0 >= 2 else 6 - f0                # gaps of the first half
+    per0 = -(-34 // n0)
+    per1 = -(-34 // (10 - (f0 + n0 - 1)))
     for k in range(12):
-        E(mf[k])
+        if not opt("no_mfma"):
+            E(mf[k])
         for x in wl.get(k, []):
             E(x)
-        if k == 2:
+        if k == f0:
             E("s_waitcnt lgkmcnt(4)")
-        if 2 <= k <= 6:
-            take(v0, 7)
-        if k == 6:
+        if f0 <= k < f0 + n0:
+            take(v0, per0)
+        if k == f0 + n0 - 1:
             assert not v0
             E("s_waitcnt lgkmcnt(0)")
-        if 7 <= k <= 10:
-            take(v1, 9)
+        if f0 + n0 <= k <= 10:
+            take(v1, per1)
     assert not v1
 
 
@@ -256,12 +363,18 @@ def emit_chunk(jp):
     setup_load()
     L(lskip)
     E("s_waitcnt lgkmcnt(0)")
-    E("s_barrier")                        # B0
-    E("s_waitcnt vmcnt(12)")              # the halo registers (two sets of weight pieces are younger)
-    halo_stores()
-    halo_loads()
-    for i in range(3):
-        E(f"v_xor_b32_e32 v{VHST[i]}, 0x{BUFX:x}, v{VHST[i]}")
+    stamp(0)                              # arrival at B0
+    if not opt("no_barrier"):
+        E("s_barrier")                    # B0
+    stamp(1)
+    inl = opt("spread", 1) and opt("stage_in_step0", 1)
+    if not inl:
+        E("s_waitcnt vmcnt(12)")          # the halo registers (two sets of weight pieces are younger)
+        if not opt("no_halo"):
+            halo_stores()
+        halo_loads(not opt("no_halo"))
+        for i in range(3):
+            E(f"v_xor_b32_e32 v{VHST[i]}, 0x{BUFX:x}, v{VHST[i]}")
     # weight soffsets of chunk cn = c + 1 == nC ? 0 : c + 1
     E(f"s_add_u32 s{S_T[0]}, s{S_C}, 1")
     E(f"s_cmp_eq_u32 s{S_T[0]}, s{S_NC}")
@@ -272,16 +385,49 @@ def emit_chunk(jp):
     E(f"s_add_u32 s{S_WO[1][1]}, s{S_WO[0][1]}, 0xc00")
     for s in range(4):
         emit_step(jp, s)
+    if opt("steptimes"):                  # stamp 7: end of the chunk; chunk 8's stamps -> out[(wg * 8 + wave) * 8 ..]
+        E("s_waitcnt lgkmcnt(0)")
+        E("s_memtime s[92:93]")
+        E("s_waitcnt lgkmcnt(0)")
+        lno = newlabel("nostore")
+        E(f"s_cmp_lg_u32 s{S_C}, 8")
+        E(f"s_cbranch_scc1 {lno}")
+        E(f"s_mov_b32 s{S_OUTR}, s{S_OUT}")
+        E(f"s_and_b32 s{S_OUTR + 1}, s{S_OUT + 1}, 0xffff")
+        E(f"s_mov_b32 s{S_OUTR + 2}, 0x7ffffff0")
+        E(f"s_mov_b32 s{S_OUTR + 3}, 0x00020000")
+        E("s_lshl_b32 s94, s2, 3")
+        E(f"s_lshl_b32 s95, s{S_JP}, 2")
+        E(f"s_add_u32 s95, s95, s{S_WI}")
+        E("s_add_u32 s94, s94, s95")
+        E("s_lshl_b32 s94, s94, 5")
+        E("s_mov_b64 s[96:97], exec")
+        E(f"v_and_b32_e32 v{VT0}, 63, v{VTID}")
+        E(f"v_cmp_eq_u32_e32 vcc, 0, v{VT0}")
+        E("s_and_b64 exec, exec, vcc")
+        for k in range(4):
+            a, b = STAMP_PAIRS[2 * k], (STAMP_PAIRS[2 * k + 1] if k < 3 else 92)
+            if k == 3:
+                a = STAMP_PAIRS[6]
+            E(f"v_mov_b32_e32 v{VT0}, s{a}")
+            E(f"v_mov_b32_e32 v{VT1}, s{b}")
+            E(f"v_mov_b32_e32 v{VHOFF[0]}, 0")
+            E(f"buffer_store_dwordx2 v[{VT0}:{VT1}], v{VHOFF[0]}, s[{S_OUTR}:{S_OUTR + 3}], s94 offen offset:{8 * k}")
+            E("s_waitcnt vmcnt(0)")
+        E("s_mov_b64 exec, s[96:97]")
+        L(lno)
 
 
 def emit_epilogue(jp):
-    E0 = 188                              # 44 free registers v188..v231 (second operand slot + raw operands)
+    # free registers: the second operand slot (v188..v199) and raw half 1 (v216..v231); raw half 0 holds the next patch's
+    # first reads (spread schedule) and stays untouched
+    E0 = 188
     CQ, VT = VT0, VT1
     VZ0, VZ1, VOUT, VPOOL = E0 + 0, E0 + 1, E0 + 2, E0 + 3
     SCW = [E0 + 4, E0 + 5]
     SHW = [E0 + 6, E0 + 7]
-    TMP = [E0 + 8 + i for i in range(8)]
-    e0, e1, e2, e3 = E0 + 16, E0 + 17, E0 + 18, E0 + 19
+    e0, e1, e2, e3 = E0 + 8, E0 + 9, E0 + 10, E0 + 11
+    TMP = [216 + i for i in range(8)]
     E("s_nop 7")
     E("s_nop 7")
     E("s_nop 7")
@@ -448,10 +594,14 @@ def emit_epilogue(jp):
             E(f"v_max_f32_e32 v{pm + e}, v{pm + e}, v{Z(0, 0, 1) + e}")
         E(f"buffer_store_dwordx4 {vr(pm, 4)}, v{VPOOL}, s[{S_POOLR}:{S_POOLR + 3}], 0 offen offset:{nt * 128}")
         L(lnp)
+        # this n tile's accumulators (the registers of the finishing pass) are cleared for the next patch here, beside the
+        # stores and in front of the barrier wait (one instruction of distance to the last store's data registers)
+        E("s_nop 1")
+        for b in sorted(zb):
+            for r in range(16):
+                E(f"v_mov_b32_e32 v{b + r}, 0")
         E("s_waitcnt lgkmcnt(0)")
         E("s_barrier")                   # the regions are rewritten by the next pass / receive the next raw chunk
-    for r in range(128):
-        E(f"v_mov_b32_e32 v{r}, 0")
 
 
 def emit_patch_loop(jp):
@@ -463,11 +613,37 @@ def emit_patch_loop(jp):
     E(f"s_add_u32 s{S_C}, s{S_C}, 1")
     E(f"s_cmp_lt_u32 s{S_C}, s{S_NC}")
     E(f"s_cbranch_scc1 {lc}")
-    emit_epilogue(jp)
+    if opt("no_epilogue"):
+        E("s_nop 7")
+        E("s_nop 7")
+        for r in range(128):
+            E(f"v_mov_b32_e32 v{r}, 0")
+    else:
+        emit_epilogue(jp)
     E(f"s_add_u32 s{S_PI}, s{S_PI}, 1")
     E(f"s_cmp_lt_u32 s{S_PI}, s{S_NPATCH}")
     E(f"s_cbranch_scc1 {lp}")
-    E("s_branch .Lend")
+    if opt("stamp"):                 # (cycles, 100 MHz ticks) of the workgroup's life -> out[2 * wg .. 2 * wg + 1] (wave 0 writes)
+        E("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        E("s_memtime s[60:61]")
+        E("s_memrealtime s[62:63]")
+        E("s_waitcnt lgkmcnt(0)")
+        E(f"s_sub_u32 s60, s60, s{S_PAD}")
+        E(f"s_sub_u32 s62, s62, s{S_W1}")
+        E("v_mov_b32_e32 v0, s60")
+        E("v_mov_b32_e32 v1, s62")
+        E(f"s_mov_b32 s{S_OUTR}, s{S_OUT}")
+        E(f"s_and_b32 s{S_OUTR + 1}, s{S_OUT + 1}, 0xffff")
+        E(f"s_mov_b32 s{S_OUTR + 2}, 0x7ffffff0")
+        E(f"s_mov_b32 s{S_OUTR + 3}, 0x00020000")
+        E("s_lshl_b32 s61, s2, 3")
+        E(f"v_cmp_eq_u32_e32 vcc, 0, v{VTID}")
+        E("s_and_saveexec_b64 s[64:65], vcc")
+        E("v_mov_b32_e32 v2, 0")
+        E(f"buffer_store_dwordx2 v[0:1], v2, s[{S_OUTR}:{S_OUTR + 3}], s61 offen")
+        E("s_waitcnt vmcnt(0)")
+        E("s_mov_b64 exec, s[64:65]")
+    E(f"s_branch {END_LABEL}")
 
 
 def emit_prologue():
@@ -477,6 +653,12 @@ def emit_prologue():
     E("s_load_dwordx2 s[32:33], s[0:1], 0x70")
     E(f"v_mov_b32_e32 v{VTID}, v0")
     E("s_waitcnt lgkmcnt(0)")
+    if opt("stamp"):                 # timing-only: shader clock and 100 MHz real-time counter at the start of the workgroup
+        E("s_memtime s[60:61]")
+        E("s_memrealtime s[62:63]")
+        E("s_waitcnt lgkmcnt(0)")
+        E(f"s_mov_b32 s{S_PAD}, s60")
+        E(f"s_mov_b32 s{S_W1}, s62")
     # item = (wg & 7) * per_xcd + (wg >> 3)
     t = S_T
     E(f"s_and_b32 s{t[0]}, s2, 7")
@@ -484,13 +666,13 @@ def emit_prologue():
     E(f"s_lshr_b32 s{t[1]}, s2, 3")
     E(f"s_add_u32 s{t[0]}, s{t[0]}, s{t[1]}")
     E(f"s_cmp_ge_u32 s{t[0]}, s{S_NITEMS}")
-    E("s_cbranch_scc1 .Lend")
+    E(f"s_cbranch_scc1 {END_LABEL}")
     divmod_magic(t[0], S_NGROUPS, S_MGNG, S_NBLOCK, t[1], t[2], t[3])
     E(f"s_mul_i32 s{S_PBEGIN}, s{t[1]}, s{S_PPB}")
     E(f"s_sub_i32 s{t[2]}, s{S_TOTAL}, s{S_PBEGIN}")
     E(f"s_min_i32 s{S_NPATCH}, s{S_PPB}, s{t[2]}")
     E(f"s_cmp_lt_i32 s{S_NPATCH}, 1")
-    E("s_cbranch_scc1 .Lend")
+    E(f"s_cbranch_scc1 {END_LABEL}")
     # constants
     E(f"s_mov_b32 s{S_MASK}, 0xffff0000")
     E(f"s_mov_b32 s{S_PERM}, 0x07060302")
@@ -636,19 +818,25 @@ def emit_first_form(jp):
     for hf in range(2):
         for x in form_valu(jp, 0, 0, hf):
             E(x)
+    if opt("spread", 1):
+        for r in raw_reads(jp, 0, 1)[0:4]:
+            E(r)
 
 
-def main():
-    path = sys.argv[1]
-    name = "mgu_wino_cp2_gfx950"
-    hdr = f"""\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
-\t.text
+def emit_kernel(name):
+    _lbl[0] += 1000
+    end = f".Lend_{name}"
+    jp1 = f".Ljp1_{name}"
+    fe = f".Lfunc_end_{name}"
+    hdr = f"""\t.text
 \t.protected\t{name}
 \t.globl\t{name}
 \t.p2align\t8
 \t.type\t{name},@function
 {name}:"""
     out.append(hdr)
+    global END_LABEL
+    END_LABEL = end
     emit_prologue()
     if DEBUG.startswith("dump_pro:"):      # registers after the lead-in (raw reads of step 0 are issued but not transformed)
         for r in raw_reads(0, 0, 0):
@@ -657,13 +845,17 @@ def main():
             E(f"v_mov_b32_e32 v{224 + i}, s{sr}")
         emit_dump(int(DEBUG.split(":")[1]))
     E(f"s_cmp_lg_u32 s{S_JP}, 0")
-    E("s_cbranch_scc1 .Ljp1")
+    E(f"s_cbranch_scc1 {jp1}")
+    if opt("prio_jp0"):
+        E(f"s_setprio {opt('prio_jp0')}")
     emit_first_form(0)
     emit_patch_loop(0)
-    L(".Ljp1")
+    L(jp1)
+    if opt("prio_jp1"):      # static priority for the second-dispatched half (the SIMD partners of waves 0-3)
+        E(f"s_setprio {opt('prio_jp1')}")
     emit_first_form(1)
     emit_patch_loop(1)
-    L(".Lend")
+    L(end)
     E("s_endpgm")
     out.append(f"""\t.section\t.rodata,"a",@progbits
 \t.p2align\t6, 0x0
@@ -700,12 +892,10 @@ def main():
 \t\t.amdhsa_tg_split 0
 \t.end_amdhsa_kernel
 \t.text
-.Lfunc_end0:
-\t.size\t{name}, .Lfunc_end0-{name}
-\t.amdgpu_metadata
----
-amdhsa.kernels:
-  - .agpr_count:     0
+{fe}:
+\t.size\t{name}, {fe}-{name}
+""")
+    META.append(f"""  - .agpr_count:     0
     .args:
       - .offset:         0
         .size:           120
@@ -723,8 +913,45 @@ amdhsa.kernels:
     .uses_dynamic_stack: false
     .vgpr_count:     256
     .vgpr_spill_count: 0
-    .wavefront_size: 64
-amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+    .wavefront_size: 64""")
+
+
+META = []
+END_LABEL = ".Lend"
+VARIANTS = [   # (kernel-name suffix, options); suffix "" = the shipping kernel
+    ("", {}),
+]
+if os.environ.get("GEN_WINO_VARIANTS"):
+    VARIANTS += [
+        ("_v1", {"no_epilogue": 1}),
+        ("_v2", {"no_epilogue": 1, "no_valu": 1}),
+        ("_v3", {"no_epilogue": 1, "no_mfma": 1}),
+        ("_v4", {"no_epilogue": 1, "no_barrier": 1}),
+        ("_v5", {"stage_in_step0": 0}),
+        ("_v6", {"prio_jp1": 3}),
+        ("_v7", {"prio_jp0": 1}),
+        ("_v8", {"no_epilogue": 1, "stamp": 1}),
+        ("_v9", {"no_epilogue": 1, "no_valu": 1, "stamp": 1}),
+        ("_v10", {"no_epilogue": 1, "no_mfma": 1, "stamp": 1}),
+        ("_v11", {"no_epilogue": 1, "no_wload": 1, "stamp": 1}),
+        ("_v12", {"no_epilogue": 1, "no_halo": 1, "stamp": 1}),
+        ("_v13", {"no_epilogue": 1, "no_ldsread": 1, "stamp": 1}),
+        ("_v15", {"no_epilogue": 1, "steptimes": 1}),
+        ("_v16", {"no_epilogue": 1, "steptimes": 1, "prio_jp1": 1}),
+        ("_v14", {"no_epilogue": 1, "no_wload": 1, "no_halo": 1, "no_ldsread": 1, "no_valu": 1, "no_barrier": 1, "stamp": 1}),
+    ]
+
+
+def main():
+    path = sys.argv[1]
+    out.append('\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+    for suffix, o in VARIANTS:
+        OPT.clear()
+        OPT.update(o)
+        emit_kernel("mgu_wino_cp2_gfx950" + suffix)
+    out.append("\t.amdgpu_metadata\n---\namdhsa.kernels:")
+    out.extend(META)
+    out.append("""amdhsa.target:   amdgcn-amd-amdhsa--gfx950
 amdhsa.version:
   - 1
   - 2

@@ -88,7 +88,7 @@ int mgu_create(int device_id, mgu_ctx** out) {
   t.gat_fused = !flag("MGU_NO_GAT_FUSED");
   t.wino_ures = !flag("MGU_NO_WINO_URES");
   t.wino_prio = flag("MGU_WINO_PRIO");
-  t.wino_asm = num("MGU_WINO_ASM", 0) != 0;
+  t.wino_asm = std::max(0, num("MGU_WINO_ASM", t.wino_asm));
   *out = c;
   return MGU_OK;
 }

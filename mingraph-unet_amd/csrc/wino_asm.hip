@@ -6,6 +6,8 @@
 // (tests/test_gpu_wino_asm.py).  The code object is loaded once per device through the module API; everything the assembly
 // does not cover (ragged sizes, statistics epilogue, odd chunk counts, missing scale / shift) stays on the C++ kernel.
 #include "common.h"
+#include <algorithm>
+#include <cstdio>
 #include <mutex>
 
 extern "C" const unsigned char mgu_wino_cp2_hsaco[];
@@ -50,8 +52,10 @@ Plan plan_of(const IgemmDesc& d) {
   return p;
 }
 
+constexpr int MAX_VARIANTS = 24;   // wino_asm = 1: the shipping kernel; n > 1: timing-only variant _v(n-1) of a GEN_WINO_VARIANTS=1 build
 std::mutex g_mu;
-hipFunction_t g_fn[64] = {};   // one loaded function per device, written once under g_mu, immutable afterwards
+hipModule_t g_mod[64] = {};
+hipFunction_t g_fn[64][MAX_VARIANTS] = {};   // loaded functions per device, written once under g_mu, immutable afterwards
 }  // namespace
 
 bool wino_asm_applicable(const IgemmDesc& d) {
@@ -71,16 +75,21 @@ hipError_t launch_wino_cp_asm(const IgemmDesc& d, hipStream_t s) {
   if (e != hipSuccess) return e;
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   hipFunction_t fn;
+  const int var = std::min(std::max(tun(d).wino_asm, 1), MAX_VARIANTS) - 1;
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_fn[dev]) {
-      hipModule_t mod;
-      e = hipModuleLoadData(&mod, mgu_wino_cp2_hsaco);
-      if (e != hipSuccess) return e;
-      e = hipModuleGetFunction(&g_fn[dev], mod, "mgu_wino_cp2_gfx950");
+    if (!g_mod[dev]) {
+      e = hipModuleLoadData(&g_mod[dev], mgu_wino_cp2_hsaco);
       if (e != hipSuccess) return e;
     }
-    fn = g_fn[dev];
+    if (!g_fn[dev][var]) {
+      char name[64];
+      if (var) snprintf(name, sizeof name, "mgu_wino_cp2_gfx950_v%d", var);
+      else snprintf(name, sizeof name, "mgu_wino_cp2_gfx950");
+      e = hipModuleGetFunction(&g_fn[dev][var], g_mod[dev], name);
+      if (e != hipSuccess) return e;
+    }
+    fn = g_fn[dev][var];
   }
   const Plan p = plan_of(d);
   WinoAsmArgs a;
