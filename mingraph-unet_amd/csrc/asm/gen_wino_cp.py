@@ -39,7 +39,12 @@ def opt(k, d=None): return OPT.get(k, d)
 def vr(b, n=1):
     return f"v{b}" if n == 1 else f"v[{b}:{b + n - 1}]"
 
-def ACC(jj, nt, mi): return ((jj * 2 + nt) * 2 + mi) * 16
+CFG = {"ntb": 2, "nc": None}          # kernel being emitted: output-channel tiles per workgroup; static chunk count (narrow kernels)
+def NTB(): return CFG["ntb"]
+def ACC(jj, nt, mi): return ((jj * 2 + nt) * 2 + mi) * 16 if CFG["ntb"] == 2 else (jj * 2 + mi) * 16
+# narrow kernels (NTB = 1): the layer's whole weight-piece slice of the wave stays in registers, two halo register sets
+def WN(c, jj, p): return 64 + ((c * 2 + jj) * 3 + p) * 4
+def HSET(setn, i): return (232 if setn == 0 else 160) + i * 4
 def BX(jj, nt, p): return 128 + ((jj * 2 + nt) * 3 + p) * 4
 def PC(slot, p): return 176 + (slot * 3 + p) * 4
 def RAW(hf, k): return 200 + (hf * 4 + k) * 4          # k: 0 = a(x), 1 = b(x), 2 = a(y), 3 = b(y)
@@ -145,9 +150,9 @@ def setup_load():
         E(f"v_cndmask_b32_e32 v{d}, v{d}, v{VT1}, vcc")
 
 
-def halo_loads(issue=True):
+def halo_loads(issue=True, setn=0):
     for i in range(3 if issue else 0):
-        E(f"buffer_load_dwordx4 {vr(HREG(i), 4)}, v{VHOFF[i]}, s[{S_INR}:{S_INR + 3}], s{S_LC64} offen")
+        E(f"buffer_load_dwordx4 {vr(HSET(setn, i), 4)}, v{VHOFF[i]}, s[{S_INR}:{S_INR + 3}], s{S_LC64} offen")
     # lc = lc + 1 == nC ? 0 : lc + 1;  lp += lc == 0
     E(f"s_add_u32 s{S_LC}, s{S_LC}, 1")
     E(f"s_cmp_eq_u32 s{S_LC}, s{S_NC}")
@@ -157,9 +162,9 @@ def halo_loads(issue=True):
     E(f"s_lshl_b32 s{S_LC64}, s{S_LC}, 6")
 
 
-def halo_stores():
+def halo_stores(setn=0):
     for i in range(3):
-        E(f"ds_write_b128 v{VHST[i]}, {vr(HREG(i), 4)}")
+        E(f"ds_write_b128 v{VHST[i]}, {vr(HSET(setn, i), 4)}")
 
 
 def raw_reads(jp, jj, mi):
@@ -604,6 +609,250 @@ def emit_epilogue(jp):
         E("s_barrier")                   # the regions are rewritten by the next pass / receive the next raw chunk
 
 
+# =====================================================================================================================
+# Narrow kernels (32 output channels per workgroup; asm form of wino3x3_cp_kernel<1, false, true, *>): a chunk is only six MFMAs
+# per wave and step, so the loop is bound by the transform's VALU issue and by latency, not by the matrix pipe.  Against the wide
+# kernel: (i) the wave's weight pieces of ALL chunks stay in registers (2 or 4 chunks: 48 / 96 registers; the accumulators are only
+# 64) -- no weight stream at all; (ii) the halo is requested two chunks ahead through two register sets whose parity is static
+# (the chunk loop is unrolled); (iii) scale / shift are applied by the finishing pass (two of the four shares are plain copies of
+# the accumulators).  Same arithmetic order as the C++ kernel: bitwise equal outputs.
+# =====================================================================================================================
+def mfmas_n(jj, mi, slot, c):
+    acc = vr(ACC(jj, 0, mi), 16)
+    return [f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(PC(slot, pa), 4)}, {vr(WN(c, jj, pb), 4)}, {acc}"
+            for (pa, pb) in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0))]
+
+
+def emit_step_n(jp, s, c):
+    jj, mi, slot = s >> 1, s & 1, s & 1
+    n1, n2 = (s + 1) & 3, (s + 2) & 3
+    if s == 2:
+        E("s_waitcnt lgkmcnt(0)")
+        E("s_barrier")                    # B1
+    E("s_nop 1")                          # the previous step ends with the v_perm that writes this step's low-order operand piece, and the
+    #                                       first MFMA reads that piece: two wait states between a VALU write and an MFMA read of it
+    mf = mfmas_n(jj, mi, slot, c)
+    v0 = form_valu(jp, n1 >> 1, slot ^ 1, 0)
+    v1 = form_valu(jp, n1 >> 1, slot ^ 1, 1)
+    r1 = raw_reads(jp, n1 >> 1, n1 & 1)[4:8]
+    r2 = raw_reads(jp, n2 >> 1, n2 & 1)[0:4]
+    extra = {}
+    if s == 0:
+        hs = (c + 1) & 1                  # the set holding chunk c + 1; it is refilled with chunk c + 3
+        E("s_waitcnt vmcnt(3)")           # (only the three loads of chunk c + 2 are younger)
+        for i in range(3):
+            extra.setdefault(i, []).append(f"ds_write_b128 v{VHST[i]}, {vr(HSET(hs, i), 4)}")
+        extra.setdefault(3, []).extend([f"v_xor_b32_e32 v{VHST[i]}, 0x{BUFX:x}, v{VHST[i]}" for i in range(3)])
+        for i in range(3):
+            extra.setdefault(3 + i, []).append(f"buffer_load_dwordx4 {vr(HSET(hs, i), 4)}, v{VHOFF[i]}, s[{S_INR}:{S_INR + 3}], s{S_LC64} offen")
+        extra.setdefault(5, []).extend([
+            f"s_add_u32 s{S_LC}, s{S_LC}, 1", f"s_cmp_eq_u32 s{S_LC}, s{S_NC}", f"s_cselect_b32 s{S_LC}, 0, s{S_LC}",
+            f"s_cmp_eq_u32 s{S_LC}, 0", f"s_addc_u32 s{S_LP}, s{S_LP}, 0", f"s_lshl_b32 s{S_LC64}, s{S_LC}, 6"])
+    def take(lst, n):
+        for _ in range(min(n, len(lst))):
+            E(lst.pop(0))
+    nlds = 0
+    for k in range(6):
+        E(mf[k])
+        for x in extra.get(k, []):
+            E(x)
+            nlds += x.startswith("ds_")
+        if k in (0, 1):
+            take(r1, 2)
+            nlds += 2
+        if k == 1:
+            E(f"s_waitcnt lgkmcnt({nlds})")   # half 0 (requested in the previous step); everything issued in this step may be in flight
+        if k in (1, 2):
+            take(v0, 17)
+        if k == 3:
+            E("s_waitcnt lgkmcnt(0)")
+            if s == 2:
+                E(f"v_xor_b32_e32 v{VA}, 0x{BUFX:x}, v{VA}")
+                E(f"v_xor_b32_e32 v{VB}, 0x{BUFX:x}, v{VB}")
+        if k in (3, 4):
+            take(r2, 2)
+        if k >= 3:
+            take(v1, 12)
+    assert not v0 and not v1 and not r1 and not r2
+
+
+def emit_chunk_n(jp, c):
+    lskip = newlabel("nosetup")
+    E(f"s_cmp_lg_u32 s{S_LC}, 0")
+    E(f"s_cbranch_scc1 {lskip}")
+    E(f"s_cmp_ge_u32 s{S_LP}, s{S_NPATCH}")
+    E(f"s_cbranch_scc1 {lskip}")
+    setup_load()
+    L(lskip)
+    E("s_waitcnt lgkmcnt(0)")
+    E("s_barrier")                        # B0
+    for s in range(4):
+        emit_step_n(jp, s, c)
+
+
+def emit_epilogue_n(jp):
+    CQ, VT = VT0, VT1
+    VZ0, VZ1, VOUT, VPOOL = 188, 189, 190, 191
+    e0, e1, e2, e3 = 192, 193, 194, 195
+    SC4, SH4 = 196, 216
+    TMP = [220 + i for i in range(8)]
+    E("s_nop 7")
+    E("s_nop 7")
+    E("s_nop 7")
+    E(f"s_add_u32 s{S_P}, s{S_PBEGIN}, s{S_PI}")
+    patch_coords(S_P)
+    E(f"s_mul_i32 s{S_T[6]}, s{S_IMG}, s{S_OUTIMGB}")
+    E(f"s_mul_hi_u32 s{S_T[7]}, s{S_IMG}, s{S_OUTIMGB}")
+    E(f"s_add_u32 s{S_OUTR}, s{S_OUT}, s{S_T[6]}")
+    E(f"s_addc_u32 s{S_OUTR + 1}, s{S_OUT + 1}, s{S_T[7]}")
+    E(f"s_and_b32 s{S_OUTR + 1}, s{S_OUTR + 1}, 0xffff")
+    E(f"s_lshr_b32 s{S_T[4]}, s{S_H}, 1")
+    E(f"s_lshr_b32 s{S_T[5]}, s{S_W}, 1")
+    E(f"s_mul_i32 s{S_T[4]}, s{S_T[4]}, s{S_T[5]}")
+    E(f"s_mul_i32 s{S_T[4]}, s{S_T[4]}, s{S_LDPOOL}")
+    E(f"s_lshl_b32 s{S_T[4]}, s{S_T[4]}, 2")
+    E(f"s_mov_b32 s{S_POOLR + 2}, s{S_T[4]}")
+    E(f"s_mul_i32 s{S_T[6]}, s{S_IMG}, s{S_T[4]}")
+    E(f"s_mul_hi_u32 s{S_T[7]}, s{S_IMG}, s{S_T[4]}")
+    E(f"s_add_u32 s{S_POOLR}, s{S_POOL}, s{S_T[6]}")
+    E(f"s_addc_u32 s{S_POOLR + 1}, s{S_POOL + 1}, s{S_T[7]}")
+    E(f"s_and_b32 s{S_POOLR + 1}, s{S_POOLR + 1}, 0xffff")
+    E(f"v_and_b32_e32 v{CQ}, 7, v{VTID}")
+    E(f"v_lshrrev_b32_e32 v{VT}, 3, v{VTID}")
+    # per-channel scale / shift of the finishing unit's channel quad (n0 = nblock * 32 + cq * 4): requested first, used last
+    E(f"v_lshlrev_b32_e32 v{e0}, 4, v{CQ}")
+    E(f"buffer_load_dwordx4 {vr(SC4, 4)}, v{e0}, s[{S_SCR}:{S_SCR + 3}], s{S_N64X4} offen")
+    E(f"buffer_load_dwordx4 {vr(SH4, 4)}, v{e0}, s[{S_SHR}:{S_SHR + 3}], s{S_N64X4} offen")
+    E(f"v_and_b32_e32 v{e0}, 32, v{VT}")
+    E(f"v_and_b32_e32 v{e1}, 3, v{VT}")
+    E(f"v_bfe_u32 v{e2}, v{VT}, 3, 2")
+    E(f"v_lshl_add_u32 v{e1}, v{e2}, 2, v{e1}")
+    E(f"v_lshl_add_u32 v{e0}, v{e1}, 1, v{e0}")
+    E(f"v_bfe_u32 v{e2}, v{VT}, 2, 1")
+    E(f"v_add_u32_e32 v{e0}, v{e0}, v{e2}")
+    E(f"v_lshlrev_b32_e32 v{e0}, 7, v{e0}")
+    E(f"v_lshl_add_u32 v{VZ0}, v{CQ}, 4, v{e0}")
+    E(f"v_add_u32_e32 v{VZ1}, 0x10000, v{VZ0}")
+    E(f"v_lshrrev_b32_e32 v{e1}, 4, v{VT}")
+    E(f"v_lshl_add_u32 v{e1}, v{e1}, 1, s{S_Y0}")
+    E(f"v_and_b32_e32 v{e2}, 15, v{VT}")
+    E(f"v_lshl_add_u32 v{e2}, v{e2}, 1, s{S_X0}")
+    E(f"v_mad_u32_u24 v{e3}, v{e1}, s{S_W}, v{e2}")
+    E(f"v_mul_lo_u32 v{e3}, v{e3}, s{S_LDOUT}")
+    E(f"v_lshl_add_u32 v{e3}, v{CQ}, 2, v{e3}")
+    E(f"v_lshlrev_b32_e32 v{VOUT}, 2, v{e3}")
+    E(f"v_add_u32_e32 v{VOUT}, s{S_N64X4}, v{VOUT}")
+    E(f"v_lshrrev_b32_e32 v{e1}, 1, v{e1}")
+    E(f"v_lshrrev_b32_e32 v{e2}, 1, v{e2}")
+    E(f"v_mad_u32_u24 v{e3}, v{e1}, s{S_T[5]}, v{e2}")
+    E(f"v_mul_lo_u32 v{e3}, v{e3}, s{S_LDPOOL}")
+    E(f"v_lshl_add_u32 v{e3}, v{CQ}, 2, v{e3}")
+    E(f"v_lshlrev_b32_e32 v{VPOOL}, 2, v{e3}")
+    E(f"v_add_u32_e32 v{VPOOL}, s{S_N64X4}, v{VPOOL}")
+    E(f"s_lshl_b32 s{S_T[0]}, s{S_WI}, 13")
+    if jp:
+        E(f"s_add_u32 s{S_T[0]}, s{S_T[0]}, 0x{RAWB:x}")
+    E(f"s_lshl_b32 s{S_T[1]}, s{S_WI}, 13")
+    E(f"s_add_u32 s{S_T[1]}, s{S_T[1]}, 0x{(2 + jp) * RAWB - ZBIAS:x}")
+    E("s_waitcnt lgkmcnt(0)")
+    E("s_barrier")
+    # shares: jp 0: q0 = m0 + m1, q1 = m1 (the accumulator itself);  jp 1: q0 = m0 (itself), q1 = -m0 - m1
+    for q in range(2):
+        E(f"s_mov_b32 m0, s{S_T[q]}")
+        E("s_nop 0")
+        g = 0
+        for mi in range(2):
+            for r0 in range(0, 16, 4):
+                ts = TMP[(g & 1) * 4:(g & 1) * 4 + 4]
+                g += 1
+                src = []
+                for k in range(4):
+                    m0, m1 = ACC(0, 0, mi) + r0 + k, ACC(1, 0, mi) + r0 + k
+                    if jp == 0 and q == 0:
+                        E(f"v_add_f32_e32 v{ts[k]}, v{m0}, v{m1}")
+                        src.append(ts[k])
+                    elif jp == 0:
+                        src.append(m1)
+                    elif q == 0:
+                        src.append(m0)
+                    else:
+                        E(f"v_sub_f32_e64 v{ts[k]}, -v{m0}, v{m1}")
+                        src.append(ts[k])
+                E("s_nop 0")
+                for k in range(4):
+                    off = (32 * mi + 2 * (r0 + k)) * 128 + (ZBIAS if q else 0)
+                    E(f"ds_write_addtid_b32 v{src[k]} offset:{off}")
+    E("s_waitcnt lgkmcnt(0)")
+    E("s_barrier")
+    zb = [ACC(0, 0, 0), ACC(0, 0, 1), ACC(1, 0, 0), ACC(1, 0, 1)]
+    def Z(q, j, i):
+        k = (q * 2 + j) * 4 + i
+        return zb[k // 4] + (k % 4) * 4
+    for q in range(2):
+        for j in range(2):
+            for i in range(4):
+                E(f"ds_read_b128 {vr(Z(q, j, i), 4)}, v{VZ1 if q else VZ0} offset:{j * RAWB + i * 8192}")
+    E("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    for q in range(2):
+        for i in range(4):
+            for e in range(4):
+                E(f"v_add_f32_e32 v{Z(q, 0, i) + e}, v{Z(q, 0, i) + e}, v{Z(q, 1, i) + e}")
+        ya, yb = Z(q, 1, 0), Z(q, 1, 1)
+        for e in range(4):
+            E(f"v_add_f32_e32 v{ya + e}, v{Z(q, 0, 0) + e}, v{Z(q, 0, 1) + e}")
+        for e in range(4):
+            E(f"v_add_f32_e32 v{ya + e}, v{ya + e}, v{Z(q, 0, 2) + e}")
+        for e in range(4):
+            E(f"v_sub_f32_e32 v{yb + e}, v{Z(q, 0, 1) + e}, v{Z(q, 0, 2) + e}")
+        for e in range(4):
+            E(f"v_sub_f32_e32 v{yb + e}, v{yb + e}, v{Z(q, 0, 3) + e}")
+        for y in (ya, yb):
+            for e in range(4):
+                E(f"v_fma_f32 v{y + e}, v{SC4 + e}, v{y + e}, v{SH4 + e}")
+    lnr = newlabel("norelu")
+    E(f"s_cmp_eq_u32 s{S_RELU}, 0")
+    E(f"s_cbranch_scc1 {lnr}")
+    for q in range(2):
+        for y in (Z(q, 1, 0), Z(q, 1, 1)):
+            for e in range(4):
+                E(f"v_max_f32_e32 v{y + e}, 0, v{y + e}")
+    L(lnr)
+    ya0, yb0, ya1, yb1 = Z(0, 1, 0), Z(0, 1, 1), Z(1, 1, 0), Z(1, 1, 1)
+    E(f"buffer_store_dwordx4 {vr(ya0, 4)}, v{VOUT}, s[{S_OUTR}:{S_OUTR + 3}], 0 offen nt")
+    E(f"buffer_store_dwordx4 {vr(ya1, 4)}, v{VOUT}, s[{S_OUTR}:{S_OUTR + 3}], s{S_LD4} offen nt")
+    E(f"buffer_store_dwordx4 {vr(yb0, 4)}, v{VOUT}, s[{S_OUTR}:{S_OUTR + 3}], s{S_SW4} offen nt")
+    E(f"buffer_store_dwordx4 {vr(yb1, 4)}, v{VOUT}, s[{S_OUTR}:{S_OUTR + 3}], s{S_SUMOFF} offen nt")
+    lnp = newlabel("nopool")
+    E(f"s_cmp_eq_u64 s[{S_POOL}:{S_POOL + 1}], 0")
+    E(f"s_cbranch_scc1 {lnp}")
+    pm = Z(0, 0, 0)
+    for e in range(4):
+        E(f"v_max_f32_e32 v{pm + e}, v{ya0 + e}, v{yb0 + e}")
+    for e in range(4):
+        E(f"v_max_f32_e32 v{Z(0, 0, 1) + e}, v{ya1 + e}, v{yb1 + e}")
+    for e in range(4):
+        E(f"v_max_f32_e32 v{pm + e}, v{pm + e}, v{Z(0, 0, 1) + e}")
+    E(f"buffer_store_dwordx4 {vr(pm, 4)}, v{VPOOL}, s[{S_POOLR}:{S_POOLR + 3}], 0 offen")
+    L(lnp)
+    E("s_nop 1")
+    for r in range(64):
+        E(f"v_mov_b32_e32 v{r}, 0")
+    E("s_waitcnt lgkmcnt(0)")
+    E("s_barrier")
+
+
+def emit_patch_loop_n(jp):
+    lp = newlabel("patch")
+    L(lp)
+    for c in range(CFG["nc"]):
+        emit_chunk_n(jp, c)
+    emit_epilogue_n(jp)
+    E(f"s_add_u32 s{S_PI}, s{S_PI}, 1")
+    E(f"s_cmp_lt_u32 s{S_PI}, s{S_NPATCH}")
+    E(f"s_cbranch_scc1 {lp}")
+    E(f"s_branch {END_LABEL}")
+
+
 def emit_patch_loop(jp):
     lp, lc = newlabel("patch"), newlabel("chunk")
     L(lp)
@@ -684,7 +933,7 @@ def emit_prologue():
     E(f"s_mul_i32 s{S_IMGB}, s{S_IMGB}, s{S_LDIN}")
     E(f"s_lshl_b32 s{S_IMGB}, s{S_IMGB}, 2")
     E(f"s_mul_i32 s{S_NTSTRIDE}, s{S_NC}, 0xc000")
-    E(f"s_lshl_b32 s{S_N64X4}, s{S_NBLOCK}, 8")
+    E(f"s_lshl_b32 s{S_N64X4}, s{S_NBLOCK}, {8 if NTB() == 2 else 7}")     # byte offset of the workgroup's first output channel
     E(f"s_lshl_b32 s{S_LD4}, s{S_LDOUT}, 2")
     E(f"s_mul_i32 s{S_SW4}, s{S_W}, s{S_LD4}")
     E(f"s_add_u32 s{S_SUMOFF}, s{S_SW4}, s{S_LD4}")
@@ -715,7 +964,7 @@ def emit_prologue():
     E(f"s_cmp_eq_u32 s{S_WI}, 1")
     E(f"s_cselect_b32 s{S_SGN}, 1.0, -1.0")
     # weight descriptor: base = wu + nblock * 2 * nC * 49152 + (wi * 4 + 2 jp) * 3072
-    E(f"s_lshl_b32 s64, s{S_NTSTRIDE}, 1")                    # u_bytes of the workgroup's two n tiles
+    E(f"s_lshl_b32 s64, s{S_NTSTRIDE}, {1 if NTB() == 2 else 0}")   # u_bytes of the workgroup's n tiles
     E(f"s_mul_i32 s65, s{S_NBLOCK}, s64")
     E(f"s_lshl_b32 s66, s{S_WI}, 2")
     E(f"s_lshl_b32 s67, s{S_JP}, 1")
@@ -763,6 +1012,35 @@ def emit_prologue():
     E(f"s_mov_b32 s{S_LP}, 0")
     E(f"s_mov_b32 s{S_PI}, 0")
     E(f"s_mov_b32 s{S_LC64}, 0")
+    if NTB() == 1:
+        # the wave's weight pieces of every chunk (resident for the life of the workgroup), then the halo of chunks 0 (-> slot 4), 1 and 2
+        for c in range(CFG["nc"]):
+            for jj in range(2):
+                E(f"s_mov_b32 s{S_WO[0][0]}, 0x{c * 0xc000 + jj * 0xc00:x}")
+                for pp in range(3):
+                    E(f"buffer_load_dwordx4 {vr(WN(c, jj, pp), 4)}, v{VLANE16}, s[{S_UR}:{S_UR + 3}], s{S_WO[0][0]} offen offset:{pp * 1024}")
+        setup_load()
+        halo_loads(True, 0)
+        for i in range(3):
+            E(f"v_xor_b32_e32 v{VHST[i]}, 0x{BUFX:x}, v{VHST[i]}")
+        E("s_waitcnt vmcnt(0)")
+        halo_stores(0)
+        for i in range(3):
+            E(f"v_xor_b32_e32 v{VHST[i]}, 0x{BUFX:x}, v{VHST[i]}")
+        for setn in (1, 0):
+            lsk = newlabel("nosetup")
+            E(f"s_cmp_lg_u32 s{S_LC}, 0")
+            E(f"s_cbranch_scc1 {lsk}")
+            E(f"s_cmp_ge_u32 s{S_LP}, s{S_NPATCH}")
+            E(f"s_cbranch_scc1 {lsk}")
+            setup_load()
+            L(lsk)
+            halo_loads(True, setn)
+        for r in range(64):
+            E(f"v_mov_b32_e32 v{r}, 0")
+        E("s_waitcnt lgkmcnt(0)")
+        E("s_barrier")
+        return
     setup_load()
     halo_loads()                                     # chunk 0
     for i in range(3):
@@ -849,12 +1127,12 @@ def emit_kernel(name):
     if opt("prio_jp0"):
         E(f"s_setprio {opt('prio_jp0')}")
     emit_first_form(0)
-    emit_patch_loop(0)
+    (emit_patch_loop if NTB() == 2 else emit_patch_loop_n)(0)
     L(jp1)
     if opt("prio_jp1"):      # static priority for the second-dispatched half (the SIMD partners of waves 0-3)
         E(f"s_setprio {opt('prio_jp1')}")
     emit_first_form(1)
-    emit_patch_loop(1)
+    (emit_patch_loop if NTB() == 2 else emit_patch_loop_n)(1)
     L(end)
     E("s_endpgm")
     out.append(f"""\t.section\t.rodata,"a",@progbits
@@ -948,7 +1226,12 @@ def main():
     for suffix, o in VARIANTS:
         OPT.clear()
         OPT.update(o)
+        CFG.update(ntb=2, nc=None)
         emit_kernel("mgu_wino_cp2_gfx950" + suffix)
+    for nc in (2, 4):            # the narrow kernels: 32 output channels, the layer's 2 / 4 chunks of weight pieces resident
+        OPT.clear()
+        CFG.update(ntb=1, nc=nc)
+        emit_kernel(f"mgu_wino_cp1r{nc}_gfx950")
     out.append("\t.amdgpu_metadata\n---\namdhsa.kernels:")
     out.extend(META)
     out.append("""amdhsa.target:   amdgcn-amd-amdhsa--gfx950

@@ -807,7 +807,8 @@ const char* igemm_kernel_name(const IgemmDesc& d, int dtype) {
   if (wino_applicable(d)) {
     const bool wide = d.N > 32 && tun(d).wino_mode != 1;
     if (tun(d).wino_prec && tun(d).wino_cp && (wide || tun(d).wino_cp_narrow) && (long)d.H * d.W * d.ldin * 4 < (1l << 31))
-      return wide ? (wino_asm_applicable(d) ? "mgu_wino_cp2_gfx950 (asm form of wino3x3_cp_kernel<2>)" : "wino3x3_cp_kernel<2>") : "wino3x3_cp_kernel<1>";
+      return wide ? (wino_asm_applicable(d) ? "mgu_wino_cp2_gfx950 (asm form of wino3x3_cp_kernel<2>)" : "wino3x3_cp_kernel<2>")
+                  : (wino_asm_applicable(d) ? "mgu_wino_cp1r_gfx950 (asm form of wino3x3_cp_kernel<1>)" : "wino3x3_cp_kernel<1>");
     if (tun(d).wino_prec) return wide ? "wino3x3_f32_kernel<0,1>" : "wino3x3_f32_kernel<1,1>";
     return wide ? "wino3x3_f32_kernel<0,0>" : "wino3x3_f32_kernel<1,0>";
   }

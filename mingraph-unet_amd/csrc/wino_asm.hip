@@ -37,11 +37,13 @@ unsigned magic(unsigned d) { return d <= 1 ? 0xffffffffu : (unsigned)((1ull << 3
 struct Plan {
   int tiles_x, tiles_y, total, nblk, ppb, ngroups, per_xcd;
 };
+bool is_wide(const IgemmDesc& d) { return d.N > 32 && tun(d).wino_mode != 1; }
 Plan plan_of(const IgemmDesc& d) {
   Plan p;
   p.tiles_x = (d.W + 31) / 32, p.tiles_y = (d.H + 7) / 8;
   const int B = d.M / (d.H * d.W);
-  p.total = p.tiles_x * p.tiles_y * B, p.nblk = (d.N + 63) / 64;
+  const int nc = is_wide(d) ? 64 : 32;   // output channels of a workgroup
+  p.total = p.tiles_x * p.tiles_y * B, p.nblk = (d.N + nc - 1) / nc;
   const int rounds = std::max(1, tun(d).wino_rounds), cap = std::max(1, tun(d).wino_ppb_cap);
   int ppb = (int)(((long)p.total * p.nblk) / (256 * rounds));   // the C++ launcher's walk (launch_wino_cp)
   if (ppb < 1) ppb = 1;
@@ -55,12 +57,19 @@ Plan plan_of(const IgemmDesc& d) {
 constexpr int MAX_VARIANTS = 24;   // wino_asm = 1: the shipping kernel; n > 1: timing-only variant _v(n-1) of a GEN_WINO_VARIANTS=1 build
 std::mutex g_mu;
 hipModule_t g_mod[64] = {};
-hipFunction_t g_fn[64][MAX_VARIANTS] = {};   // loaded functions per device, written once under g_mu, immutable afterwards
+hipFunction_t g_fn[64][MAX_VARIANTS + 2] = {};   // loaded functions per device (the last two: the narrow kernels), written once under
+                                                 // g_mu, immutable afterwards
 }  // namespace
 
 bool wino_asm_applicable(const IgemmDesc& d) {
   if (!tun(d).wino_asm || !tun(d).wino_prec || !tun(d).wino_cp || tun(d).wino_yfast || tun(d).wino_prio) return false;
-  if (tun(d).wino_mode == 1 || d.N <= 32 || (d.N & 63) || d.stat_slots || !d.scale || !d.shift) return false;
+  if (d.stat_slots || !d.scale || !d.shift) return false;
+  if (is_wide(d)) {
+    if (d.N & 63) return false;
+  } else {   // narrow kernels: exactly one 32-channel tile, 2 or 4 chunks (their weight pieces stay in registers), the C++ kernel's
+             // two-chunk load lead and reader-side scale / shift (what launch_wino_f32 picks for these layers)
+    if (d.N != 32 || !(d.Cp == 32 || d.Cp == 64) || !tun(d).wino_cp_narrow || !tun(d).wino_deep || tun(d).wino_asm > 1) return false;
+  }
   if ((d.H & 7) || (d.W & 31) || (d.Cp & 31) || (d.ldin & 3) || (d.ldout & 3) || (d.coff & 3)) return false;
   if (d.pool && ((d.ldpool & 3) || (d.H & 1) || (d.W & 1))) return false;
   if ((long)d.H * d.W * d.ldin * 4 >= 0x7fff0000l || (long)d.H * d.W * d.ldout * 4 >= 0x7fff0000l) return false;
@@ -75,7 +84,8 @@ hipError_t launch_wino_cp_asm(const IgemmDesc& d, hipStream_t s) {
   if (e != hipSuccess) return e;
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
   hipFunction_t fn;
-  const int var = std::min(std::max(tun(d).wino_asm, 1), MAX_VARIANTS) - 1;
+  const bool wide = is_wide(d);
+  const int var = wide ? std::min(std::max(tun(d).wino_asm, 1), MAX_VARIANTS) - 1 : MAX_VARIANTS + (d.Cp == 64);
   {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_mod[dev]) {
@@ -84,7 +94,8 @@ hipError_t launch_wino_cp_asm(const IgemmDesc& d, hipStream_t s) {
     }
     if (!g_fn[dev][var]) {
       char name[64];
-      if (var) snprintf(name, sizeof name, "mgu_wino_cp2_gfx950_v%d", var);
+      if (!wide) snprintf(name, sizeof name, "mgu_wino_cp1r%d_gfx950", d.Cp >> 4);
+      else if (var) snprintf(name, sizeof name, "mgu_wino_cp2_gfx950_v%d", var);
       else snprintf(name, sizeof name, "mgu_wino_cp2_gfx950");
       e = hipModuleGetFunction(&g_fn[dev][var], g_mod[dev], name);
       if (e != hipSuccess) return e;

@@ -1464,8 +1464,8 @@ hipError_t launch_wino_f32(const IgemmDesc& d, hipStream_t s) {
     const bool deep = !wide && ((d.Cp >> 4) & 1) == 0 && tun(d).wino_deep && !d.stat_slots;
     const bool ures = deep && (d.Cp >> 4) == 2 && tun(d).wino_ures;
     if (d.stat_slots) return wide ? launch_wino_cp<2, true>(d, s) : deep ? launch_wino_cp<1, true, true>(d, s) : launch_wino_cp<1, true>(d, s);
+    if (wino_asm_applicable(d)) return launch_wino_cp_asm(d, s);   // wide layers and the two- / four-chunk narrow layers (wino_asm.hip)
     if (deep && ures) return launch_wino_cp<1, false, true, true>(d, s);
-    if (wide && wino_asm_applicable(d)) return launch_wino_cp_asm(d, s);
     return wide ? launch_wino_cp<2, false>(d, s) : deep ? launch_wino_cp<1, false, true>(d, s) : launch_wino_cp<1, false>(d, s);
   }
   if (tun(d).wino_prec) return wide ? launch_wino_mode<0, 1>(d, s) : launch_wino_mode<1, 1>(d, s);

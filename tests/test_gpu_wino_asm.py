@@ -41,6 +41,13 @@ SHAPES = [
     (8, 256, 256, 32, 64),    # eight patches per workgroup (the persistent walk, the cross-patch prefetch)
     (1, 8, 32, 32, 64),       # a single patch: every halo side outside the image
     (3, 40, 96, 96, 192),     # sizes that are not powers of two (five tile rows, three tile columns, six chunks, three n blocks)
+    # the narrow kernels (32 output channels; the layer's weight pieces resident, two chunks of halo lead)
+    (1, 128, 128, 32, 32),    # enc0.c2 / dec3.c2: two chunks
+    (1, 128, 128, 64, 32),    # dec3.c1: four chunks
+    (4, 256, 256, 32, 32),    # four patches per workgroup
+    (2, 256, 256, 64, 32),
+    (1, 8, 32, 32, 32),       # a single patch
+    (3, 40, 96, 64, 32),      # sizes that are not powers of two
 ]
 
 

@@ -10,7 +10,8 @@ cuda = torch.device("cuda:0")
 LAYERS = [("enc1.c1", 256, 32, 64), ("enc1.c2", 256, 64, 64), ("enc2.c1", 128, 64, 128), ("enc2.c2", 128, 128, 128),
           ("enc3.c1", 64, 128, 256), ("enc3.c2", 64, 256, 256), ("bott.c1", 32, 256, 512), ("bott.c2", 32, 512, 512),
           ("dec0.c1", 64, 512, 256), ("dec0.c2", 64, 256, 256), ("dec1.c1", 128, 256, 128), ("dec1.c2", 128, 128, 128),
-          ("dec2.c1", 256, 128, 64), ("dec2.c2", 256, 64, 64)]
+          ("dec2.c1", 256, 128, 64), ("dec2.c2", 256, 64, 64),
+          ("enc0.c2", 512, 32, 32), ("dec3.c1", 512, 64, 32), ("dec3.c2", 512, 32, 32)]
 B = 8
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 FLAGS = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "1"]

@@ -74,6 +74,10 @@ case("2x2 patches rand", 1, 16, 64, 32, 64, xr, wr)
 case("4 chunks", 1, 8, 32, 64, 64, xr, wr)
 case("2 nblocks", 1, 8, 32, 32, 128, xr, wr)
 case("many patches", 2, 128, 128, 32, 64, xr, wr)
+case("N1 1patch 2ch", 1, 8, 32, 32, 32, xr, wr)
+case("N1 1patch 4ch", 1, 8, 32, 64, 32, xr, wr)
+case("N1 many 2ch", 2, 128, 128, 32, 32, xr, wr)
+case("N1 many 4ch", 2, 128, 128, 64, 32, xr, wr, relu=1)
 print("######## probes")
 def x0(B, H, W, C): return torch.zeros(B, H, W, C)
 def x1(B, H, W, C): return torch.ones(B, H, W, C)
