@@ -240,8 +240,16 @@ def emit_step_spread(jp, s):
         if not opt("no_barrier"):
             E("s_barrier")                # B1: chunk c + 1 is complete in the other buffer
         stamp(5)
-    if s in (0, 2):
-        E("s_waitcnt vmcnt(9)")           # this component's weight pieces (requested a chunk ago)
+    if s == 0:
+        # this component's weight pieces (requested in step 1 of the previous chunk).  VMEM operations retire in order: younger than
+        # them are the other component's six pieces (step 3) and, when the staging stood in front of this step, this chunk's three
+        # halo loads; with the staging inside the step they are issued BEHIND this wait.  The halo registers (older) are covered.
+        E(f"s_waitcnt vmcnt({6 if opt('stage_in_step0', 1) else 9})")
+    if s == 2:
+        E("s_waitcnt vmcnt(9)")           # pieces requested in step 3 of the previous chunk; younger: 3 halo loads + 6 pieces of step 1
+    # two wait states between the v_perm that wrote the last dword of this step's low-order operand piece (tail of the previous
+    # step: only its final MFMA lies between) and the first MFMA, which reads that piece
+    E("s_nop 1")
     mf = mfmas(jj, mi, slot)
     v0 = form_valu(jp, n1 >> 1, slot ^ 1, 0)
     v1 = form_valu(jp, n1 >> 1, slot ^ 1, 1)

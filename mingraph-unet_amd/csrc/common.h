@@ -42,6 +42,7 @@ struct Tuning {
   bool gat_fused = true;    // MGU_NO_GAT_FUSED=1
   bool wino_ures = true;    // MGU_NO_WINO_URES=1: the 32-input-channel narrow layers reload their weight pieces every chunk (A/B)
   bool wino_prio = false;   // MGU_WINO_PRIO=1: s_setprio 1 for waves 4-7 of the component-pair Winograd kernels (A/B)
+  bool wino_asm_narrow = true;   // MGU_WINO_ASM_NARROW=0: the assembly form only for the wide layers (A/B)
   int wino_asm = 1;         // MGU_WINO_ASM=0: the C++ component-pair kernels instead of their hand-scheduled assembly forms (wino_asm.hip; bitwise
                             // equal results, A/B and fallback); n > 1: timing-only variant n - 1 of a GEN_WINO_VARIANTS=1 build (never shipped)
 };

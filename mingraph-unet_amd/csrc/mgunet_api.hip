@@ -89,6 +89,7 @@ int mgu_create(int device_id, mgu_ctx** out) {
   t.wino_ures = !flag("MGU_NO_WINO_URES");
   t.wino_prio = flag("MGU_WINO_PRIO");
   t.wino_asm = std::max(0, num("MGU_WINO_ASM", t.wino_asm));
+  t.wino_asm_narrow = num("MGU_WINO_ASM_NARROW", 1) != 0;
   *out = c;
   return MGU_OK;
 }

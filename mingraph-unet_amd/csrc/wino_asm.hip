@@ -68,7 +68,7 @@ bool wino_asm_applicable(const IgemmDesc& d) {
     if (d.N & 63) return false;
   } else {   // narrow kernels: exactly one 32-channel tile, 2 or 4 chunks (their weight pieces stay in registers), the C++ kernel's
              // two-chunk load lead and reader-side scale / shift (what launch_wino_f32 picks for these layers)
-    if (d.N != 32 || !(d.Cp == 32 || d.Cp == 64) || !tun(d).wino_cp_narrow || !tun(d).wino_deep || tun(d).wino_asm > 1) return false;
+    if (!tun(d).wino_asm_narrow || d.N != 32 || !(d.Cp == 32 || d.Cp == 64) || !tun(d).wino_cp_narrow || !tun(d).wino_deep || tun(d).wino_asm > 1) return false;
   }
   if ((d.H & 7) || (d.W & 31) || (d.Cp & 31) || (d.ldin & 3) || (d.ldout & 3) || (d.coff & 3)) return false;
   if (d.pool && ((d.ldpool & 3) || (d.H & 1) || (d.W & 1))) return false;
