@@ -497,11 +497,21 @@ def emit_epilogue(jp):
     # per-channel scale / shift of the writer lane (n = nblock * 64 + nt * 32 + (tid & 31))
     E(f"v_and_b32_e32 v{e0}, 31, v{VTID}")
     E(f"v_lshlrev_b32_e32 v{e0}, 2, v{e0}")
+    lsn, lsd = newlabel("scn"), newlabel("scd")
+    E(f"s_cmp_eq_u64 s[{S_SCALE}:{S_SCALE + 1}], 0")          # no scale array (a data-gradient convolution): 1
+    E(f"s_cbranch_scc1 {lsn}")
     for nt in range(2):
         E(f"buffer_load_dword v{SCW[nt]}, v{e0}, s[{S_SCR}:{S_SCR + 3}], s{S_N64X4} offen offset:{nt * 128}")
+    E(f"s_branch {lsd}")
+    L(lsn)
+    for nt in range(2):
+        E(f"v_mov_b32_e32 v{SCW[nt]}, 1.0")
+    L(lsd)
     lz, ld = newlabel("shz"), newlabel("shd")
     if jp == 0:
         E(f"s_cmp_lg_u32 s{S_WI}, 1")
+        E(f"s_cbranch_scc1 {lz}")
+        E(f"s_cmp_eq_u64 s[{S_SHIFT}:{S_SHIFT + 1}], 0")
         E(f"s_cbranch_scc1 {lz}")
         for nt in range(2):
             E(f"buffer_load_dword v{SHW[nt]}, v{e0}, s[{S_SHR}:{S_SHR + 3}], s{S_N64X4} offen offset:{nt * 128}")
@@ -729,8 +739,16 @@ def emit_epilogue_n(jp):
     E(f"v_lshrrev_b32_e32 v{VT}, 3, v{VTID}")
     # per-channel scale / shift of the finishing unit's channel quad (n0 = nblock * 32 + cq * 4): requested first, used last
     E(f"v_lshlrev_b32_e32 v{e0}, 4, v{CQ}")
-    E(f"buffer_load_dwordx4 {vr(SC4, 4)}, v{e0}, s[{S_SCR}:{S_SCR + 3}], s{S_N64X4} offen")
-    E(f"buffer_load_dwordx4 {vr(SH4, 4)}, v{e0}, s[{S_SHR}:{S_SHR + 3}], s{S_N64X4} offen")
+    for (ptr, rs, reg, dflt) in ((S_SCALE, S_SCR, SC4, "1.0"), (S_SHIFT, S_SHR, SH4, "0")):
+        ln, ldn = newlabel("nul"), newlabel("nud")
+        E(f"s_cmp_eq_u64 s[{ptr}:{ptr + 1}], 0")
+        E(f"s_cbranch_scc1 {ln}")
+        E(f"buffer_load_dwordx4 {vr(reg, 4)}, v{e0}, s[{rs}:{rs + 3}], s{S_N64X4} offen")
+        E(f"s_branch {ldn}")
+        L(ln)
+        for e in range(4):
+            E(f"v_mov_b32_e32 v{reg + e}, {dflt}")
+        L(ldn)
     E(f"v_and_b32_e32 v{e0}, 32, v{VT}")
     E(f"v_and_b32_e32 v{e1}, 3, v{VT}")
     E(f"v_bfe_u32 v{e2}, v{VT}, 3, 2")

@@ -63,7 +63,7 @@ hipFunction_t g_fn[64][MAX_VARIANTS + 2] = {};   // loaded functions per device 
 
 bool wino_asm_applicable(const IgemmDesc& d) {
   if (!tun(d).wino_asm || !tun(d).wino_prec || !tun(d).wino_cp || tun(d).wino_yfast || tun(d).wino_prio) return false;
-  if (d.stat_slots || !d.scale || !d.shift) return false;
+  if (d.stat_slots) return false;   // (a missing scale / shift array is 1 / 0 in the kernels, as in the C++ epilogue)
   if (is_wide(d)) {
     if (d.N & 63) return false;
   } else {   // narrow kernels: exactly one 32-channel tile, 2 or 4 chunks (their weight pieces stay in registers), the C++ kernel's
