@@ -179,6 +179,12 @@ int mgu_adam_step(mgu_ctx* ctx, void* flat_param_dev, const void* flat_grad_dev,
                   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                   float grad_scale, void* hip_stream);
 
+/* torch.optim.SGD(lr, momentum, weight_decay).step() on the flat buffers -- the other optimizer branch of the reference's train loop
+ * (scripts/train_segmentation.py:97-98, selected by configs/training.yaml:5-6; dampening 0, no Nesterov): g = grad_scale*grad + wd*p;
+ * momentum != 0: buf = (step == 1 ? g : momentum*buf + g), p -= lr*buf; momentum == 0: p -= lr*g (momentum_buf_dev may be NULL). */
+int mgu_sgd_step(mgu_ctx* ctx, void* flat_param_dev, const void* flat_grad_dev, void* momentum_buf_dev, int64_t n, float lr,
+                 float momentum, float weight_decay, int step, float grad_scale, void* hip_stream);
+
 /* ---- gradient exchange of the data-parallel train step: RCCL over xGMI (the reference is single-process and has no
  *      collective; BASELINE configs[4] adds exactly this one, SURVEY sections 5 / 8b / 8e) -------------------------------
  * librccl is bound at run time inside libmgunet.so.  The host only moves 128 bytes: rank 0 calls mgu_comm_get_unique_id,

@@ -213,6 +213,8 @@ hipError_t launch_pack_convt_dgrad_w(const float* w, float* wp, int Cin, int Cou
 hipError_t launch_unpack_conv_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cout, int Cin, int Cp, int KS,
                                    int Kp, hipStream_t s, double* fold_slots = nullptr, int fold_rows = 0, int fold_n = 0, float* fold_out = nullptr);
 hipError_t launch_unpack_convt_grad(const float* dwp, int groups, size_t panel_stride, float* g, int Cin, int Cout, int Kp, hipStream_t s);
+hipError_t launch_sgd(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd, int step, float grad_scale,
+                      hipStream_t s);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                        float wd, int step, float grad_scale, hipStream_t s);
 

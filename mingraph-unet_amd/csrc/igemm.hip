@@ -325,6 +325,10 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x70 | 0xF00);
 }
 
+#if defined(MGU_DIAG) && MGU_DIAG == 50
+__device__ unsigned mgu_diag_glds_bad;
+__device__ unsigned long long mgu_diag_glds_n;
+#endif
 template <typename T, int NP, int TH, int WAVES_M, int WAVES_N, int WMT, int WNT, int TPS>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d, const int tiles_x, const int tiles_y,
                                                            const int total_patches, const int patches_per_block, const int yfast) {
@@ -499,15 +503,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
   };
   // workgroup barrier.  GLDS: the raw form -- __syncthreads() drains vmcnt while an LDS-DMA is in flight (its fence), i.e. the weight
   // tile requested at the top of the step would be waited for at once; the waits for the DMA are counted by hand below
+  // The raw form carries no fence of its own (s_barrier is IntrNoMem), so the two compiler-only ordering points keep every LDS access
+  // of the source on its side of the barrier -- the fragment reads of Bs / Hs must not rise above it, the halo stores must not sink
+  // below it -- without emitting a wait: an empty asm with a "memory" clobber generates no instruction and, unlike a workgroup fence,
+  // no vmcnt(0).
   auto wg_barrier = [&]() {
     if constexpr (GLDS) {
+      asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
       __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     } else {
       __syncthreads();
     }
   };
-  constexpr int NST = WMT * WNT * 16 < 63 ? WMT * WNT * 16 : 63;   // output stores of an interior patch per lane (vmcnt counts to 63)
+  // The counted vmcnt waits below name LOWER bounds of what this wave has in flight behind the awaited DMA (a smaller count waits
+  // for more, never for less): an interior patch's epilogue issues exactly one buffer store per accumulator register (store_patch,
+  // !GUARDED: WMT * WNT * 16; the pooled stores come on top) and load_halo issues exactly HR buffer loads -- the two constants the
+  // waits are built from.  vmcnt counts to 63.
+  constexpr int STORES_PER_INTERIOR_PATCH = WMT * WNT * 16;
+  constexpr int NST = STORES_PER_INTERIOR_PATCH < 63 ? STORES_PER_INTERIOR_PATCH : 63;
+  static_assert(NST <= STORES_PER_INTERIOR_PATCH && NST <= 63, "vmcnt count above the stores really issued");
   int w0 = 0;                // (GLDS) stores issued behind the weight DMA of the NEXT item's first step: NST after an interior patch
   load_next_halo(Set0{});
   if constexpr (GLDS) {
@@ -562,6 +578,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmDesc d,
       }
       wg_barrier();  // Bs[par] (and a fresh halo when tap == 0) visible; the buffer of the previous step no longer read
       HALO_T(1);
+#if defined(MGU_DIAG) && MGU_DIAG == 50
+      // one-shot checking build (never shipped): the weight tile of THIS step, as it stands in LDS behind the hand-counted wait and
+      // the barrier, against its global source; a mismatch sets bit 0 of mgu_diag_glds_bad, every compared 16-byte piece counts in
+      // mgu_diag_glds_n (tests read both through mgu_diag_glds_read)
+      if constexpr (GLDS) {
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt) {
+          const int k0 = (tap * TPS + tt) * d.Cp + c * CK;
+          for (int e = tid; e < BN * 8; e += 256) {
+            const int row = e >> 3, piece = e & 7;
+            const int pos = piece ^ ((row >> 1) & 7);      // LDS position of logical piece `piece` of the row
+            const u32x4 got = *reinterpret_cast<const u32x4*>(Bs + ((size_t)(par * TPS + tt) * BN + row) * BROW + pos * VEC);
+            const u32x4 ref = *reinterpret_cast<const u32x4*>(w_t + (size_t)(bn0 + row) * d.Kp + k0 + piece * VEC);
+            if (got[0] != ref[0] || got[1] != ref[1] || got[2] != ref[2] || got[3] != ref[3]) atomicOr(&mgu_diag_glds_bad, 1u);
+          }
+          if (tid == 0) atomicAdd(&mgu_diag_glds_n, (unsigned long long)(BN * 8));
+        }
+      }
+#endif
       if constexpr (GLDS) {   // the tile of step s + NBUF - 1 into the buffer the previous step read
         constexpr int ahead = NBUF - 1;
         const int tgt = NBUF == 2 ? (par ^ 1) : (par == 0 ? 2 : par - 1);
@@ -857,5 +892,18 @@ hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s) {
 extern "C" int mgu_diag_read(unsigned long long* out, int n) {
   if (n > 4 * 256 * 4) n = 4 * 256 * 4;
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mgu::mgu_halo_ts), (size_t)n * sizeof(unsigned long long));
+}
+#endif
+
+#if defined(MGU_DIAG) && MGU_DIAG == 50
+// checking build: (mismatch flag, 16-byte pieces compared) of the LDS-DMA weight tiles since the last call; clears both
+extern "C" int mgu_diag_glds_read(unsigned* bad, unsigned long long* n) {
+  unsigned z = 0;
+  unsigned long long zn = 0;
+  if (hipMemcpyFromSymbol(bad, HIP_SYMBOL(mgu::mgu_diag_glds_bad), sizeof(unsigned)) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(mgu::mgu_diag_glds_n), sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mgu::mgu_diag_glds_bad), &z, sizeof z) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mgu::mgu_diag_glds_n), &zn, sizeof zn) != hipSuccess) return -1;
+  return 0;
 }
 #endif

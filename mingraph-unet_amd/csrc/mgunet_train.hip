@@ -514,4 +514,15 @@ int mgu_adam_step(mgu_ctx* c, void* flat_param_dev, const void* flat_grad_dev, v
   return MGU_OK;
 }
 
+int mgu_sgd_step(mgu_ctx* c, void* flat_param_dev, const void* flat_grad_dev, void* momentum_buf_dev, int64_t n, float lr,
+                 float momentum, float weight_decay, int step, float grad_scale, void* hip_stream) {
+  if (!c) return MGU_ERR_INVALID;
+  if (!flat_param_dev || !flat_grad_dev || (momentum != 0.f && !momentum_buf_dev) || n < 0 || step < 1 || momentum < 0.f)
+    return fail(c, MGU_ERR_INVALID, "bad sgd args (step counts from 1; a momentum buffer when momentum != 0)");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, launch_sgd((float*)flat_param_dev, (const float*)flat_grad_dev, (float*)momentum_buf_dev, n, lr, momentum, weight_decay,
+                       step, grad_scale, (hipStream_t)hip_stream));
+  return MGU_OK;
+}
+
 }  // extern "C"

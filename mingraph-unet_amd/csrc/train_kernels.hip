@@ -673,4 +673,24 @@ hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, 
   return hipGetLastError();
 }
 
+// torch.optim.SGD(lr, momentum, weight_decay) on the flat buffer (scripts/train_segmentation.py:97-98; dampening 0, no Nesterov):
+//   g = grad_scale * grad + wd * p;  buf = step == 1 ? g : momentum * buf + g  (momentum != 0);  p -= lr * (momentum ? buf : g)
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, int64_t n, float lr,
+                           float momentum, float wd, int first, float grad_scale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    float d = g[i] * grad_scale + wd * pi;
+    if (momentum != 0.f) {
+      d = first ? d : momentum * buf[i] + d;
+      buf[i] = d;
+    }
+    p[i] = pi - lr * d;
+  }
+}
+hipError_t launch_sgd(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float wd, int step, float grad_scale,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(sgd_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, p, g, buf, n, lr, momentum, wd, step == 1 ? 1 : 0, grad_scale);
+  return hipGetLastError();
+}
+
 }  // namespace mgu

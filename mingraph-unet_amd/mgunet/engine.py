@@ -214,7 +214,7 @@ class Trainer:
     own shard (DDP semantics)."""
 
     def __init__(self, model: UNet, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None, comm="auto",
-                 loss="ce", dice_smooth=1.0):
+                 loss="ce", dice_smooth=1.0, optimizer="adam", momentum=0.9):
         """comm: "auto" (default) -- with more than one rank the gradient is mean-all-reduced by torch.distributed (RCCL when the
         backend is "nccl") after backward: the path exercised with two ranks.  "rccl" -- opt in to libmgunet's own RCCL
         communicator with the bucketed exchange overlapped with backward (mgu_unet_backward_allreduce); tests/test_gpu_rccl.py
@@ -222,7 +222,12 @@ class Trainer:
         loss: "ce" -- nn.CrossEntropyLoss() alone (train_segmentation.py:91,127); "ce+dice" -- the sum the script forms at
         :126-130, `criterion_ce(logits, masks) + dice_loss(logits, masks)`: the Dice gradient (through the softmax) is added to
         the cross-entropy gradient in the same dlogits buffer (mgu_dice_loss_backward, accumulate) before the one backward pass.
-        ("rccl" also creates the communicator for a single process: the collective then degenerates to a copy.)"""
+        ("rccl" also creates the communicator for a single process: the collective then degenerates to a copy.)
+        optimizer: "adam" (train_segmentation.py:96, the shipped configs/training.yaml) or "sgd" -- the script's other branch,
+        optim.SGD(lr, momentum=sgd_momentum, weight_decay) (:97-98; training.yaml:5-6): one fused kernel on the flat buffers either way."""
+        if optimizer not in ("adam", "sgd"):
+            raise ValueError(f"unknown optimizer {optimizer!r}: 'adam' or 'sgd'")
+        self.optimizer, self.momentum = optimizer, float(momentum)
         params = list(model.named_parameters())
         if not params or not params[0][1].is_cuda:
             raise RuntimeError("move the model to a HIP device before building a Trainer (no CPU fallback)")
@@ -297,12 +302,39 @@ class Trainer:
         """What torch.optim.Adam(model.parameters(), lr, weight_decay=wd).state_dict() would hold after the same steps: per
         parameter {'step', 'exp_avg', 'exp_avg_sq'} (views of the flat moment buffers, cloned) + one param_group.  Loadable into a
         real torch.optim.Adam, and back (load_optimizer_state_dict)."""
+        if self.optimizer == "sgd":   # torch.optim.SGD's layout: {'momentum_buffer'} per parameter, one param_group
+            params = [p for _, p in self.model.named_parameters()]
+            state, off = {}, 0
+            for i, p in enumerate(params):
+                k = p.numel()
+                if self.step_count > 0 and self.momentum != 0:
+                    state[i] = {"momentum_buffer": self.exp_avg[off:off + k].view_as(p).clone()}
+                off += k
+            return {"state": state, "param_groups": [{"lr": self.lr, "momentum": self.momentum, "dampening": 0, "weight_decay": self.wd,
+                                                      "nesterov": False, "maximize": False, "foreach": None, "differentiable": False,
+                                                      "fused": None, "params": list(range(len(params)))}]}
         return adam_state_dict([p for _, p in self.model.named_parameters()], self.exp_avg, self.exp_avg_sq, self.step_count,
                                self.lr, self.betas, self.eps, self.wd)
 
     def load_optimizer_state_dict(self, sd: dict) -> None:
         params = [p for _, p in self.model.named_parameters()]
         g = sd["param_groups"][0]
+        if self.optimizer == "sgd":
+            if len(sd["param_groups"]) != 1 or list(g["params"]) != list(range(len(params))):
+                raise ValueError("expected the single param_group of optim.SGD(model.parameters(), ...) (train_segmentation.py:98)")
+            self.lr, self.momentum, self.wd = float(g["lr"]), float(g["momentum"]), float(g["weight_decay"])
+            off, have = 0, 0
+            for i, p in enumerate(params):
+                k = p.numel()
+                st = sd["state"].get(i)
+                if st is not None and st.get("momentum_buffer") is not None:
+                    self.exp_avg[off:off + k].copy_(st["momentum_buffer"].reshape(-1))
+                    have += 1
+                off += k
+            if have not in (0, len(params)):
+                raise ValueError("a momentum buffer for some parameters only cannot be represented by the fused flat SGD")
+            self.step_count = 2 if have else 0     # SGD keeps no step count: any value past the first step continues the buffers
+            return
         if len(sd["param_groups"]) != 1 or list(g["params"]) != list(range(len(params))):
             raise ValueError("expected the single param_group of optim.Adam(model.parameters(), ...) (train_segmentation.py:96)")
         self.lr, self.betas, self.eps, self.wd = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
@@ -387,10 +419,15 @@ class Trainer:
         ctx = model._context(dev)
         self.step_count += 1
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mgu_adam_step(ctx.handle, self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
-                                                self.exp_avg_sq.data_ptr(), self.flat.numel(), self.lr, self.betas[0],
-                                                self.betas[1], self.eps, self.wd, self.step_count, grad_scale,
-                                                _lib.current_stream_ptr(dev)), ctx.handle)
+            if self.optimizer == "sgd":   # the momentum buffer lives in exp_avg (exp_avg_sq is unused by this branch)
+                _lib.check(_lib.lib().mgu_sgd_step(ctx.handle, self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                   self.flat.numel(), self.lr, self.momentum, self.wd, self.step_count, grad_scale,
+                                                   _lib.current_stream_ptr(dev)), ctx.handle)
+            else:
+                _lib.check(_lib.lib().mgu_adam_step(ctx.handle, self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                    self.exp_avg_sq.data_ptr(), self.flat.numel(), self.lr, self.betas[0],
+                                                    self.betas[1], self.eps, self.wd, self.step_count, grad_scale,
+                                                    _lib.current_stream_ptr(dev)), ctx.handle)
         model.refresh_packed_weights(dev)   # same tensors, new contents: repack in place (no state_dict round trip per step)
 
     def train_step(self, images: torch.Tensor, masks: torch.Tensor) -> torch.Tensor:
@@ -410,11 +447,13 @@ class FlatAdam:
     gradient buffer that autograd accumulates into, and step() is one mgu_adam_step launch.  (`Trainer` does the same for the U-Net,
     whose flat order the library fixes; this is the graph branch's half.)"""
 
-    def __init__(self, modules, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, modules, lr=1e-3, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-8, exclude=()):
+        """exclude: parameter-name fragments (as in named_parameters()) left out of the flat buffers -- parameters whose .grad stays
+        None in the reference loop: torch.optim.Adam skips those entirely (no step count, no weight decay)."""
         seen, params = set(), []
         for m in modules:
-            for q in m.parameters():
-                if id(q) not in seen and q.requires_grad:
+            for name, q in m.named_parameters():
+                if id(q) not in seen and q.requires_grad and not any(x in name for x in exclude):
                     seen.add(id(q))
                     params.append(q)
         if not params or not params[0].is_cuda:
@@ -474,15 +513,19 @@ class E2ETrainer:
     the same parameters after it.  The placeholders are ARGUMENTS here (the script draws them from torch's RNG per image)."""
 
     def __init__(self, unet_trainer: Trainer, patch_gat: GATNetwork, segment_predictor, mincut, feature_loss, num_segments: int = 2,
-                 l_feature_weight: float = 0.1, l_partition_weight: float = 0.5, extra_modules=()):
+                 l_feature_weight: float = 0.1, l_partition_weight: float = 0.5, extra_modules=(),
+                 untouched_params=("fc_bbox", "fc_class_scores")):
         """extra_modules: the sub-models the loss does not reach but the script's optimizer holds (region GAT, FeatureFusion,
-        DetectionHead, train_end_to_end.py:223-226): stepped with zero gradients, i.e. the weight-decay term alone."""
+        DetectionHead, train_end_to_end.py:223-226): stepped with zero gradients, i.e. the weight-decay term alone.
+        untouched_params: name fragments of parameters that are NOT on the path to pred_confidence, the one head output the script's
+        loss touches (train_end_to_end.py:462) -- DetectionHead.fc_bbox and .fc_class_scores (detection_head.py:57,67): their .grad
+        stays None in the reference, so its Adam never steps or decays them, and neither does this one."""
         self.unet = unet_trainer
         self.patch_gat, self.predictor, self.mincut, self.feature_loss = patch_gat, segment_predictor, mincut, feature_loss
         self.K, self.wf, self.wp = num_segments, l_feature_weight, l_partition_weight
         self.extra_modules = [m for m in extra_modules if any(True for _ in m.parameters())]
         self.graph_opt = FlatAdam([patch_gat, segment_predictor, *self.extra_modules], lr=unet_trainer.lr, weight_decay=unet_trainer.wd,
-                                  betas=unet_trainer.betas, eps=unet_trainer.eps)
+                                  betas=unet_trainer.betas, eps=unet_trainer.eps, exclude=tuple(untouched_params))
         self._batch_graph = None
 
     def _block_diagonal(self, edge_index: torch.Tensor, Np: int, B: int):

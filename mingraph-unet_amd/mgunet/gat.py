@@ -144,12 +144,24 @@ def seed_dropout(seed: int) -> None:
     _DROPOUT["seed"], _DROPOUT["stream"] = int(seed) & (2 ** 64 - 1), 0
 
 
+def _rank_key() -> int:
+    """(rank of a data-parallel run, 0 otherwise): folded into the Philox key so that the ranks of one job draw DIFFERENT masks on
+    their different shards from the same seed (torch's per-process generators differ the same way)."""
+    try:
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    except Exception:
+        return 0
+
+
 def _draw_mask(ctx, dev, shape, p: float) -> torch.Tensor:
-    """nn.Dropout's mask (0 or 1 / (1 - p)) from Philox-4x32-10 on the device: element i of stream s under the seed."""
+    """nn.Dropout's mask (0 or 1 / (1 - p)) from Philox-4x32-10 on the device: element i of stream s under the key
+    seed + 0x9E3779B97F4A7C15 * (rank, device index): ranks and devices of one process group never share a mask sequence."""
     m = torch.empty(shape, device=dev, dtype=torch.float32)
     _DROPOUT["stream"] += 1
+    key = (_DROPOUT["seed"] + 0x9E3779B97F4A7C15 * (_rank_key() * 64 + (dev.index or 0))) & (2 ** 64 - 1)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib().mgu_dropout_mask(ctx.handle, _DROPOUT["seed"], _DROPOUT["stream"], m.numel(), float(p), m.data_ptr(),
+        _lib.check(_lib.lib().mgu_dropout_mask(ctx.handle, key, _DROPOUT["stream"], m.numel(), float(p), m.data_ptr(),
                                                _lib.current_stream_ptr(dev)), ctx.handle)
     return m
 

@@ -294,3 +294,57 @@ def test_optimizer_step_invalidates_the_models_other_contexts(cuda):
         want = fresh.to(cuda).eval()(x)[0]
     assert float((after - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))
     assert float((after - before).abs().max()) > 1e-3   # the step really changed the output
+
+
+def test_sgd_kernel_matches_torch_optim_sgd(cuda):
+    """mgu_sgd_step against torch.optim.SGD(lr, momentum, weight_decay) itself (scripts/train_segmentation.py:97-98) over three steps:
+    first step (buffer = gradient), later steps (momentum * buffer + gradient), and momentum 0 (no buffer)."""
+    from mgunet import _lib
+    from mgunet.gat import _context
+    n = 50021
+    p0 = torch.from_numpy(O.formula_normal("sgd/p", (n,), seed=1))
+    grads = [torch.from_numpy(O.formula_normal(f"sgd/g{i}", (n,), seed=2 + i)) * 1e-2 for i in range(3)]
+    ctx = _context(cuda)
+    for momentum in (0.9, 0.0):
+        ref = torch.nn.Parameter(p0.clone().double())
+        opt = torch.optim.SGD([ref], lr=1e-2, momentum=momentum, weight_decay=1e-4)
+        dp, buf = p0.clone().to(cuda), torch.zeros(n, device=cuda)
+        for step, g in enumerate(grads, 1):
+            ref.grad = g.double()
+            opt.step()
+            _lib.check(_lib.lib().mgu_sgd_step(ctx.handle, dp.data_ptr(), g.to(cuda).data_ptr(), buf.data_ptr() if momentum else None, n,
+                                               1e-2, momentum, 1e-4, step, 1.0, _lib.current_stream_ptr(cuda)), ctx.handle)
+            assert float((dp.cpu().double() - ref.detach()).abs().max()) <= 2e-7 * step
+        if momentum:
+            assert float((buf.cpu().double() - opt.state[ref]["momentum_buffer"]).abs().max()) <= 1e-8
+
+
+def test_trainer_with_sgd_follows_torch_optim_sgd_and_interchanges_state(cuda):
+    """Trainer(optimizer='sgd'): two train steps; the parameters follow torch.optim.SGD applied to the trainer's own gradients, and the
+    optimizer state loads into a real torch.optim.SGD and back."""
+    cfg, shape = (3, 2, 8, 2), (2, 3, 32, 32)
+    x = torch.from_numpy(O.formula_normal("sgdt/x", shape, seed=31)).to(cuda)
+    y = torch.from_numpy(O.formula_labels("sgdt/y", (2, 32, 32), 2, seed=32)).to(cuda)
+    model = build(cfg, 31, cuda)
+    tr = mgunet.Trainer(model, lr=5e-3, weight_decay=1e-4, optimizer="sgd", momentum=0.9)
+    names = [n for n, _ in model.named_parameters()]
+    shadow = [torch.nn.Parameter(p.detach().clone().double()) for _, p in model.named_parameters()]
+    opt = torch.optim.SGD(shadow, lr=5e-3, momentum=0.9, weight_decay=1e-4)
+    for step in range(2):
+        tr.forward_backward(x, y)
+        for s_, (_, p) in zip(shadow, model.named_parameters()):
+            s_.grad = p.grad.detach().clone().double()
+        opt.step()
+        tr.optimizer_step()
+        for n_, s_, (_, p) in zip(names, shadow, model.named_parameters()):
+            assert float((p.detach().double() - s_.detach()).abs().max()) <= 1e-6, (step, n_)
+            s_.data.copy_(p.detach().double())     # keep the shadow on the fp32 trajectory
+    sd = tr.optimizer_state_dict()
+    opt2 = torch.optim.SGD([torch.nn.Parameter(p.detach().clone()) for _, p in model.named_parameters()], lr=1.0, momentum=0.5)
+    opt2.load_state_dict(sd)
+    assert opt2.param_groups[0]["momentum"] == 0.9 and opt2.param_groups[0]["lr"] == 5e-3
+    tr2 = mgunet.Trainer(build(cfg, 31, cuda), optimizer="sgd")
+    tr2.load_optimizer_state_dict(opt2.state_dict())
+    assert tr2.momentum == 0.9 and torch.equal(tr2.exp_avg, tr.exp_avg)
+    with pytest.raises(ValueError):
+        mgunet.Trainer(build(cfg, 31, cuda), optimizer="rmsprop")
