@@ -169,10 +169,18 @@ def roofline_from(stats, nprof, arithmetic, traffic=None):
 
 def load_traffic(kernel, dtype):
     """HBM bytes per launch of `kernel` from this round's committed PMC passes (rocprofv3 cannot run inside this process)."""
-    tj = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_traffic_{dtype}.json") for r in ("r04", "r03", "r02")) if os.path.exists(q)), None)
+    tj = next((q for q in (os.path.join(ROOT, "profiles", f"{r}_traffic_{dtype}.json") for r in ("r05", "r04", "r03", "r02")) if os.path.exists(q)), None)
     if tj is None:
         return None
     t = json.load(open(tj))
+    # a stamped file (round 5 on) names the library build its counters were taken from: a different library -> the bytes describe other
+    # kernels, so the field is dropped rather than quoted stale
+    if t.get("lib_build_id") is not None:
+        import hashlib
+        from mgunet import _lib as _l
+        cur = hashlib.sha256(open(_l.LIB_PATH, "rb").read()).hexdigest()[:16]
+        if cur != t["lib_build_id"]:
+            return None
     base = kernel.split("<")[0].split(" ")[0]
     args = kernel.split("<")[1].split(">")[0].replace(" ", "") if "<" in kernel else ""
     exact = bool(args) and all(ch.isdigit() or ch == "," for ch in args)    # literal template arguments: one instantiation

@@ -6,7 +6,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 import os
 rows = list(csv.DictReader(open(max(glob.glob(root + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime))))
-ig = [r for r in rows if any(t in r["Kernel_Name"] for t in ("igemm", "convt2x2", "conv3x3_halo", "conv3x3_first", "wino3x3", "head_kernel", "patch_mean_kernel"))]
+ig = [r for r in rows if any(t in r["Kernel_Name"] for t in ("igemm", "convt2x2", "conv3x3_halo", "conv3x3_first", "wino3x3", "mgu_wino_cp", "head_kernel", "patch_mean_kernel"))]
 last = ig[-23:]   # the 23 conv launches of the last U-Net forward
 def convf(h, cin, cout): return 2 * B * h * h * 9 * cin * cout
 layers = []
@@ -25,7 +25,7 @@ for (name, fl), r in zip(layers, last):
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     tot += d
     kname = r["Kernel_Name"]
-    tag = "head<" if ("head_kernel" in kname or "patch_mean" in kname) else "first<" if "conv3x3_first" in kname else "wino<" if "wino3x3" in kname else "halo<" if "halo" in kname else "convt_x3<" if "convt2x2" in kname else "igemm<"
+    tag = "head<" if ("head_kernel" in kname or "patch_mean" in kname) else "first<" if "conv3x3_first" in kname else "wino<" if "wino3x3" in kname else "wino_asm<" + kname.split("_gfx950")[0][-5:] + " " if "mgu_wino_cp" in kname else "halo<" if "halo" in kname else "convt_x3<" if "convt2x2" in kname else "igemm<"
     kn = tag + (kname.split("<")[1].split(">")[0].replace(" ", "") if "<" in kname else "?") + ">"
     print(f"{name:9s} {kn:22s} grid={r['Grid_Size_X']:>9s}x{r['Grid_Size_Y']:>4s} {d:8.1f} us {fl/d/1e6:7.1f} TF/s vgpr={r['VGPR_Count']}+{r['Accum_VGPR_Count']} lds={r['LDS_Block_Size']}")
 print("total us", round(tot, 1))

@@ -36,7 +36,17 @@ for k, e in agg.items():
         continue
     rd, wr = e["read_bytes"] / e["fetch_n"], e["write_bytes"] / max(e["write_n"], 1)
     kern[k] = {"launches": e["fetch_n"], "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr), "hbm_bytes_per_launch": round(rd + wr)}
-j = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; tools/gpu_pmc.sh + tools/traffic_kernels.py) over `"
+def lib_build_id():
+    """first 16 hex digits of the SHA-256 of the library the passes ran (bench.py drops `roofline.traffic` when it differs from the
+    library it is running)"""
+    import hashlib
+    lib = os.environ.get("MGU_LIB_PATH") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mingraph-unet_amd", "lib",
+                                                         "libmgunet.so")
+    return hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None
+
+
+j = {"lib_build_id": lib_build_id(),
+     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only; tools/gpu_pmc.sh + tools/traffic_kernels.py) over `"
                + cmd + "`",
      "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md HBM section), WRITE_SIZE exact",
      "kernels": kern,
