@@ -183,6 +183,8 @@ def load_traffic(kernel, dtype):
             return None
     base = kernel.split("<")[0].split(" ")[0]
     args = kernel.split("<")[1].split(">")[0].replace(" ", "") if "<" in kernel else ""
+    if base.startswith("mgu_wino_cp"):     # assembly kernels: the profiler knows them by their symbol, the label's "(asm form of ...<2>)" is prose
+        args = ""
     exact = bool(args) and all(ch.isdigit() or ch == "," for ch in args)    # literal template arguments: one instantiation
     n = b = 0
     for k, v in t.get("kernels", {}).items():
