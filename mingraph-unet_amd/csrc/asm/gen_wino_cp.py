@@ -283,6 +283,10 @@ def emit_step_spread(jp, s):
     a0, a1 = opt("sp_v0", (2, 6)), opt("sp_v1", (7, 10))      # gap ranges of the two transform halves
     per0 = -(-34 // (a0[1] - a0[0] + 1))
     per1 = -(-34 // (a1[1] - a1[0] + 1))
+    pr = opt("prio")                      # timing experiments: s_setprio per (jp, step)
+    if pr and pr[jp][s] != pr[jp][(s + 3) & 3]:
+        E(f"s_setprio {pr[jp][s]}")
+    nlds = 0                              # LDS operations issued in this step so far (all younger than half 0's reads)
     for k in range(12):
         if not opt("no_mfma"):
             E(mf[k])
@@ -290,11 +294,13 @@ def emit_step_spread(jp, s):
             E(x)
         for x in extra.get(k, []):
             E(x)
+            nlds += x.startswith("ds_")
         if k in (0, 1):
+            nlds += min(2, len(r1))
             take(r1, 2)
         if k == a0[0]:
-            # half 0 (requested in the previous step); the four reads of half 1 (and step 0's three halo stores) may be in flight
-            E(f"s_waitcnt lgkmcnt({7 if extra and not opt('no_halo') else 4})")
+            # half 0 (requested in the previous step) complete: everything issued in this step so far may stay in flight
+            E(f"s_waitcnt lgkmcnt({nlds})")
         if a0[0] <= k <= a0[1]:
             take(v0, per0)
         if k == a1[0]:
@@ -310,7 +316,88 @@ def emit_step_spread(jp, s):
     assert not v1 and not r1 and not r2
 
 
+def emit_step_pp(jp, s):
+    """Ping-pong schedule (option pingpong): a wave alternates a PURE matrix phase (the step's twelve MFMAs back to back) with a
+    transform phase (wait for the raw operands requested before the burst, 68 VALU into the single operand-piece slot), and the two
+    waves of a SIMD run the phases in opposite order -- waves 0-3 (jp 0): M(s) then V(s + 1); waves 4-7 (jp 1): V(s) then M(s) -- so
+    one wave's transform always lies beside its partner's burst (tools/ubench: a burst of 8 MFMAs followed by 48 VALU, two waves per
+    SIMD: both finish together at 100 % of the matrix pipe; the same work interleaved per gap: 75-93 %).  One operand-piece slot and
+    one raw set per wave; the raw reads of the next transform are issued right in front of the burst."""
+    jj, mi = s >> 1, s & 1
+    X = jp == 0
+    ns = (s + 1) & 3
+    stamp(2 + s if s < 3 else 5)          # starts of steps 0..2; arrival at B1
+    if s == 3:
+        E("s_waitcnt lgkmcnt(0)")
+        if not opt("no_barrier"):
+            E("s_barrier")                # B1: the next chunk is complete in the other buffer (first read of it: this step)
+        stamp(6)
+    def reads(step):
+        if not opt("no_ldsread"):
+            for r in raw_reads(jp, step >> 1, step & 1):
+                E(r)
+    def flip():
+        E(f"v_xor_b32_e32 v{VA}, 0x{BUFX:x}, v{VA}")
+        E(f"v_xor_b32_e32 v{VB}, 0x{BUFX:x}, v{VB}")
+    def staging():
+        if opt("no_halo"):
+            return
+        for i in range(3):
+            E(f"ds_write_b128 v{VHST[i]}, {vr(HREG(i), 4)}")
+        for i in range(3):
+            E(f"v_xor_b32_e32 v{VHST[i]}, 0x{BUFX:x}, v{VHST[i]}")
+        halo_loads(True)
+    def V(step):                          # transform + split of `step`'s operands into slot 0
+        E("s_waitcnt lgkmcnt(0)")
+        if not opt("no_valu"):
+            for hf in range(2):
+                for x in form_valu(jp, step >> 1, 0, hf):
+                    E(x)
+    def M():
+        mf = mfmas(jj, mi, 0)
+        wl = {}
+        if mi == 1 and not opt("no_wload"):
+            wl = {1: [weight_load(jj, 0, 2)], 4: [weight_load(jj, 0, 1)], 5: [weight_load(jj, 0, 0)],
+                  7: [weight_load(jj, 1, 2)], 10: [weight_load(jj, 1, 1)], 11: [weight_load(jj, 1, 0)]}
+        if opt("pp_prio"):
+            E("s_setprio 1")
+        for k in range(12):
+            if not opt("no_mfma"):
+                E(mf[k])
+            for x in wl.get(k, []):
+                E(x)
+        if opt("pp_prio"):
+            E("s_setprio 0")
+    if X:
+        if s == 3:
+            flip()
+        reads(ns)                         # operands of the NEXT step: requested in front of the burst, transformed behind it
+        if s == 0:
+            E("s_waitcnt vmcnt(6)")       # weight pieces of component 0 (step 1 of the previous chunk); younger: the six of step 3
+        if s == 2:
+            E("s_waitcnt vmcnt(9)")       # pieces of step 3 of the previous chunk; younger: 3 halo loads + 6 pieces of step 1
+        M()
+        V(ns)
+        if s == 0:
+            staging()                     # halo registers are older than the pieces waited for above
+    else:
+        if s == 0:
+            E("s_waitcnt vmcnt(12)")      # the halo registers (both sets of weight pieces are younger)
+        V(s)
+        if s == 0:
+            staging()
+        if s == 3:
+            flip()
+        reads(ns)
+        E("s_nop 1")
+        if s in (0, 2):
+            E("s_waitcnt vmcnt(9)")       # this component's pieces; younger: the other six + three halo loads (step 0: just issued)
+        M()
+
+
 def emit_step(jp, s):
+    if opt("pingpong"):
+        return emit_step_pp(jp, s)
     if opt("spread", 1):
         return emit_step_spread(jp, s)
     jj, mi, slot = s >> 1, s & 1, s & 1
@@ -380,7 +467,7 @@ def emit_chunk(jp):
     if not opt("no_barrier"):
         E("s_barrier")                    # B0
     stamp(1)
-    inl = opt("spread", 1) and opt("stage_in_step0", 1)
+    inl = (opt("spread", 1) and opt("stage_in_step0", 1)) or opt("pingpong")
     if not inl:
         E("s_waitcnt vmcnt(12)")          # the halo registers (two sets of weight pieces are younger)
         if not opt("no_halo"):
@@ -441,6 +528,8 @@ def emit_epilogue(jp):
     SHW = [E0 + 6, E0 + 7]
     e0, e1, e2, e3 = E0 + 8, E0 + 9, E0 + 10, E0 + 11
     TMP = [216 + i for i in range(8)]
+    if opt("pingpong"):                   # the whole raw set may hold the next patch's first operands: four share temporaries
+        TMP = [e0, e1, e2, e3] * 2        # (e0..e3 are dead once the addresses are formed)
     E("s_nop 7")
     E("s_nop 7")
     E("s_nop 7")
@@ -1116,13 +1205,17 @@ def emit_dump(first_reg):
 
 def emit_first_form(jp):
     """step 0 of the first chunk (no MFMAs to hide behind)"""
+    if opt("pingpong") and jp == 1:       # waves 4-7 transform inside the loop: only the request
+        for r in raw_reads(jp, 0, 0):
+            E(r)
+        return
     for r in raw_reads(jp, 0, 0):
         E(r)
     E("s_waitcnt lgkmcnt(0)")
     for hf in range(2):
         for x in form_valu(jp, 0, 0, hf):
             E(x)
-    if opt("spread", 1):
+    if opt("spread", 1) and not opt("pingpong"):
         for r in raw_reads(jp, 0, 1)[0:4]:
             E(r)
 
@@ -1231,9 +1324,9 @@ if os.environ.get("GEN_WINO_VARIANTS"):
         ("_v2", {"no_epilogue": 1, "no_valu": 1}),
         ("_v3", {"no_epilogue": 1, "no_mfma": 1}),
         ("_v4", {"no_epilogue": 1, "no_barrier": 1}),
-        ("_v5", {"stage_in_step0": 0}),
-        ("_v6", {"prio_jp1": 3}),
-        ("_v7", {"prio_jp0": 1}),
+        ("_v5", {"pingpong": 1}),
+        ("_v6", {"pingpong": 1, "pp_prio": 1}),
+        ("_v7", {"prio": ((0, 0, 1, 1), (1, 1, 0, 0))}),
         ("_v8", {"no_epilogue": 1, "stamp": 1}),
         ("_v9", {"no_epilogue": 1, "no_valu": 1, "stamp": 1}),
         ("_v10", {"no_epilogue": 1, "no_mfma": 1, "stamp": 1}),
@@ -1241,7 +1334,11 @@ if os.environ.get("GEN_WINO_VARIANTS"):
         ("_v12", {"no_epilogue": 1, "no_halo": 1, "stamp": 1}),
         ("_v13", {"no_epilogue": 1, "no_ldsread": 1, "stamp": 1}),
         ("_v15", {"no_epilogue": 1, "steptimes": 1}),
-        ("_v16", {"no_epilogue": 1, "steptimes": 1, "prio_jp1": 1}),
+        ("_v16", {"no_epilogue": 1, "steptimes": 1, "pingpong": 1}),
+        ("_v17", {"prio": ((0, 0, 0, 0), (0, 1, 0, 1))}),
+        ("_v18", {"sp_v0": (0, 5), "sp_v1": (6, 11)}),
+        ("_v19", {"sp_v0": (0, 5), "sp_v1": (6, 11), "prio": ((0, 0, 0, 0), (1, 0, 1, 0))}),
+        ("_v20", {"no_epilogue": 1, "steptimes": 1, "sp_v0": (0, 5), "sp_v1": (6, 11)}),
         ("_v14", {"no_epilogue": 1, "no_wload": 1, "no_halo": 1, "no_ldsread": 1, "no_valu": 1, "no_barrier": 1, "stamp": 1}),
     ]
 

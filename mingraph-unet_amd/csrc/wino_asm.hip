@@ -54,7 +54,7 @@ Plan plan_of(const IgemmDesc& d) {
   return p;
 }
 
-constexpr int MAX_VARIANTS = 24;   // wino_asm = 1: the shipping kernel; n > 1: timing-only variant _v(n-1) of a GEN_WINO_VARIANTS=1 build
+constexpr int MAX_VARIANTS = 32;   // wino_asm = 1: the shipping kernel; n > 1: timing-only variant _v(n-1) of a GEN_WINO_VARIANTS=1 build
 std::mutex g_mu;
 hipModule_t g_mod[64] = {};
 hipFunction_t g_fn[64][MAX_VARIANTS + 2] = {};   // loaded functions per device (the last two: the narrow kernels), written once under

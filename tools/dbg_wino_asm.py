@@ -8,8 +8,9 @@ from mgunet import gat as G
 
 cuda = torch.device("cuda:0")
 
+ASM_FLAG = os.environ.get("DBG_ASM_FLAG", "1")
 def conv(xin, wd, sc, sh, Cout, relu, flag):
-    os.environ["MGU_WINO_ASM"] = flag
+    os.environ["MGU_WINO_ASM"] = ASM_FLAG if flag == "1" else flag
     G._CTX.clear()
     B, H, W, Cin = xin.shape
     out = torch.full((B, H, W, Cout), -7.0, device=cuda)

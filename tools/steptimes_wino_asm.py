@@ -24,7 +24,7 @@ st = out.view(-1)[:256 * 8 * 8].view(torch.int32).view(256, 8, 8).cpu().long()
 names = ["B0 wait", "stage", "step0", "step1", "step2", "B1 wait", "step3a", "step3b"]
 d = (st[:, :, 1:] - st[:, :, :-1])              # 7 intervals
 tot = st[:, :, 7] - st[:, :, 0]
-print("intervals (cycles), median over workgroups, per wave (rows) x [B0wait, stage, step0, step1, B1wait, step2, step3] ; total")
+print("intervals (cycles), median over workgroups, per wave (rows) x [B0wait, stage, step0, step1, (spread: B1wait, step2 | pingpong: step2, B1wait), step3] ; total")
 for wv in range(8):
     print(f"wave {wv} (wi {wv & 3}, jp {wv >> 2}):", [int(d[:, wv, k].median()) for k in range(7)], int(tot[:, wv].median()))
 print("all waves median:", [int(d[:, :, k].median()) for k in range(7)], int(tot.median()))
