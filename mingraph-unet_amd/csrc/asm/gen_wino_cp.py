@@ -32,6 +32,10 @@ DEBUG = os.environ.get("GEN_WINO_DEBUG", "")
 #   valu_from     first MFMA gap of a step that carries transform work
 OPT = {}
 def opt(k, d=None): return OPT.get(k, d)
+def TT(i):
+    """cold-code temporary i (0 / 1): raw half 1's last registers; in the ping-pong experiment (whole raw set in flight across chunk tops)
+    the unused second operand-piece slot"""
+    return (198 + i) if OPT.get("pingpong") else (230 + i)
 
 # ---------------------------------------------------------------------------------------------------------------------
 # register map
@@ -54,7 +58,11 @@ VHST = [246, 247, 248]
 VHOFF = [249, 250, 251]
 VLANE16 = 252
 VTID = 253
-VT0, VT1 = 254, 255
+VT0, VT1 = 230, 231   # temporaries of the cold code (halo-offset setup, epilogue addressing, debug stores): the last two registers of raw half 1,
+                      # free at every point those run (narrow kernels: see emit_epilogue_n, which keeps its own temporaries clear of them)
+def VMASK(): return 254 if CFG["ntb"] == 2 else 172   # 0xffff0000 in a VGPR and the wave's transform sign (+-1.0) in a VGPR: with all-VGPR VOP2
+def VSGN(): return 255 if CFG["ntb"] == 2 else 173    # forms (v_fmac / v_add / v_sub / v_and) two waves of a SIMD issue the transform + split at
+                                                      # 2.4 cycles per instruction instead of 4 (tools/ubench/gen_issue_cost.py: mix2 vs mix)
 
 # SGPRs
 S_IN, S_WU, S_OUT, S_SCALE, S_SHIFT, S_POOL = 4, 6, 8, 10, 12, 14
@@ -126,28 +134,28 @@ def setup_load():
     E(f"s_sub_u32 s{S_T[7]}, s{S_X0}, 1")     # x0 - 1
     for i in range(3):
         d = VHOFF[i]
-        E(f"v_lshrrev_b32_e32 v{VT0}, 2, v{VTID}")
+        E(f"v_lshrrev_b32_e32 v{TT(0)}, 2, v{VTID}")
         if i:
-            E(f"v_add_u32_e32 v{VT0}, {128 * i}, v{VT0}")                    # hp
-        E(f"v_mul_u32_u24_e32 v{VT1}, 0x788, v{VT0}")
-        E(f"v_lshrrev_b32_e32 v{VT1}, 16, v{VT1}")                            # r = hp / 34
-        E(f"v_mul_u32_u24_e32 v{d}, 34, v{VT1}")
-        E(f"v_sub_u32_e32 v{d}, v{VT0}, v{d}")                                # cc
-        E(f"v_cmp_gt_u32_e32 vcc, 0x154, v{VT0}")                             # hp < 340
-        E(f"v_add_u32_e32 v{VT1}, s{S_T[6]}, v{VT1}")                         # y
+            E(f"v_add_u32_e32 v{TT(0)}, {128 * i}, v{TT(0)}")                    # hp
+        E(f"v_mul_u32_u24_e32 v{TT(1)}, 0x788, v{TT(0)}")
+        E(f"v_lshrrev_b32_e32 v{TT(1)}, 16, v{TT(1)}")                            # r = hp / 34
+        E(f"v_mul_u32_u24_e32 v{d}, 34, v{TT(1)}")
+        E(f"v_sub_u32_e32 v{d}, v{TT(0)}, v{d}")                                # cc
+        E(f"v_cmp_gt_u32_e32 vcc, 0x154, v{TT(0)}")                             # hp < 340
+        E(f"v_add_u32_e32 v{TT(1)}, s{S_T[6]}, v{TT(1)}")                         # y
         E(f"v_add_u32_e32 v{d}, s{S_T[7]}, v{d}")                             # x
-        E(f"v_cmp_gt_u32_e64 s[{S_M}:{S_M + 1}], s{S_H}, v{VT1}")
+        E(f"v_cmp_gt_u32_e64 s[{S_M}:{S_M + 1}], s{S_H}, v{TT(1)}")
         E(f"s_and_b64 vcc, vcc, s[{S_M}:{S_M + 1}]")
         E(f"v_cmp_gt_u32_e64 s[{S_M}:{S_M + 1}], s{S_W}, v{d}")
         E(f"s_and_b64 vcc, vcc, s[{S_M}:{S_M + 1}]")
-        E(f"v_mad_u32_u24 v{VT1}, v{VT1}, s{S_W}, v{d}")                      # y * W + x
-        E(f"v_mul_lo_u32 v{VT1}, v{VT1}, s{S_LDIN}")
-        E(f"v_and_b32_e32 v{VT0}, 3, v{VTID}")                                # kq
-        E(f"v_lshl_add_u32 v{VT1}, v{VT0}, 2, v{VT1}")
-        E(f"v_lshlrev_b32_e32 v{VT1}, 2, v{VT1}")                             # bytes
+        E(f"v_mad_u32_u24 v{TT(1)}, v{TT(1)}, s{S_W}, v{d}")                      # y * W + x
+        E(f"v_mul_lo_u32 v{TT(1)}, v{TT(1)}, s{S_LDIN}")
+        E(f"v_and_b32_e32 v{TT(0)}, 3, v{VTID}")                                # kq
+        E(f"v_lshl_add_u32 v{TT(1)}, v{TT(0)}, 2, v{TT(1)}")
+        E(f"v_lshlrev_b32_e32 v{TT(1)}, 2, v{TT(1)}")                             # bytes
         E(f"v_mov_b32_e32 v{d}, s{S_OOB}")
         E("s_nop 1")
-        E(f"v_cndmask_b32_e32 v{d}, v{d}, v{VT1}, vcc")
+        E(f"v_cndmask_b32_e32 v{d}, v{d}, v{TT(1)}, vcc")
 
 
 def halo_loads(issue=True, setn=0):
@@ -186,19 +194,27 @@ def form_valu(jp, jj, slot, hf):
     w = "-1.0" if not (jj == 1 and jp == 0) else "1.0"
     a, b, c, d = RAW(hf, 0), RAW(hf, 1), RAW(hf, 2), RAW(hf, 3)
     r = []
-    for e in range(4):
-        r.append(f"v_fma_f32 v{a + e}, s{S_SGN}, v{b + e}, v{a + e}")       # qx = sgn * rb_x + ra_x
-    for e in range(4):
-        r.append(f"v_fma_f32 v{c + e}, s{S_SGN}, v{d + e}, v{c + e}")       # qy
-    for e in range(4):
-        r.append(f"v_fma_f32 v{a + e}, {w}, v{c + e}, v{a + e}")            # v = w * qy + qx
+    if opt("slow_valu"):                  # the first version's forms (VOP3 / SGPR operands), kept for the A/B
+        for e in range(4):
+            r.append(f"v_fma_f32 v{a + e}, s{S_SGN}, v{b + e}, v{a + e}")       # qx = sgn * rb_x + ra_x
+        for e in range(4):
+            r.append(f"v_fma_f32 v{c + e}, s{S_SGN}, v{d + e}, v{c + e}")       # qy
+        for e in range(4):
+            r.append(f"v_fma_f32 v{a + e}, {w}, v{c + e}, v{a + e}")            # v = w * qy + qx
+    else:                                 # the same values bit for bit: fma(sgn, b, a) as v_fmac; fma(+-1, qy, qx) = qx +- qy rounded once
+        for e in range(4):
+            r.append(f"v_fmac_f32_e32 v{a + e}, v{VSGN()}, v{b + e}")
+        for e in range(4):
+            r.append(f"v_fmac_f32_e32 v{c + e}, v{VSGN()}, v{d + e}")
+        for e in range(4):
+            r.append(f"v_{'add' if w == '1.0' else 'sub'}_f32_e32 v{a + e}, v{a + e}, v{c + e}")
     # pairs (0,1) -> piece dword hf*2, (2,3) -> hf*2+1;  temporaries: the b registers
     for piece in range(3):
         for p in range(2):
             r.append(f"v_perm_b32 v{PC(slot, piece) + hf * 2 + p}, v{a + 2 * p + 1}, v{a + 2 * p}, s{S_PERM}")
         if piece < 2:
             for e in range(4):
-                r.append(f"v_and_b32_e32 v{b + e}, s{S_MASK}, v{a + e}")
+                r.append(f"v_and_b32_e32 v{b + e}, {'s' + str(S_MASK) if opt('slow_valu') else 'v' + str(VMASK())}, v{a + e}")
             for e in range(4):
                 r.append(f"v_sub_f32_e32 v{a + e}, v{a + e}, v{b + e}")
     assert len(r) == 34
@@ -317,7 +333,9 @@ def emit_step_spread(jp, s):
 
 
 def emit_step_pp(jp, s):
-    """Ping-pong schedule (option pingpong): a wave alternates a PURE matrix phase (the step's twelve MFMAs back to back) with a
+    """Ping-pong schedule (option pingpong; an experiment of record -- measured 1.8 % slower than the spread schedule, see
+    profiles/r05_asm_experiments.txt -- and not maintained against later changes of the register map: the cold-code temporaries of
+    setup_load / the epilogue would have to move out of the raw set, which it keeps in flight across chunk tops): a wave alternates a PURE matrix phase (the step's twelve MFMAs back to back) with a
     transform phase (wait for the raw operands requested before the burst, 68 VALU into the single operand-piece slot), and the two
     waves of a SIMD run the phases in opposite order -- waves 0-3 (jp 0): M(s) then V(s + 1); waves 4-7 (jp 1): V(s) then M(s) -- so
     one wave's transform always lies beside its partner's burst (tools/ubench: a burst of 8 MFMAs followed by 48 VALU, two waves per
@@ -502,17 +520,17 @@ def emit_chunk(jp):
         E("s_add_u32 s94, s94, s95")
         E("s_lshl_b32 s94, s94, 5")
         E("s_mov_b64 s[96:97], exec")
-        E(f"v_and_b32_e32 v{VT0}, 63, v{VTID}")
-        E(f"v_cmp_eq_u32_e32 vcc, 0, v{VT0}")
+        E(f"v_and_b32_e32 v{TT(0)}, 63, v{VTID}")
+        E(f"v_cmp_eq_u32_e32 vcc, 0, v{TT(0)}")
         E("s_and_b64 exec, exec, vcc")
         for k in range(4):
             a, b = STAMP_PAIRS[2 * k], (STAMP_PAIRS[2 * k + 1] if k < 3 else 92)
             if k == 3:
                 a = STAMP_PAIRS[6]
-            E(f"v_mov_b32_e32 v{VT0}, s{a}")
-            E(f"v_mov_b32_e32 v{VT1}, s{b}")
+            E(f"v_mov_b32_e32 v{TT(0)}, s{a}")
+            E(f"v_mov_b32_e32 v{TT(1)}, s{b}")
             E(f"v_mov_b32_e32 v{VHOFF[0]}, 0")
-            E(f"buffer_store_dwordx2 v[{VT0}:{VT1}], v{VHOFF[0]}, s[{S_OUTR}:{S_OUTR + 3}], s94 offen offset:{8 * k}")
+            E(f"buffer_store_dwordx2 v[{TT(0)}:{TT(1)}], v{VHOFF[0]}, s[{S_OUTR}:{S_OUTR + 3}], s94 offen offset:{8 * k}")
             E("s_waitcnt vmcnt(0)")
         E("s_mov_b64 exec, s[96:97]")
         L(lno)
@@ -522,7 +540,7 @@ def emit_epilogue(jp):
     # free registers: the second operand slot (v188..v199) and raw half 1 (v216..v231); raw half 0 holds the next patch's
     # first reads (spread schedule) and stays untouched
     E0 = 188
-    CQ, VT = VT0, VT1
+    CQ, VT = 224, 225
     VZ0, VZ1, VOUT, VPOOL = E0 + 0, E0 + 1, E0 + 2, E0 + 3
     SCW = [E0 + 4, E0 + 5]
     SHW = [E0 + 6, E0 + 7]
@@ -798,7 +816,7 @@ def emit_chunk_n(jp, c):
 
 
 def emit_epilogue_n(jp):
-    CQ, VT = VT0, VT1
+    CQ, VT = 228, 229
     VZ0, VZ1, VOUT, VPOOL = 188, 189, 190, 191
     e0, e1, e2, e3 = 192, 193, 194, 195
     SC4, SH4 = 196, 216
@@ -1122,6 +1140,8 @@ def emit_prologue():
         E("v_mul_u32_u24_e32 v4, 0x50, v4")
         E(f"v_and_b32_e32 v5, 3, v{VTID}")
         E(f"v_lshl_add_u32 v{VHST[i]}, v5, 4, v4")
+    E(f"v_mov_b32_e32 v{VMASK()}, s{S_MASK}")
+    E(f"v_mov_b32_e32 v{VSGN()}, s{S_SGN}")
     # pipeline lead-in
     E(f"s_mov_b32 s{S_LC}, 0")
     E(f"s_mov_b32 s{S_LP}, 0")
@@ -1196,9 +1216,9 @@ def emit_dump(first_reg):
     E(f"s_and_b32 s{S_OUTR + 1}, s{S_OUT + 1}, 0xffff")
     E(f"s_mov_b32 s{S_OUTR + 2}, 0x7ffffff0")
     E(f"s_mov_b32 s{S_OUTR + 3}, 0x00020000")
-    E(f"v_lshlrev_b32_e32 v{VT0}, 7, v{VTID}")
+    E(f"v_lshlrev_b32_e32 v{TT(0)}, 7, v{VTID}")
     for k in range(8):
-        E(f"buffer_store_dwordx4 {vr(first_reg + 4 * k, 4)}, v{VT0}, s[{S_OUTR}:{S_OUTR + 3}], 0 offen offset:{16 * k}")
+        E(f"buffer_store_dwordx4 {vr(first_reg + 4 * k, 4)}, v{TT(0)}, s[{S_OUTR}:{S_OUTR + 3}], 0 offen offset:{16 * k}")
     E("s_waitcnt vmcnt(0)")
     E("s_endpgm")
 
@@ -1324,8 +1344,8 @@ if os.environ.get("GEN_WINO_VARIANTS"):
         ("_v2", {"no_epilogue": 1, "no_valu": 1}),
         ("_v3", {"no_epilogue": 1, "no_mfma": 1}),
         ("_v4", {"no_epilogue": 1, "no_barrier": 1}),
-        ("_v5", {"pingpong": 1}),
-        ("_v6", {"pingpong": 1, "pp_prio": 1}),
+        ("_v5", {"slow_valu": 1}),
+        ("_v6", {"sp_v0": (1, 5), "sp_v1": (6, 10)}),
         ("_v7", {"prio": ((0, 0, 1, 1), (1, 1, 0, 0))}),
         ("_v8", {"no_epilogue": 1, "stamp": 1}),
         ("_v9", {"no_epilogue": 1, "no_valu": 1, "stamp": 1}),
@@ -1334,7 +1354,7 @@ if os.environ.get("GEN_WINO_VARIANTS"):
         ("_v12", {"no_epilogue": 1, "no_halo": 1, "stamp": 1}),
         ("_v13", {"no_epilogue": 1, "no_ldsread": 1, "stamp": 1}),
         ("_v15", {"no_epilogue": 1, "steptimes": 1}),
-        ("_v16", {"no_epilogue": 1, "steptimes": 1, "pingpong": 1}),
+        ("_v16", {"no_epilogue": 1, "steptimes": 1, "slow_valu": 1}),
         ("_v17", {"prio": ((0, 0, 0, 0), (0, 1, 0, 1))}),
         ("_v18", {"sp_v0": (0, 5), "sp_v1": (6, 11)}),
         ("_v19", {"sp_v0": (0, 5), "sp_v1": (6, 11), "prio": ((0, 0, 0, 0), (1, 0, 1, 0))}),

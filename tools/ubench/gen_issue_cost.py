@@ -26,13 +26,20 @@ def valu_block(kind, n, base=64):
             r.append(f"v_pack_b32_f16 v{d}, v{d + 16}, v{d + 32} op_sel:[1,1,0]")
         elif kind == "cvtpk":
             r.append(f"v_cvt_pk_bf16_f32 v{d}, v{d + 16}, v{d + 32}")
+        elif kind == "fmac":      # VOP2, VGPR operands only
+            r.append(f"v_fmac_f32_e32 v{d}, v{d + 32}, v{d + 16}")
+        elif kind == "andv":      # VOP2 and with the mask in a VGPR
+            r.append(f"v_and_b32_e32 v{d}, v{d + 32}, v{d + 16}")
+        elif kind == "mix2":      # the transform + split with VOP2 / VGPR-only forms: 8 fmac + 4 add, 6 perm, 8 and (VGPR mask), 8 sub
+            seq = ["fmac"] * 8 + ["add"] * 4 + ["perm"] * 2 + ["andv"] * 4 + ["sub"] * 4 + ["perm"] * 2 + ["andv"] * 4 + ["sub"] * 4 + ["perm"] * 2
+            return [valu_block(seq[i % 34], 1, base + (i % 12))[0] for i in range(n)]
         elif kind == "mix":      # the transform + split mix of one half: 12 fma, 6 perm, 8 and, 8 sub
             seq = ["fma_s"] * 12 + ["perm"] * 2 + ["and"] * 4 + ["sub"] * 4 + ["perm"] * 2 + ["and"] * 4 + ["sub"] * 4 + ["perm"] * 2
             return [valu_block(seq[i % 34], 1, base + (i % 12))[0] for i in range(n)]
     return r
 MF = "v_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]"
 MF2 = "v_mfma_f32_32x32x16_bf16 v[32:47], v[16:19], v[20:23], v[32:47]"
-for k in ("fma_s", "fma_v", "perm", "and", "sub", "add", "pack", "cvtpk", "mix"):
+for k in ("fma_s", "perm", "and", "sub", "fmac", "andv", "mix", "mix2"):
     CASES[f"valu_{k}"] = valu_block(k, 48)                         # 48 VALU alone
     body = []
     for i in range(8):
