@@ -96,6 +96,11 @@ size_t convt_x3_floats(int Cin, int Cout);
 hipError_t launch_pack_convt_x3(const float* w, float* Wx, int Cin, int Cout, hipStream_t s);
 bool convt_x3_applicable(const IgemmDesc& d);
 hipError_t launch_convt_x3(const IgemmDesc& d, hipStream_t s);
+// convt_bf16.hip: the bf16-storage ConvTranspose2d(k2,s2) on fragment-ordered bf16 weights (IgemmDesc::wu), 16-byte transposed stores
+size_t convt_bf16f_floats(int Cin, int Cout);
+hipError_t launch_pack_convt_bf16f(const float* w, float* Wf, int Cin, int Cout, hipStream_t s);
+bool convt_bf16f_applicable(const IgemmDesc& d);
+hipError_t launch_convt_bf16f(const IgemmDesc& d, hipStream_t s);
 // the same kernel as the layer's data gradient (KS = 2 gather descriptors whose d.wu holds launch_pack_convt_x3_dgrad's panel)
 size_t convt_x3_dgrad_floats(int Cin, int Cout);
 hipError_t launch_pack_convt_x3_dgrad(const float* w, float* Wx, int Cin, int Cout, hipStream_t s);

@@ -21,6 +21,7 @@ struct Layer {
   int K = 0, Kp = 0, N = 0, Np = 0;
   float *wp = nullptr, *scale = nullptr, *shift = nullptr;
   bool first = false;    // fp32 first convolution (<= 4 input channels): VALU kernel, weights kept in wf
+  bool ctb = false;      // bf16-storage ConvTranspose with Cin % 64 == 0, Cout % 32 == 0: bf16 fragment weights kept in wu (convt_bf16.hip)
   bool ctx3 = false;     // fp32 ConvTranspose with Cin % 32 == 0, Cout % 32 == 0: three-piece fragment weights kept in wu (convt_x3.hip)
   bool wino = false;     // fp32 3x3 layer with Cp % 16 == 0: Winograd-transformed weights kept in wu
   mutable bool wp_dirty = false;   // direct panel wp not yet rebuilt from w_src (packed on first use)

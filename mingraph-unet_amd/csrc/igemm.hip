@@ -835,7 +835,7 @@ bool halo_pool_fusable(const IgemmDesc& d, int dtype) {
 
 const char* igemm_kernel_name(const IgemmDesc& d, int dtype) {
   if (dtype == 1) {
-    if (d.out_mode == 1) return "igemm_kernel<bf16> (ConvTranspose)";
+    if (d.out_mode == 1) return convt_bf16f_applicable(d) ? "convt2x2_bf16_kernel" : "igemm_kernel<bf16> (ConvTranspose)";
     return halo_np<__bf16>(d) ? "conv3x3_halo_kernel<bf16>" : "igemm_kernel<bf16>";
   }
   if (d.out_mode == 1) return convt_x3_applicable(d) ? "convt2x2_x3_kernel" : "igemm_kernel<f32> (ConvTranspose)";
@@ -876,6 +876,7 @@ hipError_t launch_igemm_bf16(const IgemmDesc& d, hipStream_t s) {
   if ((d.Cp & 7) || (d.ldin & 7) || (d.Kp % 64) || d.K > d.Kp || d.split_n) return hipErrorInvalidValue;
   if (d.out_mode == 1) {
     if (d.KS != 1) return hipErrorInvalidValue;
+    if (convt_bf16f_applicable(d)) return launch_convt_bf16f(d, s);
     return launch_tiles<__bf16, 1, 1>(d, s);
   }
   const int np = halo_np<__bf16>(d);

@@ -190,6 +190,9 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     // step: 32-byte row segments per K slice; not kept.)
     L.ctx3 = dtype == MGU_DTYPE_F32 && L.convt && L.Cin % 32 == 0 && L.Cout % 32 == 0 && c->tn.wino_prec != 0 && c->tn.convt_frag;
     if (L.ctx3) total += convt_x3_floats(L.Cin, L.Cout) + convt_x3_dgrad_floats(L.Cin, L.Cout);
+    // bf16 storage: the layer's weights as bf16 MFMA fragments for convt2x2_bf16_kernel (whole-row LDS staging, transposed 16-byte stores)
+    L.ctb = dtype == MGU_DTYPE_BF16 && L.convt && L.Cin % 64 == 0 && L.Cout % 32 == 0 && c->tn.convt_frag;
+    if (L.ctb) total += convt_bf16f_floats(L.Cin, L.Cout);
     if (dtype == MGU_DTYPE_F32 && !L.convt && L.bn.empty()) total += (size_t)rup(L.Cin, 128) * rup(L.KS * L.KS * rup(L.Cout, 4), 32);   // final conv: data-gradient panel
     L.first = !L.convt && L.KS == 3 && first_conv_applicable(dtype, L.Cin, L.Cp, L.Cout, 8, 0);
     if (L.first) total += 9 * 4 * (size_t)L.Cout + first_mfma_floats();
@@ -239,6 +242,7 @@ int mgu_unet_configure(mgu_ctx* c, int in_ch, int ncls, int feat, int depth, int
     L.wug = nullptr, L.wug_valid = false;
     if (L.wino && rup(L.Cout, 4) % 16 == 0) L.wug = p, p += wino_u_floats(L.Cin, rup(L.Cout, 4));
     if (L.ctx3) L.wu = p, p += convt_x3_floats(L.Cin, L.Cout);
+    if (L.ctb) L.wu = p, p += convt_bf16f_floats(L.Cin, L.Cout);
     L.wxg = nullptr, L.wxg_valid = false;
     if (L.ctx3) L.wxg = p, p += convt_x3_dgrad_floats(L.Cin, L.Cout);
     if (c->dtype == MGU_DTYPE_F32 && !L.convt && L.bn.empty()) L.wxg = p, p += (size_t)rup(L.Cin, 128) * rup(L.KS * L.KS * rup(L.Cout, 4), 32);
@@ -364,6 +368,7 @@ int mgud::repack_weights(mgu_ctx* c, hipStream_t s) {
       // the generic panel is read by the fallback kernels only: built on first use when the layer runs on its three-piece fragments
       L.wp_dirty = L.ctx3;
       if (!L.ctx3) HIPCHK(c, launch_pack_convt_w(w, L.wp, c->dtype, L.Cin, L.Cout, L.Kp, s));
+      if (L.ctb) HIPCHK(c, launch_pack_convt_bf16f(w, L.wu, L.Cin, L.Cout, s));
       if (L.ctx3) items.push_back(WinoPackItem{w, L.wu, L.Cout, L.Cin, 0, 0, 0, 0, PACK_CONVT_X3});
       items.push_back(WinoPackItem{b, L.shift, L.Cout, 4, 0, 0, 0, 0, PACK_BIAS_TILE});   // scale unused (nullptr at launch)
       if (L.wxg && c->want_train && c->tn.convt_dgrad_x3 && (L.Cin & 63) == 0 && (L.Cout & 31) == 0) {
