@@ -221,12 +221,15 @@ def form_valu(jp, jj, slot, hf):
     return r
 
 
+FIRST_CHUNK = [False]      # emitting the peeled first chunk of a patch: every accumulator chain starts from the constant 0
+#                            (no clearing of the 128 / 64 accumulators per patch: they were 8 % of the VALU operations of a 64-channel layer)
 def mfmas(jj, mi, slot):
     r = []
     for nt in range(2):
         acc = vr(ACC(jj, nt, mi), 16)
-        for (pa, pb) in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)):
-            r.append(f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(PC(slot, pa), 4)}, {vr(BX(jj, nt, pb), 4)}, {acc}")
+        for k, (pa, pb) in enumerate(((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0))):
+            src = "0" if (FIRST_CHUNK[0] and k == 0 and not opt("zero_acc")) else acc
+            r.append(f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(PC(slot, pa), 4)}, {vr(BX(jj, nt, pb), 4)}, {src}")
     return r
 
 
@@ -724,12 +727,13 @@ def emit_epilogue(jp):
             E(f"v_max_f32_e32 v{pm + e}, v{pm + e}, v{Z(0, 0, 1) + e}")
         E(f"buffer_store_dwordx4 {vr(pm, 4)}, v{VPOOL}, s[{S_POOLR}:{S_POOLR + 3}], 0 offen offset:{nt * 128}")
         L(lnp)
-        # this n tile's accumulators (the registers of the finishing pass) are cleared for the next patch here, beside the
-        # stores and in front of the barrier wait (one instruction of distance to the last store's data registers)
-        E("s_nop 1")
-        for b in sorted(zb):
-            for r in range(16):
-                E(f"v_mov_b32_e32 v{b + r}, 0")
+        # (the accumulators -- registers of the finishing pass -- are NOT cleared: the first chunk of a patch is a peeled copy of the
+        # chunk loop whose accumulator chains start from the constant 0; option zero_acc restores the clearing for the A/B)
+        if opt("zero_acc"):
+            E("s_nop 1")
+            for b in sorted(zb):
+                for r in range(16):
+                    E(f"v_mov_b32_e32 v{b + r}, 0")
         E("s_waitcnt lgkmcnt(0)")
         E("s_barrier")                   # the regions are rewritten by the next pass / receive the next raw chunk
 
@@ -744,8 +748,8 @@ def emit_epilogue(jp):
 # =====================================================================================================================
 def mfmas_n(jj, mi, slot, c):
     acc = vr(ACC(jj, 0, mi), 16)
-    return [f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(PC(slot, pa), 4)}, {vr(WN(c, jj, pb), 4)}, {acc}"
-            for (pa, pb) in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0))]
+    return [f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(PC(slot, pa), 4)}, {vr(WN(c, jj, pb), 4)}, {'0' if (c == 0 and k == 0) else acc}"
+            for k, (pa, pb) in enumerate(((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)))]
 
 
 def emit_step_n(jp, s, c):
@@ -967,10 +971,7 @@ def emit_epilogue_n(jp):
         E(f"v_max_f32_e32 v{pm + e}, v{pm + e}, v{Z(0, 0, 1) + e}")
     E(f"buffer_store_dwordx4 {vr(pm, 4)}, v{VPOOL}, s[{S_POOLR}:{S_POOLR + 3}], 0 offen")
     L(lnp)
-    E("s_nop 1")
-    for r in range(64):
-        E(f"v_mov_b32_e32 v{r}, 0")
-    E("s_waitcnt lgkmcnt(0)")
+    E("s_waitcnt lgkmcnt(0)")            # (no clearing of the accumulators: chunk 0's chains start from the constant 0)
     E("s_barrier")
 
 
@@ -990,6 +991,11 @@ def emit_patch_loop(jp):
     lp, lc = newlabel("patch"), newlabel("chunk")
     L(lp)
     E(f"s_mov_b32 s{S_C}, 0")
+    if not opt("zero_acc"):              # chunk 0, peeled (a layer has at least two chunks: Cp % 32 == 0)
+        FIRST_CHUNK[0] = True
+        emit_chunk(jp)
+        FIRST_CHUNK[0] = False
+        E(f"s_mov_b32 s{S_C}, 1")
     L(lc)
     emit_chunk(jp)
     E(f"s_add_u32 s{S_C}, s{S_C}, 1")
@@ -1171,8 +1177,6 @@ def emit_prologue():
             setup_load()
             L(lsk)
             halo_loads(True, setn)
-        for r in range(64):
-            E(f"v_mov_b32_e32 v{r}, 0")
         E("s_waitcnt lgkmcnt(0)")
         E("s_barrier")
         return
@@ -1201,8 +1205,9 @@ def emit_prologue():
         for nt in range(2):
             for p in range(3):
                 E(weight_load(jj, nt, p))
-    for r in range(128):
-        E(f"v_mov_b32_e32 v{r}, 0")
+    if opt("zero_acc") or opt("no_epilogue"):
+        for r in range(128):
+            E(f"v_mov_b32_e32 v{r}, 0")
     E("s_waitcnt lgkmcnt(0)")
     E("s_barrier")
 
@@ -1359,6 +1364,7 @@ if os.environ.get("GEN_WINO_VARIANTS"):
         ("_v18", {"sp_v0": (0, 5), "sp_v1": (6, 11)}),
         ("_v19", {"sp_v0": (0, 5), "sp_v1": (6, 11), "prio": ((0, 0, 0, 0), (1, 0, 1, 0))}),
         ("_v20", {"no_epilogue": 1, "steptimes": 1, "sp_v0": (0, 5), "sp_v1": (6, 11)}),
+        ("_v21", {"zero_acc": 1}),
         ("_v14", {"no_epilogue": 1, "no_wload": 1, "no_halo": 1, "no_ldsread": 1, "no_valu": 1, "no_barrier": 1, "stamp": 1}),
     ]
 

@@ -36,7 +36,10 @@ def test_generated_streams_pass_the_lint(tmp_path):
     text = _generate(tmp_path)
     errs, n = lint.check(text)
     assert n == 3 and not errs, errs[:5]          # the wide kernel and the two narrow kernels
-    assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", text)) == 2 * (48 + 24 * 2 + 24 * 4)
+    # two component-pair code paths each; wide: the peeled first chunk + the chunk loop (48 MFMAs per chunk); narrow: 24 per unrolled chunk
+    assert len(re.findall(r"v_mfma_f32_32x32x16_bf16", text)) == 2 * (2 * 48 + 24 * 2 + 24 * 4)
+    # every accumulator chain of a patch starts from the constant 0 (no clearing pass): 8 tuples in the wide kernel, 4 in a narrow one
+    assert len(re.findall(r"v_mfma_f32_32x32x16_bf16 v\[\d+:\d+\], v\[\d+:\d+\], v\[\d+:\d+\], 0\n", text)) == 2 * (8 + 4 + 4)
 
 
 def test_shipping_kernels_of_a_variants_build_pass_the_lint(tmp_path):

@@ -30,6 +30,22 @@ def valu_block(kind, n, base=64):
             r.append(f"v_fmac_f32_e32 v{d}, v{d + 32}, v{d + 16}")
         elif kind == "andv":      # VOP2 and with the mask in a VGPR
             r.append(f"v_and_b32_e32 v{d}, v{d + 32}, v{d + 16}")
+        elif kind == "pkadd":     # VOP3P packed fp32: two adds per lane and instruction on aligned register pairs
+            dd = base + 2 * (i % 8)
+            r.append(f"v_pk_add_f32 v[{dd}:{dd + 1}], v[{dd + 16}:{dd + 17}], v[{dd + 32}:{dd + 33}] neg_lo:[0,1] neg_hi:[0,1]")
+        elif kind == "pkfma":     # packed fma, one factor broadcast from the low half of a pair
+            dd = base + 2 * (i % 8)
+            r.append(f"v_pk_fma_f32 v[{dd}:{dd + 1}], v[{dd + 16}:{dd + 17}], v[{dd + 32}:{dd + 33}], v[{dd}:{dd + 1}] op_sel_hi:[1,0,1]")
+        elif kind == "dot2c":     # VOP2 v_dot2c_f32_bf16: d += a.bf16x2 . b.bf16x2 (the residual v - hi straight from the packed piece)
+            r.append(f"v_dot2c_f32_bf16_e32 v{d}, v{d + 32}, v{d + 16}")
+        elif kind == "dot2cs":    # the constant pair in an SGPR
+            r.append(f"v_dot2c_f32_bf16_e32 v{d}, s23, v{d + 16}")
+        elif kind == "mix4":      # transform + split with the residuals by v_dot2c: 8 fmac + 4 add, 6 perm, 8 dot2c = 26 per half
+            seq = ["fmac"] * 8 + ["add"] * 4 + ["perm"] * 2 + ["dot2c"] * 4 + ["perm"] * 2 + ["dot2c"] * 4 + ["perm"] * 2
+            return [valu_block(seq[i % 26], 1, base + (i % 12))[0] for i in range(n)]
+        elif kind == "mix3":      # the transform + split on packed adds: per 8 values 4 pk transform, 8 and, 4 pk sub, 8 and, 4 pk sub, 12 perm -> 26 per 8
+            seq = ["pkfma"] * 4 + ["pkadd"] * 2 + ["perm"] * 2 + ["andv"] * 4 + ["pkadd"] * 2 + ["perm"] * 2 + ["andv"] * 4 + ["pkadd"] * 2 + ["perm"] * 2
+            return [valu_block(seq[i % 24], 1, base + 2 * (i % 6))[0] for i in range(n)]
         elif kind == "mix2":      # the transform + split with VOP2 / VGPR-only forms: 8 fmac + 4 add, 6 perm, 8 and (VGPR mask), 8 sub
             seq = ["fmac"] * 8 + ["add"] * 4 + ["perm"] * 2 + ["andv"] * 4 + ["sub"] * 4 + ["perm"] * 2 + ["andv"] * 4 + ["sub"] * 4 + ["perm"] * 2
             return [valu_block(seq[i % 34], 1, base + (i % 12))[0] for i in range(n)]
@@ -39,7 +55,7 @@ def valu_block(kind, n, base=64):
     return r
 MF = "v_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]"
 MF2 = "v_mfma_f32_32x32x16_bf16 v[32:47], v[16:19], v[20:23], v[32:47]"
-for k in ("fma_s", "perm", "and", "sub", "fmac", "andv", "mix", "mix2"):
+for k in ("fma_s", "perm", "and", "sub", "fmac", "andv", "pkadd", "pkfma", "dot2c", "dot2cs", "mix", "mix2", "mix3", "mix4"):
     CASES[f"valu_{k}"] = valu_block(k, 48)                         # 48 VALU alone
     body = []
     for i in range(8):
@@ -51,6 +67,20 @@ for k in ("fma_s", "perm", "and", "sub", "fmac", "andv", "mix", "mix2"):
         body.append(MF)
         body += valu_block(k, 8, 64)
     CASES[f"mfma8_{k}"] = body
+# accumulators in AccVGPRs (accum_offset 128: v0-127 + a0-127): does the VALU in the shadow of an MFMA get cheaper when C / D are not in the
+# architectural file?
+MFA = "v_mfma_f32_32x32x16_bf16 a[0:15], v[16:19], v[20:23], a[0:15]"
+ACC_CASES = set()
+for k in ("fmac", "mix2"):
+    for g in (6, 8):
+        body = []
+        for i in range(8):
+            body.append(MFA)
+            body += valu_block(k, g, 64)
+        CASES[f"mfma{g}acc_{k}"] = body
+        ACC_CASES.add(f"mfma{g}acc_{k}")
+CASES["mfma_only_acc"] = [MFA] * 8
+ACC_CASES.add("mfma_only_acc")
 CASES["mfma_only"] = [MF] * 8
 CASES["mfma_2acc"] = [MF, MF2] * 4
 body = []
@@ -64,10 +94,13 @@ meta = []
 for name, body in CASES.items():
     k = "ub_" + name
     out.append(f"\t.text\n\t.protected {k}\n\t.globl {k}\n\t.p2align 8\n\t.type {k},@function\n{k}:")
-    out += ["\ts_load_dwordx2 s[4:5], s[0:1], 0x0", "\ts_mov_b32 s20, 1.0", "\ts_mov_b32 s21, 0x07060302", "\ts_mov_b32 s22, 0xffff0000",
+    out += ["\ts_load_dwordx2 s[4:5], s[0:1], 0x0", "\ts_mov_b32 s20, 1.0", "\ts_mov_b32 s21, 0x07060302", "\ts_mov_b32 s22, 0xffff0000", "\ts_mov_b32 s23, 0x0000bf80",
             "\tv_mov_b32 v200, v0"]
     for r in range(24, 128):
         out.append(f"\tv_mov_b32_e32 v{r}, 1.0")
+    if name in ACC_CASES:
+        for r in range(0, 16):
+            out.append(f"\tv_accvgpr_write_b32 a{r}, 0")
     for r in range(0, 24):
         out.append(f"\tv_mov_b32_e32 v{r}, 0")
     out += ["\ts_waitcnt lgkmcnt(0)", "\ts_barrier", "\ts_memtime s[8:9]", "\ts_waitcnt lgkmcnt(0)", f"\ts_movk_i32 s10, {REP}", f".L{k}:"]
@@ -89,7 +122,7 @@ for name, body in CASES.items():
 \t\t.amdhsa_system_vgpr_workitem_id 0
 \t\t.amdhsa_next_free_vgpr 256
 \t\t.amdhsa_next_free_sgpr 32
-\t\t.amdhsa_accum_offset 256
+\t\t.amdhsa_accum_offset {128 if name in ACC_CASES else 256}
 \t\t.amdhsa_reserve_vcc 1
 \t\t.amdhsa_float_denorm_mode_32 3
 \t\t.amdhsa_float_denorm_mode_16_64 3
@@ -97,7 +130,7 @@ for name, body in CASES.items():
 \t\t.amdhsa_ieee_mode 1
 \t.end_amdhsa_kernel
 \t.text""")
-    meta.append(f"""  - .agpr_count: 0
+    meta.append(f"""  - .agpr_count: {128 if name in ACC_CASES else 0}
     .args:
       - .offset: 0
         .size: 8
@@ -112,7 +145,7 @@ for name, body in CASES.items():
     .sgpr_count: 40
     .sgpr_spill_count: 0
     .symbol: {k}.kd
-    .vgpr_count: 256
+    .vgpr_count: {128 if name in ACC_CASES else 256}
     .vgpr_spill_count: 0
     .wavefront_size: 64""")
 out.append("\t.amdgpu_metadata\n---\namdhsa.kernels:")
