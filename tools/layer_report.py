@@ -26,7 +26,10 @@ for (name, fl), r in zip(layers, last):
     tot += d
     kname = r["Kernel_Name"]
     tag = "head<" if ("head_kernel" in kname or "patch_mean" in kname) else "first<" if "conv3x3_first" in kname else "wino<" if "wino3x3" in kname else "wino_asm<" + kname.split("_gfx950")[0][-5:] + " " if "mgu_wino_cp" in kname else "halo<" if "halo" in kname else "convt_x3<" if "convt2x2" in kname else "igemm<"
-    kn = tag + (kname.split("<")[1].split(">")[0].replace(" ", "") if "<" in kname else "?") + ">"
+    if "mgu_wino_cp" in kname:      # hand-written code objects: mgu_wino_cp2_gfx950 (wide), mgu_wino_cp1r2/4_gfx950 (narrow, 2 / 4 resident chunks)
+        kn = "wino_asm<" + kname.split("mgu_wino_")[1].split("_gfx950")[0] + ">"
+    else:
+        kn = tag + (kname.split("<")[1].split(">")[0].replace(" ", "") if "<" in kname else "?") + ">"
     print(f"{name:9s} {kn:22s} grid={r['Grid_Size_X']:>9s}x{r['Grid_Size_Y']:>4s} {d:8.1f} us {fl/d/1e6:7.1f} TF/s vgpr={r['VGPR_Count']}+{r['Accum_VGPR_Count']} lds={r['LDS_Block_Size']}")
 print("total us", round(tot, 1))
 oth = [r for r in rows if r not in ig]
