@@ -1,5 +1,9 @@
 """Runs the issue-cost micro-benchmarks (tools/ubench/gen_issue_cost.py): one workgroup per CU of 256 threads (one wave per SIMD) and of 512
-threads (two waves per SIMD); prints cycles per loop body and per instruction."""
+threads (two waves per SIMD); prints cycles per loop body and per instruction.
+Build (in the build container; the .s and the .hsaco are git-ignored, the .hsaco travels with the gpurun snapshot):
+  python3 tools/ubench/gen_issue_cost.py tools/ubench/issue_cost.s
+  /opt/rocm/lib/llvm/bin/clang -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c tools/ubench/issue_cost.s -o /tmp/ic.co
+  /opt/rocm/lib/llvm/bin/ld.lld -shared /tmp/ic.co -o tools/ubench/issue_cost.hsaco"""
 import ctypes as C, os, sys
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
