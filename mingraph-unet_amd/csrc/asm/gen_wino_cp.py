@@ -545,12 +545,14 @@ def emit_epilogue(jp):
     E0 = 188
     CQ, VT = 224, 225
     VZ0, VZ1, VOUT, VPOOL = E0 + 0, E0 + 1, E0 + 2, E0 + 3
-    SCW = [E0 + 4, E0 + 5]
-    SHW = [E0 + 6, E0 + 7]
     e0, e1, e2, e3 = E0 + 8, E0 + 9, E0 + 10, E0 + 11
-    TMP = [216 + i for i in range(8)]
-    if opt("pingpong"):                   # the whole raw set may hold the next patch's first operands: four share temporaries
-        TMP = [e0, e1, e2, e3] * 2        # (e0..e3 are dead once the addresses are formed)
+    TMP = [216 + i for i in range(4)] * 2
+    # per-channel scale / shift of the FINISHING unit's channel quad, both n tiles (reader side: two of the four shares are then plain
+    # copies of the accumulators and the other two one add / subtract -- 32 instead of 96 VALU per n tile in the write phase, 16 fma in
+    # the finishing pass); e0..e3 are dead once the addresses are formed
+    SC4 = [E0 + 4, 226]
+    SH4 = [e0, 220]
+    assert not opt("pingpong")
     E("s_nop 7")
     E("s_nop 7")
     E("s_nop 7")
@@ -604,32 +606,20 @@ def emit_epilogue(jp):
     E(f"v_lshl_add_u32 v{e3}, v{CQ}, 2, v{e3}")
     E(f"v_lshlrev_b32_e32 v{VPOOL}, 2, v{e3}")
     E(f"v_add_u32_e32 v{VPOOL}, s{S_N64X4}, v{VPOOL}")
-    # per-channel scale / shift of the writer lane (n = nblock * 64 + nt * 32 + (tid & 31))
-    E(f"v_and_b32_e32 v{e0}, 31, v{VTID}")
-    E(f"v_lshlrev_b32_e32 v{e0}, 2, v{e0}")
-    lsn, lsd = newlabel("scn"), newlabel("scd")
-    E(f"s_cmp_eq_u64 s[{S_SCALE}:{S_SCALE + 1}], 0")          # no scale array (a data-gradient convolution): 1
-    E(f"s_cbranch_scc1 {lsn}")
-    for nt in range(2):
-        E(f"buffer_load_dword v{SCW[nt]}, v{e0}, s[{S_SCR}:{S_SCR + 3}], s{S_N64X4} offen offset:{nt * 128}")
-    E(f"s_branch {lsd}")
-    L(lsn)
-    for nt in range(2):
-        E(f"v_mov_b32_e32 v{SCW[nt]}, 1.0")
-    L(lsd)
-    lz, ld = newlabel("shz"), newlabel("shd")
-    if jp == 0:
-        E(f"s_cmp_lg_u32 s{S_WI}, 1")
-        E(f"s_cbranch_scc1 {lz}")
-        E(f"s_cmp_eq_u64 s[{S_SHIFT}:{S_SHIFT + 1}], 0")
-        E(f"s_cbranch_scc1 {lz}")
+    # scale / shift quads (n0 = nblock * 64 + nt * 32 + cq * 4): requested first, used last; a missing array is 1 / 0
+    E(f"v_lshlrev_b32_e32 v{CQ}, 4, v{CQ}")                   # (cq is not needed any more)
+    for (ptr, rs, regs, dflt) in ((S_SCALE, S_SCR, SC4, "1.0"), (S_SHIFT, S_SHR, SH4, "0")):
+        ln, ldn = newlabel("nul"), newlabel("nud")
+        E(f"s_cmp_eq_u64 s[{ptr}:{ptr + 1}], 0")
+        E(f"s_cbranch_scc1 {ln}")
         for nt in range(2):
-            E(f"buffer_load_dword v{SHW[nt]}, v{e0}, s[{S_SHR}:{S_SHR + 3}], s{S_N64X4} offen offset:{nt * 128}")
-        E(f"s_branch {ld}")
-        L(lz)
-    for nt in range(2):
-        E(f"v_mov_b32_e32 v{SHW[nt]}, 0")
-    L(ld)
+            E(f"buffer_load_dwordx4 {vr(regs[nt], 4)}, v{CQ}, s[{rs}:{rs + 3}], s{S_N64X4} offen offset:{nt * 128}")
+        E(f"s_branch {ldn}")
+        L(ln)
+        for nt in range(2):
+            for e in range(4):
+                E(f"v_mov_b32_e32 v{regs[nt] + e}, {dflt}")
+        L(ldn)
     # add-TID bases of this wave's two shares
     #   q = 0: jp 0 -> region (0,0) = slot 0 (the consumed raw buffer, even chunk count), jp 1 -> region (0,1) = slot 1
     #   q = 1: slot 2 + jp, biased by ZBIAS
@@ -642,41 +632,31 @@ def emit_epilogue(jp):
     E("s_barrier")                       # every wave has finished reading the consumed raw buffer
     E("s_waitcnt vmcnt(0)")
     for nt in range(2):
-        def share(q, mi, r, t):
+        def share(q, mi, r, t):          # -> the register that holds the share;  jp 0: q0 = m0 + m1, q1 = m1;  jp 1: q0 = m0, q1 = -m0 - m1
             m0, m1 = ACC(0, nt, mi) + r, ACC(1, nt, mi) + r
             if jp == 0 and q == 0:
                 E(f"v_add_f32_e32 v{t}, v{m0}, v{m1}")
-                E(f"v_fma_f32 v{t}, v{SCW[nt]}, v{t}, v{SHW[nt]}")
-            elif jp == 0:
-                E(f"v_fma_f32 v{t}, v{m1}, v{SCW[nt]}, v{SHW[nt]}")
-            elif q == 0:
-                E(f"v_fma_f32 v{t}, v{m0}, v{SCW[nt]}, v{SHW[nt]}")
-            else:
-                E(f"v_sub_f32_e64 v{t}, -v{m0}, v{m1}")
-                E(f"v_fma_f32 v{t}, v{SCW[nt]}, v{t}, v{SHW[nt]}")
+                return t
+            if jp == 0:
+                return m1
+            if q == 0:
+                return m0
+            E(f"v_sub_f32_e64 v{t}, -v{m0}, v{m1}")
+            return t
         for q in range(2):
             E(f"s_mov_b32 m0, s{S_T[q]}")
             E("s_nop 0")
-            if "noaddtid" in DEBUG:   # ordinary stores with a VGPR address (debug A/B of the add-TID form)
-                E(f"v_and_b32_e32 v{e0}, 63, v{VTID}")
-                E(f"v_lshlrev_b32_e32 v{e0}, 2, v{e0}")
-                E(f"v_add_u32_e32 v{e0}, s{S_T[q]}, v{e0}")
-                if q:
-                    E(f"v_add_u32_e32 v{e0}, 0x{ZBIAS:x}, v{e0}")
             g = 0
             for mi in range(2):
                 for r0 in range(0, 16, 4):
                     ts = TMP[(g & 1) * 4:(g & 1) * 4 + 4]
                     g += 1
-                    for k in range(4):
-                        share(q, mi, r0 + k, ts[k])
+                    src = [share(q, mi, r0 + k, ts[k]) for k in range(4)]
                     E("s_nop 0")
                     for k in range(4):
                         off = (32 * mi + 2 * (r0 + k)) * 128 + (ZBIAS if q else 0)
-                        if "noaddtid" in DEBUG:
-                            E(f"ds_write_b32 v{e0}, v{ts[k]} offset:{off - (ZBIAS if q else 0)}")
-                        else:
-                            E(f"ds_write_addtid_b32 v{ts[k]} offset:{off}")
+                        assert "noaddtid" not in DEBUG
+                        E(f"ds_write_addtid_b32 v{src[k]} offset:{off}")
         E("s_waitcnt lgkmcnt(0)")
         E("s_barrier")
         # finishing pass of unit (T, cq): 16 share reads into the dead accumulators of this n tile
@@ -702,6 +682,9 @@ def emit_epilogue(jp):
                 E(f"v_sub_f32_e32 v{yb + e}, v{Z(q, 0, 1) + e}, v{Z(q, 0, 2) + e}")
             for e in range(4):
                 E(f"v_sub_f32_e32 v{yb + e}, v{yb + e}, v{Z(q, 0, 3) + e}")                        # (z1 - z2) - z3
+            for y in (ya, yb):
+                for e in range(4):
+                    E(f"v_fma_f32 v{y + e}, v{SC4[nt] + e}, v{y + e}, v{SH4[nt] + e}")
         lnr = newlabel("norelu")
         E(f"s_cmp_eq_u32 s{S_RELU}, 0")
         E(f"s_cbranch_scc1 {lnr}")

@@ -1171,10 +1171,12 @@ __global__ __launch_bounds__(512) void wino3x3_cp_kernel(const IgemmDesc d, cons
     // unconditionally (clamped index) and BEFORE the first output store of the patch: the wait for a load is a wait for every
     // older memory operation of the wave (vmcnt retires in order), so a load -- or a scratch reload of one -- behind the
     // previous pass's stores waits for their HBM round trip (measured: the whole gain of the barrier-light exchange).
-    // Narrow inference variants only: the wide kernel and the train-mode (STATS) variants keep the writer-side form -- they sit at 256
-    // registers with spills, and the eight extra live registers per n tile add to those (wide: 12 -> 28 bytes of scratch per lane
-    // and +0.6 % per launch, measured; STATS: 72 -> 136 bytes).
-    constexpr bool RSC = !STATS && NTB == 1;
+    // Inference variants: the train-mode (STATS) variants keep the writer-side form -- they sit at 256 registers with spills, and the
+    // eight extra live registers per n tile add to those (STATS: 72 -> 136 bytes of scratch per lane).  The wide inference kernel
+    // pays 12 -> 28 bytes of scratch and +0.6 % per launch for it in THIS C++ form, but it is the fallback now: the assembly kernel
+    // (csrc/asm/gen_wino_cp.py) that runs these layers has the registers (the dead accumulators) and saves 96 VALU per patch and wave
+    // with the reader-side form, and the two must stay bit-for-bit equal.
+    constexpr bool RSC = !STATS;
     f32x4 sc4[NTB], sh4[NTB];
     float scw[NTB], shw[NTB];
 #pragma unroll
