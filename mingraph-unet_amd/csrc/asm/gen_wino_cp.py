@@ -539,6 +539,40 @@ def emit_chunk(jp):
         L(lno)
 
 
+def pk2(op, d, a, b, neg_a=False, neg_b=False):
+    """two fp32 operations per lane in one VOP3P instruction on even-aligned register pairs (bit-identical to the scalar forms).
+    Only for the epilogue: next to an MFMA in flight the packed forms wait for the matrix pipe (tools/ubench)."""
+    assert d % 2 == 0 and a % 2 == 0 and b % 2 == 0
+    mod = ""
+    if neg_a or neg_b:
+        mod = f" neg_lo:[{int(neg_a)},{int(neg_b)}] neg_hi:[{int(neg_a)},{int(neg_b)}]"
+    return f"v_pk_{op}_f32 v[{d}:{d + 1}], v[{a}:{a + 1}], v[{b}:{b + 1}]{mod}"
+
+
+def pkfma2(d, a, b, c):
+    assert d % 2 == 0 and a % 2 == 0 and b % 2 == 0 and c % 2 == 0
+    return f"v_pk_fma_f32 v[{d}:{d + 1}], v[{a}:{a + 1}], v[{b}:{b + 1}], v[{c}:{c + 1}]"
+
+
+def emit_finish_math(Z, q, SCq, SHq):
+    """z_i = share(jp 0) + share(jp 1); ya = (z0 + z1) + z2; yb = (z1 - z2) - z3; y = sc * y + sh -- the scalar sequence's values, packed"""
+    for i in range(4):
+        for e in (0, 2):
+            E(pk2("add", Z(q, 0, i) + e, Z(q, 0, i) + e, Z(q, 1, i) + e))
+    ya, yb = Z(q, 1, 0), Z(q, 1, 1)
+    for e in (0, 2):
+        E(pk2("add", ya + e, Z(q, 0, 0) + e, Z(q, 0, 1) + e))
+    for e in (0, 2):
+        E(pk2("add", ya + e, ya + e, Z(q, 0, 2) + e))
+    for e in (0, 2):
+        E(pk2("add", yb + e, Z(q, 0, 1) + e, Z(q, 0, 2) + e, neg_b=True))
+    for e in (0, 2):
+        E(pk2("add", yb + e, yb + e, Z(q, 0, 3) + e, neg_b=True))
+    for y in (ya, yb):
+        for e in (0, 2):
+            E(pkfma2(y + e, SCq + e, y + e, SHq + e))
+
+
 def emit_epilogue(jp):
     # free registers: the second operand slot (v188..v199) and raw half 1 (v216..v231); raw half 0 holds the next patch's
     # first reads (spread schedule) and stays untouched
@@ -630,19 +664,20 @@ def emit_epilogue(jp):
     E(f"s_add_u32 s{S_T[1]}, s{S_T[1]}, 0x{(2 + jp) * RAWB - ZBIAS:x}")
     E("s_waitcnt lgkmcnt(0)")
     E("s_barrier")                       # every wave has finished reading the consumed raw buffer
-    E("s_waitcnt vmcnt(0)")
+    # (no vmcnt wait here: the write phase reads accumulators only; the scale / shift quads requested above are first needed by the
+    # finishing pass of n tile 0, a whole write phase and a barrier later)
     for nt in range(2):
-        def share(q, mi, r, t):          # -> the register that holds the share;  jp 0: q0 = m0 + m1, q1 = m1;  jp 1: q0 = m0, q1 = -m0 - m1
+        def share2(q, mi, r, t):         # -> the registers of the shares of accumulators r, r + 1;  jp 0: q0 = m0 + m1, q1 = m1;  jp 1: q0 = m0, q1 = -m0 - m1
             m0, m1 = ACC(0, nt, mi) + r, ACC(1, nt, mi) + r
             if jp == 0 and q == 0:
-                E(f"v_add_f32_e32 v{t}, v{m0}, v{m1}")
-                return t
+                E(pk2("add", t, m0, m1))
+                return [t, t + 1]
             if jp == 0:
-                return m1
+                return [m1, m1 + 1]
             if q == 0:
-                return m0
-            E(f"v_sub_f32_e64 v{t}, -v{m0}, v{m1}")
-            return t
+                return [m0, m0 + 1]
+            E(pk2("add", t, m0, m1, neg_a=True, neg_b=True))
+            return [t, t + 1]
         for q in range(2):
             E(f"s_mov_b32 m0, s{S_T[q]}")
             E("s_nop 0")
@@ -651,7 +686,7 @@ def emit_epilogue(jp):
                 for r0 in range(0, 16, 4):
                     ts = TMP[(g & 1) * 4:(g & 1) * 4 + 4]
                     g += 1
-                    src = [share(q, mi, r0 + k, ts[k]) for k in range(4)]
+                    src = share2(q, mi, r0, ts[0]) + share2(q, mi, r0 + 2, ts[2])
                     E("s_nop 0")
                     for k in range(4):
                         off = (32 * mi + 2 * (r0 + k)) * 128 + (ZBIAS if q else 0)
@@ -668,23 +703,11 @@ def emit_epilogue(jp):
             for j in range(2):
                 for i in range(4):
                     E(f"ds_read_b128 {vr(Z(q, j, i), 4)}, v{VZ1 if q else VZ0} offset:{j * RAWB + i * 8192}")
+        # the q = 0 half of the reads first (LDS operations of a wave return in order): its arithmetic runs while the q = 1 half lands
+        E("s_waitcnt vmcnt(0) lgkmcnt(8)" if nt == 0 else "s_waitcnt lgkmcnt(8)")
+        emit_finish_math(Z, 0, SC4[nt], SH4[nt])
         E("s_waitcnt lgkmcnt(0)")
-        for q in range(2):
-            for i in range(4):
-                for e in range(4):
-                    E(f"v_add_f32_e32 v{Z(q, 0, i) + e}, v{Z(q, 0, i) + e}, v{Z(q, 1, i) + e}")     # z_i
-            ya, yb = Z(q, 1, 0), Z(q, 1, 1)
-            for e in range(4):
-                E(f"v_add_f32_e32 v{ya + e}, v{Z(q, 0, 0) + e}, v{Z(q, 0, 1) + e}")
-            for e in range(4):
-                E(f"v_add_f32_e32 v{ya + e}, v{ya + e}, v{Z(q, 0, 2) + e}")                        # (z0 + z1) + z2
-            for e in range(4):
-                E(f"v_sub_f32_e32 v{yb + e}, v{Z(q, 0, 1) + e}, v{Z(q, 0, 2) + e}")
-            for e in range(4):
-                E(f"v_sub_f32_e32 v{yb + e}, v{yb + e}, v{Z(q, 0, 3) + e}")                        # (z1 - z2) - z3
-            for y in (ya, yb):
-                for e in range(4):
-                    E(f"v_fma_f32 v{y + e}, v{SC4[nt] + e}, v{y + e}, v{SH4[nt] + e}")
+        emit_finish_math(Z, 1, SC4[nt], SH4[nt])
         lnr = newlabel("norelu")
         E(f"s_cmp_eq_u32 s{S_RELU}, 0")
         E(f"s_cbranch_scc1 {lnr}")
@@ -886,18 +909,18 @@ def emit_epilogue_n(jp):
                 ts = TMP[(g & 1) * 4:(g & 1) * 4 + 4]
                 g += 1
                 src = []
-                for k in range(4):
+                for k in (0, 2):
                     m0, m1 = ACC(0, 0, mi) + r0 + k, ACC(1, 0, mi) + r0 + k
                     if jp == 0 and q == 0:
-                        E(f"v_add_f32_e32 v{ts[k]}, v{m0}, v{m1}")
-                        src.append(ts[k])
+                        E(pk2("add", ts[k], m0, m1))
+                        src += [ts[k], ts[k] + 1]
                     elif jp == 0:
-                        src.append(m1)
+                        src += [m1, m1 + 1]
                     elif q == 0:
-                        src.append(m0)
+                        src += [m0, m0 + 1]
                     else:
-                        E(f"v_sub_f32_e64 v{ts[k]}, -v{m0}, v{m1}")
-                        src.append(ts[k])
+                        E(pk2("add", ts[k], m0, m1, neg_a=True, neg_b=True))
+                        src += [ts[k], ts[k] + 1]
                 E("s_nop 0")
                 for k in range(4):
                     off = (32 * mi + 2 * (r0 + k)) * 128 + (ZBIAS if q else 0)
@@ -912,23 +935,10 @@ def emit_epilogue_n(jp):
         for j in range(2):
             for i in range(4):
                 E(f"ds_read_b128 {vr(Z(q, j, i), 4)}, v{VZ1 if q else VZ0} offset:{j * RAWB + i * 8192}")
-    E("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    for q in range(2):
-        for i in range(4):
-            for e in range(4):
-                E(f"v_add_f32_e32 v{Z(q, 0, i) + e}, v{Z(q, 0, i) + e}, v{Z(q, 1, i) + e}")
-        ya, yb = Z(q, 1, 0), Z(q, 1, 1)
-        for e in range(4):
-            E(f"v_add_f32_e32 v{ya + e}, v{Z(q, 0, 0) + e}, v{Z(q, 0, 1) + e}")
-        for e in range(4):
-            E(f"v_add_f32_e32 v{ya + e}, v{ya + e}, v{Z(q, 0, 2) + e}")
-        for e in range(4):
-            E(f"v_sub_f32_e32 v{yb + e}, v{Z(q, 0, 1) + e}, v{Z(q, 0, 2) + e}")
-        for e in range(4):
-            E(f"v_sub_f32_e32 v{yb + e}, v{yb + e}, v{Z(q, 0, 3) + e}")
-        for y in (ya, yb):
-            for e in range(4):
-                E(f"v_fma_f32 v{y + e}, v{SC4 + e}, v{y + e}, v{SH4 + e}")
+    E("s_waitcnt vmcnt(0) lgkmcnt(8)")   # scale / shift, and the q = 0 half of the reads; its arithmetic runs while the q = 1 half lands
+    emit_finish_math(Z, 0, SC4, SH4)
+    E("s_waitcnt lgkmcnt(0)")
+    emit_finish_math(Z, 1, SC4, SH4)
     lnr = newlabel("norelu")
     E(f"s_cmp_eq_u32 s{S_RELU}, 0")
     E(f"s_cbranch_scc1 {lnr}")
