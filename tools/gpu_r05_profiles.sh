@@ -10,6 +10,8 @@ timeout -k 10 300 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_benc
 timeout -k 10 300 python bench.py --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_c3prec_bf16.json.log 2>&1; echo "bench bf16 rc=$?"
 timeout -k 10 300 python bench.py --mode train --steps 10 --warmup 3 > gpurun_out/${TAG}_bench_train_c5.json.log 2>&1; echo "bench train rc=$?"
 timeout -k 10 600 python bench.py --workload c4 --steps 5 --warmup 2 > gpurun_out/${TAG}_bench_c4.json.log 2>&1; echo "bench c4 rc=$?"
+# box calibration: boxes of the pool differ by +-4 %; the same step on the C++ kernels (unchanged since round 4) beside the assembly kernels
+timeout -k 10 300 python tools/ab_env_step.py 3 - MGU_WINO_ASM=0 > gpurun_out/${TAG}_ab_asm_cpp.txt 2>&1; echo "ab rc=$?"
 prof() { # name warm steps args...
   local name=$1 warm=$2 steps=$3; shift 3
   rm -rf gpurun_out/prof_$name

@@ -5,7 +5,8 @@ root = sys.argv[1]
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 import os
-rows = list(csv.DictReader(open(max(glob.glob(root + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime))))
+rows = sorted(csv.DictReader(open(max(glob.glob(root + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime))),
+              key=lambda r: int(r["Start_Timestamp"]))   # (the trace file is not always in dispatch order)
 ig = [r for r in rows if any(t in r["Kernel_Name"] for t in ("igemm", "convt2x2", "conv3x3_halo", "conv3x3_first", "wino3x3", "mgu_wino_cp", "head_kernel", "patch_mean_kernel"))]
 last = ig[-23:]   # the 23 conv launches of the last U-Net forward
 def convf(h, cin, cout): return 2 * B * h * h * 9 * cin * cout
